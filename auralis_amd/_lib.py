@@ -1,0 +1,300 @@
+"""ctypes binding of include/auralis_amd.h (the stub a reference maintainer would add).
+
+There is deliberately no fallback: if the HIP library is missing or no MI355X is visible, loading /
+engine creation raises.  Nothing here imports oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_C", "libauralis_amd.so")
+
+
+class AurError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"auralis_amd error {code}: {msg}")
+        self.code = code
+
+
+class aur_config(C.Structure):
+    _fields_ = [("n_layer", C.c_int32), ("max_seqs", C.c_int32), ("max_prefill_rows", C.c_int32),
+                ("max_speakers", C.c_int32), ("vocoder_min_batch", C.c_int32), ("profile", C.c_int32)]
+
+
+class aur_tensor_desc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("numel", C.c_int64)]
+
+
+class aur_seq_desc(C.Structure):
+    _fields_ = [("text_ids", C.POINTER(C.c_int32)), ("n_text", C.c_int32), ("speaker_key", C.c_uint64),
+                ("temperature", C.c_float), ("top_p", C.c_float), ("top_k", C.c_int32),
+                ("repetition_penalty", C.c_float), ("max_tokens", C.c_int32), ("seed", C.c_uint32),
+                ("ignore_stop", C.c_int32)]
+
+
+class aur_result(C.Structure):
+    _fields_ = [("seq_id", C.c_uint64), ("n_tokens", C.c_int32), ("tokens", C.POINTER(C.c_int32)),
+                ("n_samples", C.c_int32), ("wav", C.POINTER(C.c_float)), ("n_latent_rows", C.c_int32),
+                ("latents", C.POINTER(C.c_float)), ("error", C.c_int32)]
+
+
+class aur_stats(C.Structure):
+    _fields_ = [("steps", C.c_int64), ("prefill_rows", C.c_int64), ("decode_rows", C.c_int64),
+                ("tokens_generated", C.c_int64), ("samples_generated", C.c_int64), ("vocoder_batches", C.c_int64),
+                ("conv_launches", C.c_int64), ("conv_ms", C.c_double), ("conv_flops", C.c_double),
+                ("conv_bytes", C.c_double), ("vocoder_ms", C.c_double), ("gpt_ms", C.c_double),
+                ("kv_blocks_total", C.c_int64), ("kv_blocks_free", C.c_int64)]
+
+    def as_dict(self) -> Dict[str, float]:
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/auralis_amd.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "aur_last_error", "aur_version", "aur_engine_create", "aur_engine_destroy", "aur_load_weights",
+    "aur_set_conditioning", "aur_set_conditioning_device", "aur_submit", "aur_step", "aur_poll_finished",
+    "aur_release", "aur_vocode", "aur_sync", "aur_get_stats", "aur_reset_stats", "aur_dbg_gemm",
+    "aur_dbg_layernorm", "aur_dbg_conv1d", "aur_dbg_prefill", "aur_dbg_sample",
+]
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen the in-tree HIP library; raises if it was not built (no silent fallback)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.isfile(p):
+        raise FileNotFoundError(
+            f"{p} not found: build it with `python -m auralis_amd.build` (hipcc --offload-arch=gfx950). "
+            "The MI355X path has no CPU fallback.")
+    lib = C.CDLL(p)
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    eng = C.c_void_p
+    lib.aur_last_error.restype = C.c_char_p
+    lib.aur_last_error.argtypes = []
+    lib.aur_version.restype = C.c_int
+    sig = {
+        "aur_engine_create": [C.POINTER(aur_config), C.c_int, C.POINTER(eng)],
+        "aur_engine_destroy": [eng],
+        "aur_load_weights": [eng, C.POINTER(aur_tensor_desc), C.c_size_t],
+        "aur_set_conditioning": [eng, C.c_uint64, fp, fp],
+        "aur_set_conditioning_device": [eng, C.c_uint64, C.c_void_p, C.c_void_p],
+        "aur_submit": [eng, C.POINTER(aur_seq_desc), C.POINTER(C.c_uint64)],
+        "aur_step": [eng, ip, ip],
+        "aur_poll_finished": [eng, C.POINTER(aur_result), C.c_size_t, C.POINTER(C.c_size_t)],
+        "aur_release": [eng, C.c_uint64],
+        "aur_vocode": [eng, fp, ip, C.c_int32, C.c_int32, C.c_uint64, fp, C.c_int64, ip],
+        "aur_sync": [eng],
+        "aur_get_stats": [eng, C.POINTER(aur_stats)],
+        "aur_reset_stats": [eng],
+        "aur_dbg_gemm": [eng, fp, fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32],
+        "aur_dbg_layernorm": [eng, fp, fp, fp, fp, C.c_int32],
+        "aur_dbg_conv1d": [eng, fp, fp, fp, fp, fp, ip, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                           C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32],
+        "aur_dbg_prefill": [eng, ip, C.c_int32, C.c_uint64, C.c_float, fp, fp],
+        "aur_dbg_sample": [eng, fp, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_float,
+                           C.POINTER(C.c_uint8), C.c_uint32, C.c_int32, ip],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _fp(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class NativeEngine:
+    """Thin object wrapper over the C ABI; one instance per GPU."""
+
+    def __init__(self, n_layer: int = 30, max_seqs: int = 64, device: int = 0, max_prefill_rows: int = 0,
+                 max_speakers: int = 0, vocoder_min_batch: int = 0, profile: bool = False):
+        self.lib = load_library()
+        cfg = aur_config(n_layer, max_seqs, max_prefill_rows, max_speakers, vocoder_min_batch, int(profile))
+        h = C.c_void_p()
+        self._check(self.lib.aur_engine_create(C.byref(cfg), device, C.byref(h)))
+        self.h = h
+        self.max_seqs = max_seqs
+        self.n_layer = n_layer
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise AurError(rc, self.lib.aur_last_error().decode("utf-8", "replace"))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.aur_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights / conditioning ------------------------------------------------------------------------
+    def load_weights(self, packed: Dict[str, np.ndarray]):
+        names = list(packed.keys())
+        arrs = [_f32(packed[n]) for n in names]
+        descs = (aur_tensor_desc * len(names))()
+        keep = []
+        for i, (n, a) in enumerate(zip(names, arrs)):
+            b = n.encode()
+            keep.append(b)
+            descs[i].name = b
+            descs[i].data = _fp(a)
+            descs[i].numel = a.size
+        self._check(self.lib.aur_load_weights(self.h, descs, len(names)))
+
+    def set_conditioning(self, key: int, gpt_cond_latent, speaker_embedding):
+        g = _f32(np.asarray(gpt_cond_latent).reshape(32, 1024))
+        s = _f32(np.asarray(speaker_embedding).reshape(512))
+        self._check(self.lib.aur_set_conditioning(self.h, key, _fp(g), _fp(s)))
+
+    def set_conditioning_device(self, key: int, d_gpt_cond_ptr: int, d_spk_ptr: int):
+        self._check(self.lib.aur_set_conditioning_device(self.h, key, C.c_void_p(d_gpt_cond_ptr), C.c_void_p(d_spk_ptr)))
+
+    # -- sequences -------------------------------------------------------------------------------------
+    def submit(self, text_ids: Sequence[int], speaker_key: int, temperature: float = 0.75, top_p: float = 0.85,
+               top_k: int = 50, repetition_penalty: float = 5.0, max_tokens: int = 605, seed: int = 0,
+               ignore_stop: bool = False) -> int:
+        ids = _i32(list(text_ids))
+        d = aur_seq_desc(_ip(ids), len(ids), speaker_key, temperature, top_p, top_k, repetition_penalty,
+                         max_tokens, seed & 0xFFFFFFFF, int(ignore_stop))
+        sid = C.c_uint64()
+        self._check(self.lib.aur_submit(self.h, C.byref(d), C.byref(sid)))
+        return sid.value
+
+    def step(self):
+        live, fin = C.c_int32(), C.c_int32()
+        self._check(self.lib.aur_step(self.h, C.byref(live), C.byref(fin)))
+        return live.value, fin.value
+
+    def poll(self, cap: int = 64, want_latents: bool = True) -> List[dict]:
+        res = (aur_result * cap)()
+        n = C.c_size_t()
+        self._check(self.lib.aur_poll_finished(self.h, res, cap, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            r = res[i]
+            item = {
+                "seq_id": r.seq_id,
+                "tokens": np.ctypeslib.as_array(r.tokens, shape=(r.n_tokens,)).copy(),
+                "wav": np.ctypeslib.as_array(r.wav, shape=(r.n_samples,)).copy(),
+                "error": r.error,
+            }
+            if want_latents and r.n_latent_rows:
+                item["latents"] = np.ctypeslib.as_array(r.latents, shape=(r.n_latent_rows, 1024)).copy()
+            self._check(self.lib.aur_release(self.h, r.seq_id))
+            out.append(item)
+        return out
+
+    def run_until_done(self, max_steps: int = 100000) -> List[dict]:
+        """Drive aur_step until nothing is live; returns finished results in completion order."""
+        done: List[dict] = []
+        for _ in range(max_steps):
+            live, _fin = self.step()
+            done.extend(self.poll())
+            if live == 0:
+                break
+        else:
+            raise RuntimeError("run_until_done: step limit reached")
+        return done
+
+    def vocode(self, latents: np.ndarray, n_lat: Optional[Sequence[int]], speaker_key: int) -> List[np.ndarray]:
+        lat = _f32(latents)
+        if lat.ndim == 2:
+            lat = lat[None]
+        B, t_max, _ = lat.shape
+        nl = _i32(n_lat if n_lat is not None else [t_max] * B)
+        stride = int(np.floor(np.floor(t_max * 4.0) * (24000 / 22050))) * 256
+        wav = np.zeros((B, stride), dtype=np.float32)
+        ns = np.zeros(B, dtype=np.int32)
+        self._check(self.lib.aur_vocode(self.h, _fp(lat), _ip(nl), B, t_max, speaker_key, _fp(wav), stride, _ip(ns)))
+        return [wav[b, : ns[b]].copy() for b in range(B)]
+
+    def sync(self):
+        self._check(self.lib.aur_sync(self.h))
+
+    def stats(self) -> Dict[str, float]:
+        s = aur_stats()
+        self._check(self.lib.aur_get_stats(self.h, C.byref(s)))
+        return s.as_dict()
+
+    def reset_stats(self):
+        self._check(self.lib.aur_reset_stats(self.h))
+
+    # -- per-kernel debug entry points -------------------------------------------------------------------
+    def dbg_gemm(self, X, W, kw: int = 0) -> np.ndarray:
+        X, W = _f32(X), _f32(W)
+        M, K = X.shape
+        K2, N = W.shape
+        assert K == K2
+        out = np.empty((M, N), dtype=np.float32)
+        self._check(self.lib.aur_dbg_gemm(self.h, _fp(X), _fp(W), _fp(out), M, N, K, kw))
+        return out
+
+    def dbg_layernorm(self, h, gamma, beta) -> np.ndarray:
+        h, gamma, beta = _f32(h), _f32(gamma), _f32(beta)
+        out = np.empty_like(h)
+        self._check(self.lib.aur_dbg_layernorm(self.h, _fp(h), _fp(gamma), _fp(beta), _fp(out), h.shape[0]))
+        return out
+
+    def dbg_conv1d(self, x, wp, bias, res, lens, ks, dil, padl, slope, cout, ups_s=0, ups_p=0) -> np.ndarray:
+        x, wp = _f32(x), _f32(wp)
+        B, cin, L = x.shape
+        mtot = wp.shape[0] * wp.shape[3]
+        lout = L * max(1, ups_s)
+        bias = None if bias is None else _f32(bias)
+        res = None if res is None else _f32(res)
+        out = np.empty((B, cout, lout), dtype=np.float32)
+        lens = _i32(lens)
+        self._check(self.lib.aur_dbg_conv1d(self.h, _fp(x), _fp(wp), _fp(bias), _fp(res), _fp(out), _ip(lens), B, cin,
+                                            mtot, cout, L, ks, dil, padl, slope, ups_s, ups_p))
+        return out
+
+    def dbg_prefill(self, text_ids, speaker_key: int, repetition_penalty: float = 1.0):
+        ids = _i32(list(text_ids))
+        n_rows = 32 + len(ids) + 1
+        rows = np.empty((n_rows, 1024), dtype=np.float32)
+        logits = np.empty(1026, dtype=np.float32)
+        self._check(self.lib.aur_dbg_prefill(self.h, _ip(ids), len(ids), speaker_key, repetition_penalty, _fp(rows), _fp(logits)))
+        return rows, logits
+
+    def dbg_sample(self, logits, temperature, top_p, top_k, repetition_penalty=1.0, seen=None, seed=0, step=0):
+        lg = _f32(logits)
+        if lg.ndim == 1:
+            lg = lg[None]
+        B = lg.shape[0]
+        toks = np.zeros(B, dtype=np.int32)
+        sp = None
+        if seen is not None:
+            seen = np.ascontiguousarray(seen, dtype=np.uint8).reshape(B, 1026)
+            sp = seen.ctypes.data_as(C.POINTER(C.c_uint8))
+        self._check(self.lib.aur_dbg_sample(self.h, _fp(lg), B, temperature, top_p, top_k, repetition_penalty, sp,
+                                            seed & 0xFFFFFFFF, step, _ip(toks)))
+        return toks

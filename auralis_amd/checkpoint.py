@@ -1,0 +1,157 @@
+"""On-disk weight format of the reference (two safetensors + configs) and a seeded synthetic writer.
+
+Format defined by src/auralis/models/xttsv2/utils/checkpoint_converter.py:225-284 and consumed at
+src/auralis/models/xttsv2/XTTSv2.py:288-301 / components/vllm_mm_gpt.py:714-733:
+
+  <dir>/gpt/gpt2_model.safetensors        gpt.wte.weight, gpt.wpe.emb.weight, gpt.h.N.*, gpt.ln_f.*,
+                                          final_norm.*, mel_head.*   (HF Conv1D [in,out] layout)
+  <dir>/core_xttsv2/xtts-v2.safetensors   text_embedding, text_pos_embedding, final_norm,
+                                          hifigan_decoder.waveform_decoder.* (weight-norm g/v pairs), ...
+
+Real checkpoints (AstraMindAI/xttsv2, AstraMindAI/xtts2-gpt) are not available offline; every test
+and the bench use `make_synthetic_weights` (seed 1234).
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from .config import GPTDims, VocoderDims, XTTSDims
+
+Tensor = torch.Tensor
+VOC_PREFIX = "hifigan_decoder.waveform_decoder."
+
+
+def _conv_default_init(gen: torch.Generator, shape, fan_in: int) -> Tensor:
+    b = 1.0 / math.sqrt(fan_in)
+    return (torch.rand(shape, generator=gen, dtype=torch.float32) * 2.0 - 1.0) * b
+
+
+def make_synthetic_gpt(dims: GPTDims, seed: int = 1234, n_layer: Optional[int] = None) -> Dict[str, Tensor]:
+    """gpt2_model.safetensors contents: N(0, 0.02) matrices/embeddings, LayerNorm gamma=1 beta=0."""
+    g = torch.Generator().manual_seed(seed)
+    H, F_ = dims.hidden, dims.n_inner
+    L = dims.n_layer if n_layer is None else n_layer
+
+    def rn(*shape):
+        return torch.randn(*shape, generator=g, dtype=torch.float32) * 0.02
+
+    sd: Dict[str, Tensor] = {
+        "gpt.wte.weight": rn(dims.mel_vocab, H),
+        "gpt.wpe.emb.weight": rn(dims.mel_positions, H),
+    }
+    for i in range(L):
+        p = f"gpt.h.{i}."
+        sd[p + "ln_1.weight"] = torch.ones(H)
+        sd[p + "ln_1.bias"] = torch.zeros(H)
+        sd[p + "attn.c_attn.weight"] = rn(H, 3 * H)
+        sd[p + "attn.c_attn.bias"] = rn(3 * H)
+        sd[p + "attn.c_proj.weight"] = rn(H, H)
+        sd[p + "attn.c_proj.bias"] = rn(H)
+        sd[p + "ln_2.weight"] = torch.ones(H)
+        sd[p + "ln_2.bias"] = torch.zeros(H)
+        sd[p + "mlp.c_fc.weight"] = rn(H, F_)
+        sd[p + "mlp.c_fc.bias"] = rn(F_)
+        sd[p + "mlp.c_proj.weight"] = rn(F_, H)
+        sd[p + "mlp.c_proj.bias"] = rn(H)
+    sd["gpt.ln_f.weight"] = torch.ones(H)
+    sd["gpt.ln_f.bias"] = torch.zeros(H)
+    # non-trivial affine so that final_norm∘final_norm is actually exercised
+    sd["final_norm.weight"] = 1.0 + rn(H) * 5.0
+    sd["final_norm.bias"] = rn(H)
+    sd["mel_head.weight"] = rn(dims.mel_vocab, H)
+    sd["mel_head.bias"] = rn(dims.mel_vocab)
+    return sd
+
+
+def make_synthetic_xtts(dims: XTTSDims, seed: int = 1234, gpt_sd: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
+    """xtts-v2.safetensors contents needed by the hot path (text embeddings + vocoder).
+
+    Vocoder convs use torch's default conv init bound 1/sqrt(fan_in) (N(0,0.02) gives a near-silent
+    waveform); weight-norm g = ||v|| so the effective weight equals v at init.
+    """
+    gd, vd = dims.gpt, dims.voc
+    g = torch.Generator().manual_seed(seed + 1)
+    H = gd.hidden
+    sd: Dict[str, Tensor] = {
+        "mel_stats": torch.ones(80),
+        "text_embedding.weight": torch.randn(gd.text_vocab, H, generator=g) * 0.02,
+        "text_pos_embedding.emb.weight": torch.randn(gd.text_positions, H, generator=g) * 0.02,
+    }
+    if gpt_sd is not None:
+        sd["final_norm.weight"] = gpt_sd["final_norm.weight"].clone()
+        sd["final_norm.bias"] = gpt_sd["final_norm.bias"].clone()
+    p = VOC_PREFIX
+    C0 = vd.initial_channel
+    sd[p + "conv_pre.weight"] = _conv_default_init(g, (C0, vd.in_dim, 7), vd.in_dim * 7)
+    sd[p + "conv_pre.bias"] = _conv_default_init(g, (C0,), vd.in_dim * 7)
+    sd[p + "cond_layer.weight"] = _conv_default_init(g, (C0, vd.d_vector, 1), vd.d_vector)
+    sd[p + "cond_layer.bias"] = _conv_default_init(g, (C0,), vd.d_vector)
+    chans = vd.stage_channels()
+    cin = C0
+    for i, (s, k, c) in enumerate(zip(vd.upsample_rates, vd.upsample_kernels, chans)):
+        v = _conv_default_init(g, (cin, c, k), c * k)   # ConvTranspose1d: fan_in computed on dim 1
+        sd[p + f"ups.{i}.parametrizations.weight.original1"] = v
+        sd[p + f"ups.{i}.parametrizations.weight.original0"] = v.flatten(1).norm(dim=1).view(cin, 1, 1).clone()
+        sd[p + f"ups.{i}.bias"] = _conv_default_init(g, (c,), c * k)
+        sd[p + f"conds.{i}.weight"] = _conv_default_init(g, (c, vd.d_vector, 1), vd.d_vector)
+        sd[p + f"conds.{i}.bias"] = _conv_default_init(g, (c,), vd.d_vector)
+        for j, rk in enumerate(vd.resblock_kernels):
+            rb = p + f"resblocks.{i * len(vd.resblock_kernels) + j}."
+            for grp in ("convs1", "convs2"):
+                for q in range(len(vd.resblock_dilations)):
+                    v = _conv_default_init(g, (c, c, rk), c * rk)
+                    sd[rb + f"{grp}.{q}.parametrizations.weight.original1"] = v
+                    # perturb g a little so folding g*v/||v|| is really exercised
+                    gn = v.flatten(1).norm(dim=1).view(c, 1, 1)
+                    sd[rb + f"{grp}.{q}.parametrizations.weight.original0"] = gn * (
+                        1.0 + 0.1 * (torch.rand(c, 1, 1, generator=g) - 0.5))
+                    sd[rb + f"{grp}.{q}.bias"] = _conv_default_init(g, (c,), c * rk)
+        cin = c
+    sd[p + "conv_post.weight"] = _conv_default_init(g, (1, cin, 7), cin * 7)
+    return sd
+
+
+def make_synthetic_conditioning(dims: XTTSDims, seed_cond: int = 7, seed_spk: int = 8) -> Tuple[Tensor, Tensor]:
+    """gpt_cond_latent [1,32,1024] ~ N(0,1)*0.02 (seed 7); speaker_embedding = L2-normalised N(0,1) [1,512,1] (seed 8)."""
+    g1 = torch.Generator().manual_seed(seed_cond)
+    cond = torch.randn(1, dims.gpt.perceiver_latents, dims.gpt.hidden, generator=g1) * 0.02
+    g2 = torch.Generator().manual_seed(seed_spk)
+    spk = torch.randn(1, dims.voc.d_vector, 1, generator=g2)
+    spk = spk / spk.norm()
+    return cond, spk
+
+
+def make_synthetic_text_ids(dims: XTTSDims, n_text: int = 70, seed: int = 11):
+    """[START] + ids ~ U[0, text_vocab) + [STOP]  (start/stop text ids 261/0 per XTTSv2.py:520-521)."""
+    g = torch.Generator().manual_seed(seed)
+    body = torch.randint(0, dims.gpt.text_vocab, (n_text - 2,), generator=g).tolist()
+    return [261] + body + [0]
+
+
+def save_checkpoint(root: str, gpt_sd: Dict[str, Tensor], xtts_sd: Dict[str, Tensor], dims: XTTSDims) -> None:
+    from safetensors.torch import save_file
+    os.makedirs(os.path.join(root, "gpt"), exist_ok=True)
+    os.makedirs(os.path.join(root, "core_xttsv2"), exist_ok=True)
+    save_file({k: v.contiguous() for k, v in gpt_sd.items()}, os.path.join(root, "gpt", "gpt2_model.safetensors"))
+    save_file({k: v.contiguous() for k, v in xtts_sd.items()}, os.path.join(root, "core_xttsv2", "xtts-v2.safetensors"))
+    n_layer = 1 + max(int(k.split(".")[2]) for k in gpt_sd if k.startswith("gpt.h."))
+    with open(os.path.join(root, "gpt", "config.json"), "w") as f:
+        json.dump({"model_type": "xtts_gpt", "hidden_size": dims.gpt.hidden, "num_hidden_layers": n_layer,
+                   "num_attention_heads": dims.gpt.n_head, "n_inner": dims.gpt.n_inner,
+                   "num_audio_tokens": dims.gpt.mel_vocab, "start_audio_token": dims.gpt.start_token,
+                   "stop_audio_token": dims.gpt.stop_token, "max_audio_tokens": dims.gpt.max_audio_tokens,
+                   "activation_function": dims.gpt.activation}, f)
+    with open(os.path.join(root, "core_xttsv2", "config.json"), "w") as f:
+        json.dump({"model_type": "xtts", "gpt_config": {"num_hidden_layers": n_layer}}, f)
+
+
+def load_checkpoint(root: str) -> Tuple[Dict[str, Tensor], Dict[str, Tensor]]:
+    from safetensors.torch import load_file
+    gpt_sd = load_file(os.path.join(root, "gpt", "gpt2_model.safetensors"))
+    xtts_sd = load_file(os.path.join(root, "core_xttsv2", "xtts-v2.safetensors"))
+    return gpt_sd, xtts_sd

@@ -1,0 +1,50 @@
+// Shared host/device helpers for the gfx950 kernels of the XTTSv2 hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace aur {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct HipError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+inline void hip_check(hipError_t e, const char* what, const char* file, int line) {
+    if (e != hipSuccess) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+        throw HipError(buf);
+    }
+}
+#define HIP_CHECK(x) ::aur::hip_check((x), #x, __FILE__, __LINE__)
+#define AUR_REQUIRE(cond, msg)                                                          \
+    do {                                                                                \
+        if (!(cond)) throw ::aur::HipError(std::string("requirement failed: ") + (msg)); \
+    } while (0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// tanh-form GELU ("gelu_new"), same expression order as the oracle.
+__device__ __forceinline__ float gelu_new(float x) {
+    const float k = 0.7978845608028654f;  // sqrt(2/pi)
+    return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
+}
+
+}  // namespace aur

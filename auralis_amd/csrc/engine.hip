@@ -1,0 +1,1104 @@
+// Host runtime + C ABI (include/auralis_amd.h) of the MI355X-native XTTSv2 hot path.
+//
+// One Engine per GPU/process.  It owns: the packed weights, a paged KV pool with a block allocator, the
+// per-slot device state of the continuous batcher, the latent stash that replaces the reference's second
+// GPT pass (XTTSv2.py:617-687; equivalence argued in SURVEY.md §7 and tested in tests/), and the vocoder
+// workspace.  The reference's counterparts are vLLM's AsyncLLMEngine/scheduler/block manager (un-vendored,
+// XTTSv2.py:198-232), HiddenStatesCollector (components/vllm/hidden_state_collector.py) and the
+// asyncio.to_thread HiFi-GAN call (XTTSv2.py:804).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/auralis_amd.h"
+#include "gpt_kernels.h"
+#include "vocoder_kernels.h"
+
+namespace aur {
+
+static thread_local std::string g_last_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    void ensure(size_t n) {
+        if (n <= bytes) return;
+        if (p) HIP_CHECK(hipFree(p));
+        p = nullptr;
+        bytes = 0;
+        HIP_CHECK(hipMalloc(&p, n));
+        bytes = n;
+    }
+    template <class T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+struct PinBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~PinBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    void ensure(size_t n) {
+        if (n <= bytes) return;
+        if (p) HIP_CHECK(hipHostFree(p));
+        p = nullptr;
+        HIP_CHECK(hipHostMalloc(&p, n, hipHostMallocDefault));
+        bytes = n;
+    }
+    template <class T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+struct Tensor {
+    std::unique_ptr<DevBuf> buf;
+    int64_t numel = 0;
+    float* d() const { return buf->as<float>(); }
+};
+
+struct SlotInit {
+    int slot;
+    float temperature, top_p;
+    int top_k;
+    float rep_penalty;
+    int max_tokens, ignore_stop;
+    unsigned seed;
+    int ngen;   // initial n_gen (0; dbg_sample injects a step)
+};
+
+__global__ __launch_bounds__(256) void init_slots_kernel(const SlotInit* __restrict__ init, int* slot_tok,
+                                                         int* slot_pos, int* slot_kvpos, int* slot_ngen,
+                                                         int* slot_finished, float* temperature, float* top_p,
+                                                         int* top_k, float* rep, int* max_tokens, int* ignore_stop,
+                                                         unsigned* seed, unsigned char* seen, int start_token) {
+    const SlotInit s = init[blockIdx.x];
+    unsigned char* row = seen + (long)s.slot * kSeenStride;
+    for (int i = threadIdx.x; i < kSeenStride; i += 256) row[i] = (i == 1 || i == start_token) ? 1 : 0;
+    if (threadIdx.x == 0) {
+        slot_tok[s.slot] = start_token;
+        slot_pos[s.slot] = 0;
+        slot_kvpos[s.slot] = 0;
+        slot_ngen[s.slot] = s.ngen;
+        slot_finished[s.slot] = 0;
+        temperature[s.slot] = s.temperature;
+        top_p[s.slot] = s.top_p;
+        top_k[s.slot] = s.top_k;
+        rep[s.slot] = s.rep_penalty;
+        max_tokens[s.slot] = s.max_tokens;
+        ignore_stop[s.slot] = s.ignore_stop;
+        seed[s.slot] = s.seed;
+    }
+}
+
+enum class SeqState { WAITING, RUNNING, TOKENS_DONE, DONE, RELEASED };
+
+struct Seq {
+    uint64_t id = 0;
+    SeqState state = SeqState::WAITING;
+    std::vector<int> text_ids;
+    int spk_row = -1;
+    aur_seq_desc params{};
+    int slot = -1;
+    int n_prompt = 0;
+    std::vector<int> blocks;
+    std::vector<int32_t> tokens;
+    std::vector<float> wav;
+    std::vector<float> latents;
+    int error = 0;
+};
+
+struct ConvLayer {
+    const float* wp = nullptr;
+    const float* bias = nullptr;
+};
+
+class Engine {
+public:
+    Engine(const aur_config& c, int device) : cfg_(c), device_(device) {
+        HIP_CHECK(hipSetDevice(device_));
+        HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamDefault));   // blocking w.r.t. the null stream on purpose
+        AUR_REQUIRE(c.n_layer >= 1 && c.n_layer <= 64, "n_layer in [1,64]");
+        AUR_REQUIRE(c.max_seqs >= 1 && c.max_seqs <= 4096, "max_seqs in [1,4096]");
+        if (cfg_.max_prefill_rows <= 0) cfg_.max_prefill_rows = 8192;
+        if (cfg_.max_speakers <= 0) cfg_.max_speakers = 64;
+        const int S = cfg_.max_seqs;
+        n_blocks_ = (long)S * kMaxBlocks;
+        kv_layer_stride_ = n_blocks_ * kKvBlockElems;
+        kv_.ensure((size_t)cfg_.n_layer * kv_layer_stride_ * sizeof(float));
+        for (int b = (int)n_blocks_ - 1; b >= 0; --b) free_blocks_.push_back(b);
+        auto ints = [&](DevBuf& b, size_t n) {
+            b.ensure(n * sizeof(int));
+            HIP_CHECK(hipMemsetAsync(b.p, 0, n * sizeof(int), st_));
+        };
+        ints(slot_tok_, S); ints(slot_pos_, S); ints(slot_kvpos_, S); ints(slot_ngen_, S); ints(slot_finished_, S);
+        ints(temperature_, S); ints(top_p_, S); ints(top_k_, S); ints(rep_, S); ints(max_tokens_, S);
+        ints(ignore_stop_, S); ints(seed_, S);
+        ints(block_tables_, (size_t)S * kMaxBlocks);
+        seen_.ensure((size_t)S * kSeenStride);
+        HIP_CHECK(hipMemsetAsync(seen_.p, 0, (size_t)S * kSeenStride, st_));
+        latents_.ensure((size_t)S * kMaxLatRows * kHidden * sizeof(float));
+        spk_table_.ensure((size_t)cfg_.max_speakers * 32 * kHidden * sizeof(float));
+        spk_emb_.ensure((size_t)cfg_.max_speakers * 512 * sizeof(float));
+        voc_cond_.ensure((size_t)cfg_.max_speakers * kCondStride * sizeof(float));
+        zero_bias_.ensure(4096 * sizeof(float));
+        HIP_CHECK(hipMemsetAsync(zero_bias_.p, 0, 4096 * sizeof(float), st_));
+        h_block_tables_.assign((size_t)S * kMaxBlocks, 0);
+        slot_owner_.assign(S, nullptr);
+        pin_.ensure(((size_t)S * 2 + 16) * sizeof(int));
+        HIP_CHECK(hipEventCreate(&ev_a_));
+        HIP_CHECK(hipEventCreate(&ev_b_));
+        HIP_CHECK(hipStreamSynchronize(st_));
+    }
+    ~Engine() {
+        (void)hipSetDevice(device_);
+        (void)hipStreamSynchronize(st_);
+        for (auto& e : conv_events_) {
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+        (void)hipEventDestroy(ev_a_);
+        (void)hipEventDestroy(ev_b_);
+        (void)hipStreamDestroy(st_);
+    }
+
+    void use() { HIP_CHECK(hipSetDevice(device_)); }
+
+    // ------------------------------------------------------------------ weights
+    void load(const aur_tensor_desc* t, size_t n) {
+        use();
+        for (size_t i = 0; i < n; ++i) {
+            AUR_REQUIRE(t[i].name && t[i].data && t[i].numel > 0, "bad tensor desc");
+            Tensor& dst = w_[t[i].name];
+            if (!dst.buf) dst.buf.reset(new DevBuf());
+            dst.buf->ensure((size_t)t[i].numel * sizeof(float));
+            dst.numel = t[i].numel;
+            HIP_CHECK(hipMemcpy(dst.buf->p, t[i].data, (size_t)t[i].numel * sizeof(float), hipMemcpyHostToDevice));
+        }
+        voc_ready_ = false;
+        gpt_ready_ = false;
+    }
+    const float* W(const std::string& name, int64_t numel = -1) const {
+        auto it = w_.find(name);
+        if (it == w_.end()) throw HipError("weight not loaded: " + name);
+        if (numel >= 0 && it->second.numel != numel)
+            throw HipError("weight " + name + " has " + std::to_string(it->second.numel) + " elements, expected " +
+                           std::to_string(numel));
+        return it->second.d();
+    }
+
+    // ------------------------------------------------------------------ conditioning
+    int speaker_row(uint64_t key, bool create) {
+        auto it = spk_rows_.find(key);
+        if (it != spk_rows_.end()) return it->second;
+        if (!create) return -1;
+        AUR_REQUIRE((int)spk_rows_.size() < cfg_.max_speakers, "speaker table full");
+        const int row = (int)spk_rows_.size();
+        spk_rows_[key] = row;
+        return row;
+    }
+    void set_conditioning(uint64_t key, const float* gpt_cond, const float* spk, bool device_ptrs) {
+        use();
+        const int row = speaker_row(key, true);
+        const hipMemcpyKind kind = device_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        HIP_CHECK(hipMemcpyAsync(spk_table_.as<float>() + (long)row * 32 * kHidden, gpt_cond,
+                                 32 * kHidden * sizeof(float), kind, st_));
+        HIP_CHECK(hipMemcpyAsync(spk_emb_.as<float>() + (long)row * 512, spk, 512 * sizeof(float), kind, st_));
+        // 1x1 conditioning convs of the vocoder on the speaker embedding (hifigan_decoder.py:243-251)
+        float* dst = voc_cond_.as<float>() + (long)row * kCondStride;
+        const float* g = spk_emb_.as<float>() + (long)row * 512;
+        launch_gemv_rows(W("voc.cond_layer.w", 512 * 512), W("voc.cond_layer.b", 512), g, dst, 512, 512, 1, 0, 0, st_);
+        const int C[4] = {256, 128, 64, 32};
+        int off = 512;
+        for (int i = 0; i < 4; ++i) {
+            const std::string p = "voc.conds." + std::to_string(i);
+            launch_gemv_rows(W(p + ".w", (int64_t)C[i] * 512), W(p + ".b", C[i]), g, dst + off, C[i], 512, 1, 0, 0, st_);
+            off += C[i];
+        }
+        HIP_CHECK(hipStreamSynchronize(st_));
+    }
+
+    // ------------------------------------------------------------------ submit / poll
+    uint64_t submit(const aur_seq_desc& d) {
+        AUR_REQUIRE(d.text_ids && d.n_text >= 1, "text_ids");
+        AUR_REQUIRE(d.max_tokens >= 1 && d.max_tokens <= kMaxLatRows - 3, "max_tokens in [1,605]");
+        const int n_prompt = 32 + d.n_text + 1;
+        AUR_REQUIRE(n_prompt + d.max_tokens <= kMaxBlocks * kKvBlockTokens, "prompt + max_tokens exceeds max_model_len");
+        AUR_REQUIRE(n_prompt <= cfg_.max_prefill_rows, "prompt longer than max_prefill_rows");
+        AUR_REQUIRE(d.repetition_penalty > 0.f, "repetition_penalty > 0");
+        std::lock_guard<std::mutex> lk(mu_);
+        const int row = speaker_row(d.speaker_key, false);
+        AUR_REQUIRE(row >= 0, "unknown speaker_key (call aur_set_conditioning first)");
+        auto s = std::make_unique<Seq>();
+        s->id = next_id_++;
+        s->text_ids.assign(d.text_ids, d.text_ids + d.n_text);
+        s->spk_row = row;
+        s->params = d;
+        s->params.text_ids = nullptr;
+        s->n_prompt = n_prompt;
+        const uint64_t id = s->id;
+        waiting_.push_back(s.get());
+        seqs_[id] = std::move(s);
+        return id;
+    }
+
+    size_t poll(aur_result* out, size_t cap) {
+        std::lock_guard<std::mutex> lk(mu_);
+        size_t n = 0;
+        while (n < cap && !done_.empty()) {
+            Seq* s = done_.front();
+            done_.pop_front();
+            aur_result& r = out[n++];
+            r.seq_id = s->id;
+            r.n_tokens = (int)s->tokens.size();
+            r.tokens = s->tokens.data();
+            r.n_samples = (int)s->wav.size();
+            r.wav = s->wav.data();
+            r.n_latent_rows = s->latents.empty() ? 0 : (int)(s->latents.size() / kHidden);
+            r.latents = s->latents.empty() ? nullptr : s->latents.data();
+            r.error = s->error;
+        }
+        return n;
+    }
+    void release(uint64_t id) {
+        std::lock_guard<std::mutex> lk(mu_);
+        auto it = seqs_.find(id);
+        AUR_REQUIRE(it != seqs_.end(), "unknown seq_id");
+        AUR_REQUIRE(it->second->state == SeqState::DONE, "sequence not finished");
+        seqs_.erase(it);
+    }
+
+    // ------------------------------------------------------------------ one scheduler iteration
+    void step(int* n_live, int* n_finished_total) {
+        use();
+        ensure_gpt();
+        bool worked = false;
+        // 1. admission + prefill
+        std::vector<Seq*> admitted;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            int rows = 0;
+            while (!waiting_.empty()) {
+                Seq* s = waiting_.front();
+                const int need = (s->n_prompt + s->params.max_tokens + kKvBlockTokens - 1) / kKvBlockTokens;
+                int slot = -1;
+                for (int i = 0; i < cfg_.max_seqs; ++i)
+                    if (!slot_owner_[i]) {
+                        slot = i;
+                        break;
+                    }
+                if (slot < 0 || (int)free_blocks_.size() < need || rows + s->n_prompt > cfg_.max_prefill_rows) break;
+                waiting_.pop_front();
+                s->slot = slot;
+                slot_owner_[slot] = s;
+                for (int b = 0; b < need; ++b) {
+                    s->blocks.push_back(free_blocks_.back());
+                    free_blocks_.pop_back();
+                    h_block_tables_[(size_t)slot * kMaxBlocks + b] = s->blocks.back();
+                }
+                s->state = SeqState::RUNNING;
+                rows += s->n_prompt;
+                admitted.push_back(s);
+            }
+        }
+        HIP_CHECK(hipEventRecord(ev_a_, st_));
+        if (!admitted.empty()) {
+            prefill(admitted);
+            worked = true;
+        }
+        // 2. decode step for every running sequence
+        std::vector<int> active;
+        for (int i = 0; i < cfg_.max_seqs; ++i)
+            if (slot_owner_[i] && slot_owner_[i]->state == SeqState::RUNNING) active.push_back(i);
+        if (!active.empty()) {
+            decode(active);
+            worked = true;
+        }
+        HIP_CHECK(hipEventRecord(ev_b_, st_));
+        HIP_CHECK(hipStreamSynchronize(st_));
+        if (worked) {
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, ev_a_, ev_b_));
+            stats_.gpt_ms += ms;
+            stats_.steps++;
+        }
+        // 3. vocode what finished
+        std::vector<Seq*> ready;
+        int running = 0;
+        for (int i = 0; i < cfg_.max_seqs; ++i) {
+            Seq* s = slot_owner_[i];
+            if (!s) continue;
+            if (s->state == SeqState::TOKENS_DONE) ready.push_back(s);
+            if (s->state == SeqState::RUNNING) ++running;
+        }
+        size_t n_wait;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            n_wait = waiting_.size();
+        }
+        const int minb = std::max(1, cfg_.vocoder_min_batch);
+        if (!ready.empty() && ((int)ready.size() >= minb || (running == 0 && n_wait == 0))) vocode_finished(ready);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            int live = (int)waiting_.size();
+            for (int i = 0; i < cfg_.max_seqs; ++i)
+                if (slot_owner_[i]) ++live;
+            if (n_live) *n_live = live;
+            if (n_finished_total) *n_finished_total = (int)finished_total_;
+        }
+    }
+
+    // ------------------------------------------------------------------ standalone vocoder
+    void vocode_host(const float* latents, const int* n_lat, int B, int t_max, uint64_t key, float* wav_out,
+                     int64_t wav_stride, int* n_samples_out) {
+        use();
+        ensure_voc();
+        const int row = speaker_row(key, false);
+        AUR_REQUIRE(row >= 0, "unknown speaker_key");
+        AUR_REQUIRE(B >= 1 && t_max >= 1, "B, t_max");
+        std::vector<int> nl(n_lat, n_lat + B), cond(B, row);
+        int max_samples = 0;
+        for (int b = 0; b < B; ++b) {
+            AUR_REQUIRE(nl[b] >= 1 && nl[b] <= t_max, "n_lat in [1,t_max]");
+            max_samples = std::max(max_samples, frames_for(nl[b]) * 256);
+        }
+        AUR_REQUIRE(wav_stride >= max_samples, "wav_stride too small");
+        tmp_lat_.ensure((size_t)B * t_max * kHidden * sizeof(float));
+        HIP_CHECK(hipMemcpyAsync(tmp_lat_.p, latents, (size_t)B * t_max * kHidden * sizeof(float),
+                                 hipMemcpyHostToDevice, st_));
+        tmp_wav_.ensure((size_t)B * max_samples * sizeof(float));
+        run_vocoder(B, nl, tmp_lat_.as<float>(), (long)t_max * kHidden, nullptr, cond, tmp_wav_.as<float>(),
+                    max_samples);
+        HIP_CHECK(hipStreamSynchronize(st_));
+        collect_conv_events();
+        for (int b = 0; b < B; ++b) {
+            const int ns = frames_for(nl[b]) * 256;
+            HIP_CHECK(hipMemcpy(wav_out + (long)b * wav_stride, tmp_wav_.as<float>() + (long)b * max_samples,
+                                (size_t)ns * sizeof(float), hipMemcpyDeviceToHost));
+            if (n_samples_out) n_samples_out[b] = ns;
+        }
+    }
+
+    void sync() {
+        use();
+        HIP_CHECK(hipStreamSynchronize(st_));
+    }
+    aur_stats stats() {
+        std::lock_guard<std::mutex> lk(mu_);
+        aur_stats s = stats_;
+        s.kv_blocks_total = n_blocks_;
+        s.kv_blocks_free = (int64_t)free_blocks_.size();
+        return s;
+    }
+    void reset_stats() {
+        std::lock_guard<std::mutex> lk(mu_);
+        stats_ = aur_stats{};
+    }
+
+    // ------------------------------------------------------------------ debug entry points
+    void dbg_gemm(const float* X, const float* Wm, float* out, int M, int N, int K, int kw) {
+        use();
+        if (kw <= 0) kw = gemm_pick_kw(M, K);
+        const int S = K / (4 * kw);
+        DevBuf dx, dw, dp, dout;
+        dx.ensure((size_t)M * K * 4);
+        dw.ensure((size_t)K * N * 4);
+        dp.ensure((size_t)S * M * N * 4);
+        HIP_CHECK(hipMemcpy(dx.p, X, (size_t)M * K * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dw.p, Wm, (size_t)K * N * 4, hipMemcpyHostToDevice));
+        launch_gemm_splitk(dx.as<float>(), K, dw.as<float>(), dp.as<float>(), M, N, K, kw, st_);
+        HIP_CHECK(hipStreamSynchronize(st_));
+        std::vector<float> hp((size_t)S * M * N);
+        HIP_CHECK(hipMemcpy(hp.data(), dp.p, hp.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < (size_t)M * N; ++i) {
+            float t = hp[i];
+            for (int s = 1; s < S; ++s) t += hp[(size_t)s * M * N + i];
+            out[i] = t;
+        }
+    }
+    void dbg_layernorm(const float* h, const float* gamma, const float* beta, float* out, int M) {
+        use();
+        DevBuf dh, dg, db, dout;
+        dh.ensure((size_t)M * kHidden * 4);
+        dg.ensure(kHidden * 4);
+        db.ensure(kHidden * 4);
+        dout.ensure((size_t)M * kHidden * 4);
+        HIP_CHECK(hipMemcpy(dh.p, h, (size_t)M * kHidden * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dg.p, gamma, kHidden * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(db.p, beta, kHidden * 4, hipMemcpyHostToDevice));
+        launch_rows_ln(nullptr, 0, nullptr, dh.as<float>(), dg.as<float>(), db.as<float>(), dout.as<float>(), M, 1e-5f, st_);
+        HIP_CHECK(hipStreamSynchronize(st_));
+        HIP_CHECK(hipMemcpy(out, dout.p, (size_t)M * kHidden * 4, hipMemcpyDeviceToHost));
+    }
+    void dbg_conv1d(const float* x, const float* wp, const float* bias, const float* res, float* out,
+                    const int* lens, int B, int Cin, int Mtot, int Cout, int L, int KS, int DIL, int padl,
+                    float slope, int ups_s, int ups_p) {
+        use();
+        const int Lout = L * std::max(1, ups_s);
+        DevBuf dx, dw, db, dr, dout, dl;
+        dx.ensure((size_t)B * Cin * L * 4);
+        dw.ensure((size_t)Mtot * Cin * KS * 4);
+        dout.ensure((size_t)B * Cout * Lout * 4);
+        dl.ensure((size_t)B * 4);
+        HIP_CHECK(hipMemcpy(dx.p, x, (size_t)B * Cin * L * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dw.p, wp, (size_t)Mtot * Cin * KS * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dl.p, lens, (size_t)B * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemsetAsync(dout.p, 0, (size_t)B * Cout * Lout * 4, st_));
+        if (bias) {
+            db.ensure((size_t)Cout * 4);
+            HIP_CHECK(hipMemcpy(db.p, bias, (size_t)Cout * 4, hipMemcpyHostToDevice));
+        }
+        if (res) {
+            dr.ensure((size_t)B * Cout * Lout * 4);
+            HIP_CHECK(hipMemcpy(dr.p, res, (size_t)B * Cout * Lout * 4, hipMemcpyHostToDevice));
+        }
+        ConvArgs a{};
+        a.x = dx.as<float>();
+        a.wp = dw.as<float>();
+        a.bias = bias ? db.as<float>() : nullptr;
+        a.res = res ? dr.as<float>() : nullptr;
+        a.out = dout.as<float>();
+        a.base_len = dl.as<int>();
+        a.len_mul = 1;
+        a.Cin = Cin; a.Mtot = Mtot; a.Cout = Cout;
+        a.x_stride = L; a.o_stride = Lout;
+        a.x_bstride = (long)Cin * L; a.o_bstride = (long)Cout * Lout;
+        a.padl = padl; a.slope = slope; a.ups_s = ups_s; a.ups_p = ups_p;
+        a.max_len = *std::max_element(lens, lens + B);
+        a.B = B;
+        launch_conv1d(a, KS, DIL, st_);
+        HIP_CHECK(hipStreamSynchronize(st_));
+        HIP_CHECK(hipMemcpy(out, dout.p, (size_t)B * Cout * Lout * 4, hipMemcpyDeviceToHost));
+    }
+    void dbg_prefill(const int* text_ids, int n_text, uint64_t key, float rep_penalty, float* lnf_rows_out,
+                     float* logits_out) {
+        use();
+        ensure_gpt();
+        AUR_REQUIRE(idle(), "dbg_prefill needs an idle engine");
+        aur_seq_desc d{};
+        d.text_ids = text_ids; d.n_text = n_text; d.speaker_key = key; d.temperature = 0.f; d.top_p = 1.f; d.top_k = -1;
+        d.repetition_penalty = rep_penalty; d.max_tokens = 1; d.seed = 0; d.ignore_stop = 1;
+        const uint64_t id = submit(d);
+        dbg_logits_.ensure((size_t)kMelVocab * 4);
+        dbg_capture_ = true;
+        step(nullptr, nullptr);
+        dbg_capture_ = false;
+        Seq* s = seqs_.at(id).get();
+        if (lnf_rows_out)
+            HIP_CHECK(hipMemcpy(lnf_rows_out, dbg_lnf_.p, (size_t)s->n_prompt * kHidden * 4, hipMemcpyDeviceToHost));
+        if (logits_out) HIP_CHECK(hipMemcpy(logits_out, dbg_logits_.p, (size_t)kMelVocab * 4, hipMemcpyDeviceToHost));
+        aur_result r;
+        while (poll(&r, 1) == 1) {
+        }
+        release(id);
+    }
+    void dbg_sample(const float* logits, int B, float temperature, float top_p, int top_k, float rep,
+                    const uint8_t* seen, uint32_t seed, int step_idx, int* tokens_out) {
+        use();
+        AUR_REQUIRE(idle(), "dbg_sample needs an idle engine");
+        AUR_REQUIRE(B >= 1 && B <= cfg_.max_seqs, "B <= max_seqs");
+        std::vector<SlotInit> init(B);
+        std::vector<int> slots(B);
+        for (int b = 0; b < B; ++b) {
+            init[b] = SlotInit{b, temperature, top_p, top_k, rep, 1 << 30, 1, seed + (unsigned)b, step_idx};
+            slots[b] = b;
+        }
+        init_slots(init);
+        if (seen) {
+            for (int b = 0; b < B; ++b)
+                HIP_CHECK(hipMemcpyAsync(seen_.as<unsigned char>() + (long)b * kSeenStride, seen + (long)b * kMelVocab,
+                                         kMelVocab, hipMemcpyHostToDevice, st_));
+        } else {
+            HIP_CHECK(hipMemsetAsync(seen_.p, 0, (size_t)B * kSeenStride, st_));
+        }
+        DevBuf dl;
+        dl.ensure((size_t)B * kMelVocab * 4);
+        HIP_CHECK(hipMemcpyAsync(dl.p, logits, (size_t)B * kMelVocab * 4, hipMemcpyHostToDevice, st_));
+        i_sample_slot_.ensure(B * 4);
+        i_out_tok_.ensure(B * 4);
+        HIP_CHECK(hipMemcpyAsync(i_sample_slot_.p, slots.data(), B * 4, hipMemcpyHostToDevice, st_));
+        SamplerArgs a = sampler_args(dl.as<float>(), 1, B, kMelVocab, zero_bias_.as<float>(), nullptr);
+        launch_sampler(a, st_);
+        HIP_CHECK(hipStreamSynchronize(st_));
+        HIP_CHECK(hipMemcpy(tokens_out, i_out_tok_.p, B * 4, hipMemcpyDeviceToHost));
+    }
+
+private:
+    static constexpr int kMaxBlocks = 66;         // ceil(1047 / 16)
+    static constexpr int kMaxLatRows = 608;
+    static constexpr int kMelVocab = 1026;
+    static constexpr int kHeadPad = 1088;         // mel_head columns padded to a multiple of 64
+    static constexpr int kStartToken = 1024, kStopToken = 1025;
+    static constexpr long kCondStride = 1024;
+
+    bool idle() {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!waiting_.empty()) return false;
+        for (auto* s : slot_owner_)
+            if (s) return false;
+        return true;
+    }
+
+    static int frames_for(int n_lat) { return (int)std::floor((double)(4 * n_lat) * (24000.0 / 22050.0)); }
+
+    // ------------------------------------------------------------------ GPT
+    struct LayerW {
+        const float *ln1w, *ln1b, *wqkv, *bqkv, *wproj, *bproj, *ln2w, *ln2b, *wfc, *bfc, *wproj2, *bproj2;
+    };
+    void ensure_gpt() {
+        if (gpt_ready_) return;
+        layers_.clear();
+        const int H = kHidden;
+        for (int i = 0; i < cfg_.n_layer; ++i) {
+            const std::string p = "gpt.h." + std::to_string(i) + ".";
+            LayerW l;
+            l.ln1w = W(p + "ln_1.w", H); l.ln1b = W(p + "ln_1.b", H);
+            l.wqkv = W(p + "attn.c_attn.w", (int64_t)H * 3 * H); l.bqkv = W(p + "attn.c_attn.b", 3 * H);
+            l.wproj = W(p + "attn.c_proj.w", (int64_t)H * H); l.bproj = W(p + "attn.c_proj.b", H);
+            l.ln2w = W(p + "ln_2.w", H); l.ln2b = W(p + "ln_2.b", H);
+            l.wfc = W(p + "mlp.c_fc.w", (int64_t)H * 4 * H); l.bfc = W(p + "mlp.c_fc.b", 4 * H);
+            l.wproj2 = W(p + "mlp.c_proj.w", (int64_t)4 * H * H); l.bproj2 = W(p + "mlp.c_proj.b", H);
+            layers_.push_back(l);
+        }
+        wte_ = W("gpt.wte", (int64_t)kMelVocab * H);
+        wpe_ = W("gpt.wpe", (int64_t)kMaxLatRows * H);
+        lnfw_ = W("gpt.ln_f.w", H); lnfb_ = W("gpt.ln_f.b", H);
+        fnw_ = W("final_norm.w", H); fnb_ = W("final_norm.b", H);
+        headT_ = W("mel_head.wT", (int64_t)H * kHeadPad);
+        headb_ = W("mel_head.b", kHeadPad);
+        text_emb_ = W("text_emb");
+        text_pos_ = W("text_pos");
+        text_vocab_ = (int)(w_.at("text_emb").numel / H);
+        text_positions_ = (int)(w_.at("text_pos").numel / H);
+        ensure_voc();
+        gpt_ready_ = true;
+    }
+    void ensure_rows(int M) {
+        if (M <= rows_cap_) return;
+        const int cap = std::max(M, 64);
+        h_.ensure((size_t)cap * kHidden * 4);
+        xn_.ensure((size_t)cap * kHidden * 4);
+        qbuf_.ensure((size_t)cap * kHidden * 4);
+        att_.ensure((size_t)cap * kHidden * 4);
+        act_.ensure((size_t)cap * 4 * kHidden * 4);
+        // slabs: small M uses split-K (<=16 slabs of M x 1024 or 4 slabs of M x 4096), large M one slab
+        const size_t slab = std::max((size_t)16 * std::min(cap, 128) * 4096, (size_t)cap * 4096);
+        P_.ensure(slab * 4);
+        i_row_slot_.ensure((size_t)cap * 4);
+        i_row_pos_.ensure((size_t)cap * 4);
+        i_desc_.ensure((size_t)cap * sizeof(int4));
+        rows_cap_ = cap;
+    }
+    void forward_rows(int M, const int* d_row_slot, const int* d_row_pos) {
+        float* h = h_.as<float>();
+        float* xn = xn_.as<float>();
+        float* P = P_.as<float>();
+        const int* bt = block_tables_.as<int>();
+        const int* kvpos = slot_kvpos_.as<int>();
+        launch_rows_ln(nullptr, 0, nullptr, h, layers_[0].ln1w, layers_[0].ln1b, xn, M, 1e-5f, st_);
+        const int kw1 = gemm_pick_kw(M, kHidden), S1 = kHidden / (4 * kw1);
+        const int kw4 = gemm_pick_kw(M, 4 * kHidden), S4 = 4 * kHidden / (4 * kw4);
+        for (int l = 0; l < cfg_.n_layer; ++l) {
+            const LayerW& L = layers_[l];
+            float* kvl = kv_.as<float>() + (long)l * kv_layer_stride_;
+            launch_gemm_splitk(xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, kw1, st_);
+            launch_qkv_epilogue(P, S1, L.bqkv, qbuf_.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, st_);
+            launch_paged_attention(qbuf_.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, att_.as<float>(), M, st_);
+            launch_gemm_splitk(att_.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, kw1, st_);
+            launch_rows_ln(P, S1, L.bproj, h, L.ln2w, L.ln2b, xn, M, 1e-5f, st_);
+            launch_gemm_splitk(xn, kHidden, L.wfc, P, M, 4 * kHidden, kHidden, kw1, st_);
+            launch_bias_gelu(P, S1, L.bfc, act_.as<float>(), M, 4 * kHidden, st_);
+            launch_gemm_splitk(act_.as<float>(), 4 * kHidden, L.wproj2, P, M, kHidden, 4 * kHidden, kw4, st_);
+            const bool last = (l + 1 == cfg_.n_layer);
+            launch_rows_ln(P, S4, L.bproj2, h, last ? lnfw_ : layers_[l + 1].ln1w, last ? lnfb_ : layers_[l + 1].ln1b,
+                           xn, M, 1e-5f, st_);
+        }
+    }
+    SamplerArgs sampler_args(const float* P, int S, int Ms, int Npad, const float* bias, const int* next_kvpos) {
+        SamplerArgs a{};
+        a.P = P; a.S = S; a.Ms = Ms; a.Npad = Npad; a.V = kMelVocab; a.bias = bias;
+        a.sample_slot = i_sample_slot_.as<int>();
+        a.next_kvpos = next_kvpos;
+        a.seen = seen_.as<unsigned char>();
+        a.slot_tok = slot_tok_.as<int>(); a.slot_pos = slot_pos_.as<int>(); a.slot_kvpos = slot_kvpos_.as<int>();
+        a.slot_ngen = slot_ngen_.as<int>(); a.slot_finished = slot_finished_.as<int>();
+        a.temperature = temperature_.as<float>(); a.top_p = top_p_.as<float>(); a.top_k = top_k_.as<int>();
+        a.rep_penalty = rep_.as<float>(); a.max_tokens = max_tokens_.as<int>(); a.ignore_stop = ignore_stop_.as<int>();
+        a.seed = seed_.as<unsigned>();
+        a.out_tok = i_out_tok_.as<int>();
+        a.dbg_logits = dbg_capture_ ? dbg_logits_.as<float>() : nullptr;
+        a.stop_token = kStopToken;
+        return a;
+    }
+    // final_norm -> latent stash -> mel_head GEMM -> fused sampler -> read back tokens/finished flags
+    void sample_rows(const std::vector<int>& sample_row, const std::vector<int>& sample_slot,
+                     const std::vector<int>* next_kvpos) {
+        const int Ms = (int)sample_slot.size();
+        i_sample_row_.ensure((size_t)Ms * 4);
+        i_sample_slot_.ensure((size_t)Ms * 4);
+        i_next_kvpos_.ensure((size_t)Ms * 4);
+        i_out_tok_.ensure((size_t)Ms * 4);
+        ybuf_.ensure((size_t)std::max(Ms, 64) * kHidden * 4);
+        P2_.ensure((size_t)4 * std::max(Ms, 64) * kHeadPad * 4);
+        HIP_CHECK(hipMemcpyAsync(i_sample_row_.p, sample_row.data(), (size_t)Ms * 4, hipMemcpyHostToDevice, st_));
+        HIP_CHECK(hipMemcpyAsync(i_sample_slot_.p, sample_slot.data(), (size_t)Ms * 4, hipMemcpyHostToDevice, st_));
+        if (next_kvpos)
+            HIP_CHECK(hipMemcpyAsync(i_next_kvpos_.p, next_kvpos->data(), (size_t)Ms * 4, hipMemcpyHostToDevice, st_));
+        launch_final_norm(xn_.as<float>(), i_sample_row_.as<int>(), i_sample_slot_.as<int>(), fnw_, fnb_, ybuf_.as<float>(),
+                          latents_.as<float>(), (long)kMaxLatRows * kHidden, slot_ngen_.as<int>(), kMaxLatRows, Ms, 1e-5f, st_);
+        const int kw = 64, S = kHidden / (4 * kw);
+        launch_gemm_splitk(ybuf_.as<float>(), kHidden, headT_, P2_.as<float>(), Ms, kHeadPad, kHidden, kw, st_);
+        SamplerArgs a = sampler_args(P2_.as<float>(), S, Ms, kHeadPad, headb_, next_kvpos ? i_next_kvpos_.as<int>() : nullptr);
+        launch_sampler(a, st_);
+        int* pin = pin_.as<int>();
+        HIP_CHECK(hipMemcpyAsync(pin, i_out_tok_.p, (size_t)Ms * 4, hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipMemcpyAsync(pin + cfg_.max_seqs, slot_finished_.p, (size_t)cfg_.max_seqs * 4, hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipStreamSynchronize(st_));
+        for (int j = 0; j < Ms; ++j) {
+            Seq* s = slot_owner_[sample_slot[j]];
+            s->tokens.push_back(pin[j]);
+            stats_.tokens_generated++;
+            if (pin[cfg_.max_seqs + sample_slot[j]]) finish_tokens(s);
+        }
+    }
+    void finish_tokens(Seq* s) {
+        s->state = SeqState::TOKENS_DONE;
+        std::lock_guard<std::mutex> lk(mu_);
+        for (int b : s->blocks) free_blocks_.push_back(b);
+        s->blocks.clear();
+    }
+    void init_slots(const std::vector<SlotInit>& init) {
+        i_init_.ensure(init.size() * sizeof(SlotInit));
+        HIP_CHECK(hipMemcpyAsync(i_init_.p, init.data(), init.size() * sizeof(SlotInit), hipMemcpyHostToDevice, st_));
+        hipLaunchKernelGGL(init_slots_kernel, dim3((unsigned)init.size()), dim3(256), 0, st_, i_init_.as<SlotInit>(),
+                           slot_tok_.as<int>(), slot_pos_.as<int>(), slot_kvpos_.as<int>(), slot_ngen_.as<int>(),
+                           slot_finished_.as<int>(), temperature_.as<float>(), top_p_.as<float>(), top_k_.as<int>(),
+                           rep_.as<float>(), max_tokens_.as<int>(), ignore_stop_.as<int>(), seed_.as<unsigned>(),
+                           seen_.as<unsigned char>(), kStartToken);
+        HIP_CHECK(hipGetLastError());
+    }
+    void prefill(const std::vector<Seq*>& seqs) {
+        std::vector<int4> desc;
+        std::vector<int> row_slot, row_pos, sample_row, sample_slot, next_kvpos;
+        std::vector<SlotInit> init;
+        for (Seq* s : seqs) {
+            const aur_seq_desc& p = s->params;
+            init.push_back(SlotInit{s->slot, p.temperature, p.top_p, p.top_k, p.repetition_penalty, p.max_tokens,
+                                    p.ignore_stop, p.seed, 0});
+            for (int i = 0; i < 32; ++i) desc.push_back(make_int4(0, i, s->spk_row, 0));
+            for (int i = 0; i < (int)s->text_ids.size(); ++i) {
+                const int id = s->text_ids[i];
+                AUR_REQUIRE(id >= 0 && id < text_vocab_ && i < text_positions_, "text id / position out of range");
+                desc.push_back(make_int4(1, id, i, 0));
+            }
+            desc.push_back(make_int4(2, kStartToken, 0, 0));
+            for (int i = 0; i < s->n_prompt; ++i) {
+                row_slot.push_back(s->slot);
+                row_pos.push_back(i);
+            }
+            sample_row.push_back((int)row_slot.size() - 1);
+            sample_slot.push_back(s->slot);
+            next_kvpos.push_back(s->n_prompt);
+        }
+        const int M = (int)row_slot.size();
+        ensure_rows(M);
+        init_slots(init);
+        HIP_CHECK(hipMemcpyAsync(block_tables_.p, h_block_tables_.data(), h_block_tables_.size() * 4, hipMemcpyHostToDevice, st_));
+        HIP_CHECK(hipMemcpyAsync(i_desc_.p, desc.data(), (size_t)M * sizeof(int4), hipMemcpyHostToDevice, st_));
+        HIP_CHECK(hipMemcpyAsync(i_row_slot_.p, row_slot.data(), (size_t)M * 4, hipMemcpyHostToDevice, st_));
+        HIP_CHECK(hipMemcpyAsync(i_row_pos_.p, row_pos.data(), (size_t)M * 4, hipMemcpyHostToDevice, st_));
+        launch_embed_prompt(i_desc_.as<int4>(), spk_table_.as<float>(), text_emb_, text_pos_, wte_, wpe_, h_.as<float>(), M, st_);
+        forward_rows(M, i_row_slot_.as<int>(), i_row_pos_.as<int>());
+        if (dbg_capture_) {
+            dbg_lnf_.ensure((size_t)M * kHidden * 4);
+            HIP_CHECK(hipMemcpyAsync(dbg_lnf_.p, xn_.p, (size_t)M * kHidden * 4, hipMemcpyDeviceToDevice, st_));
+        }
+        stats_.prefill_rows += M;
+        sample_rows(sample_row, sample_slot, &next_kvpos);
+    }
+    void decode(const std::vector<int>& active) {
+        const int M = (int)active.size();
+        ensure_rows(M);
+        HIP_CHECK(hipMemcpyAsync(i_row_slot_.p, active.data(), (size_t)M * 4, hipMemcpyHostToDevice, st_));
+        launch_embed_decode(i_row_slot_.as<int>(), slot_tok_.as<int>(), slot_pos_.as<int>(), wte_, wpe_, h_.as<float>(), M, st_);
+        forward_rows(M, i_row_slot_.as<int>(), nullptr);
+        std::vector<int> sample_row(M);
+        for (int i = 0; i < M; ++i) sample_row[i] = i;
+        stats_.decode_rows += M;
+        sample_rows(sample_row, active, nullptr);
+    }
+
+    // ------------------------------------------------------------------ vocoder
+    struct ConvEvent {
+        hipEvent_t a, b;
+        double flops, bytes;
+        bool used;
+    };
+    void ensure_voc() {
+        if (voc_ready_) return;
+        auto get = [&](const std::string& n) { return W(n); };
+        v_pre_ = ConvLayer{get("voc.conv_pre.wp"), get("voc.conv_pre.bias")};
+        for (int i = 0; i < 4; ++i) {
+            v_ups_[i] = ConvLayer{get("voc.ups." + std::to_string(i) + ".wp"), get("voc.ups." + std::to_string(i) + ".bias")};
+            for (int j = 0; j < 3; ++j)
+                for (int c = 0; c < 3; ++c) {
+                    const std::string p = "voc.rb." + std::to_string(i * 3 + j) + ".";
+                    v_c1_[i][j][c] = ConvLayer{get(p + "c1." + std::to_string(c) + ".wp"), get(p + "c1." + std::to_string(c) + ".bias")};
+                    v_c2_[i][j][c] = ConvLayer{get(p + "c2." + std::to_string(c) + ".wp"), get(p + "c2." + std::to_string(c) + ".bias")};
+                }
+        }
+        v_post_ = get("voc.conv_post.w");
+        voc_ready_ = true;
+    }
+    void conv(ConvArgs& a, int KS, int DIL, double tot_in, double tot_out) {
+        const bool prof = cfg_.profile != 0;
+        ConvEvent* ev = nullptr;
+        if (prof) {
+            if (n_conv_events_ == conv_events_.size()) {
+                ConvEvent e{};
+                HIP_CHECK(hipEventCreate(&e.a));
+                HIP_CHECK(hipEventCreate(&e.b));
+                conv_events_.push_back(e);
+            }
+            ev = &conv_events_[n_conv_events_++];
+            ev->flops = 2.0 * a.Cin * KS * a.Mtot * tot_in;
+            ev->bytes = 4.0 * (a.Cin * tot_in + a.Cout * tot_out * (1.0 + (a.res ? 1.0 : 0.0) + (a.mrf_mode >= 2 ? 1.0 : 0.0)));
+            HIP_CHECK(hipEventRecord(ev->a, st_));
+        }
+        launch_conv1d(a, KS, DIL, st_);
+        if (prof) HIP_CHECK(hipEventRecord(ev->b, st_));
+    }
+    void collect_conv_events() {
+        for (size_t i = 0; i < n_conv_events_; ++i) {
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, conv_events_[i].a, conv_events_[i].b));
+            stats_.conv_ms += ms;
+            stats_.conv_flops += conv_events_[i].flops;
+            stats_.conv_bytes += conv_events_[i].bytes;
+            stats_.conv_launches++;
+        }
+        n_conv_events_ = 0;
+        if (voc_timed_) {
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, ev_va_, ev_vb_));
+            stats_.vocoder_ms += ms;
+            voc_timed_ = false;
+        }
+    }
+    // latents: d_lat + lat_row[b]*lat_bstride (lat_row nullable => b); wav: d_wav + b*wav_bstride
+    void run_vocoder(int B, const std::vector<int>& n_lat, const float* d_lat, long lat_bstride,
+                     const std::vector<int>* lat_row, const std::vector<int>& cond_row, float* d_wav, long wav_bstride) {
+        ensure_voc();
+        if (!ev_va_) {
+            HIP_CHECK(hipEventCreate(&ev_va_));
+            HIP_CHECK(hipEventCreate(&ev_vb_));
+        }
+        std::vector<int>& meta = h_meta_;   // member: the async H2D copy below must not outlive its source
+        meta.assign(4 * (size_t)B, 0);
+        int maxT = 0;
+        double totT = 0;
+        for (int b = 0; b < B; ++b) {
+            meta[b] = n_lat[b];
+            meta[B + b] = frames_for(n_lat[b]);
+            meta[2 * B + b] = cond_row[b];
+            meta[3 * B + b] = lat_row ? (*lat_row)[b] : b;
+            maxT = std::max(maxT, meta[B + b]);
+            totT += meta[B + b];
+        }
+        v_meta_.ensure(meta.size() * 4);
+        HIP_CHECK(hipMemcpyAsync(v_meta_.p, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, st_));
+        const int* d_nlat = v_meta_.as<int>();
+        const int* d_len = d_nlat + B;
+        const int* d_cond = d_nlat + 2 * B;
+        const int* d_latrow = d_nlat + 3 * B;
+        const size_t T = (size_t)maxT, Bz = (size_t)B;
+        v_z_.ensure(Bz * 1024 * T * 4);
+        v_s0_.ensure(Bz * 512 * T * 4);
+        for (auto* b : {&v_A_, &v_B_, &v_C_, &v_D_, &v_E_}) b->ensure(Bz * 8192 * T * 4);
+        HIP_CHECK(hipEventRecord(ev_va_, st_));
+        launch_interp2(d_lat, lat_bstride, d_latrow, d_nlat, d_len, v_z_.as<float>(), (long)T, (long)(1024 * T), 1024, B, maxT, st_);
+        const float* condt = voc_cond_.as<float>();
+        ConvArgs a{};
+        a.base_len = d_len; a.B = B; a.cond_row = d_cond; a.cond_stride = kCondStride;
+        // conv_pre (+ cond_layer)
+        a.x = v_z_.as<float>(); a.wp = v_pre_.wp; a.bias = v_pre_.bias; a.cond = condt; a.res = nullptr; a.mrf = nullptr;
+        a.out = v_s0_.as<float>(); a.len_mul = 1; a.Cin = 1024; a.Mtot = 512; a.Cout = 512;
+        a.x_stride = (long)T; a.o_stride = (long)T; a.x_bstride = (long)(1024 * T); a.o_bstride = (long)(512 * T);
+        a.padl = 3; a.slope = 1.0f; a.ups_s = 0; a.ups_p = 0; a.mrf_mode = 0; a.max_len = maxT;
+        conv(a, 7, 1, totT, totT);
+        const int rates[4] = {8, 8, 2, 2}, kern[4] = {16, 16, 4, 4}, chans[4] = {256, 128, 64, 32};
+        const int rk[3] = {3, 7, 11}, rd[3] = {1, 3, 5};
+        const float* in = v_s0_.as<float>();
+        int Cin = 512, mul = 1, cond_off = 512;
+        float *A = v_A_.as<float>(), *Bb = v_B_.as<float>(), *Cb = v_C_.as<float>(), *D = v_D_.as<float>(), *E = v_E_.as<float>();
+        for (int i = 0; i < 4; ++i) {
+            const int s = rates[i], C = chans[i], mul_out = mul * s;
+            const long Lin = (long)T * mul, Lout = (long)T * mul_out;
+            // transposed conv as 2-tap polyphase conv over virtual channels co*s + r
+            a = ConvArgs{};
+            a.base_len = d_len; a.B = B; a.cond_row = d_cond; a.cond_stride = kCondStride;
+            a.x = in; a.wp = v_ups_[i].wp; a.bias = v_ups_[i].bias; a.cond = condt + cond_off; a.out = A;
+            a.len_mul = mul; a.Cin = Cin; a.Mtot = C * s; a.Cout = C;
+            a.x_stride = Lin; a.x_bstride = (long)Cin * Lin; a.o_stride = Lout; a.o_bstride = (long)C * Lout;
+            a.padl = 1; a.slope = 0.1f; a.ups_s = s; a.ups_p = (kern[i] - s) / 2; a.mrf_mode = 0; a.max_len = maxT * mul;
+            conv(a, 2, 1, totT * mul, totT * mul_out);
+            cond_off += C;
+            for (int j = 0; j < 3; ++j)
+                for (int c = 0; c < 3; ++c) {
+                    const float* r = (c == 0) ? A : Cb;
+                    ConvArgs b1{};
+                    b1.base_len = d_len; b1.B = B;
+                    b1.x = r; b1.wp = v_c1_[i][j][c].wp; b1.bias = v_c1_[i][j][c].bias; b1.out = Bb;
+                    b1.len_mul = mul_out; b1.Cin = C; b1.Mtot = C; b1.Cout = C;
+                    b1.x_stride = Lout; b1.o_stride = Lout; b1.x_bstride = (long)C * Lout; b1.o_bstride = (long)C * Lout;
+                    b1.padl = (rk[j] - 1) / 2 * rd[c]; b1.slope = 0.1f; b1.max_len = maxT * mul_out;
+                    conv(b1, rk[j], rd[c], totT * mul_out, totT * mul_out);
+                    ConvArgs b2 = b1;
+                    b2.x = Bb; b2.wp = v_c2_[i][j][c].wp; b2.bias = v_c2_[i][j][c].bias; b2.res = r;
+                    b2.padl = (rk[j] - 1) / 2;
+                    if (c < 2) {
+                        b2.out = Cb;
+                    } else {
+                        b2.mrf = D; b2.out = E; b2.mrf_mode = (j == 0) ? 1 : (j == 1) ? 2 : 3;
+                    }
+                    conv(b2, rk[j], 1, totT * mul_out, totT * mul_out);
+                }
+            in = E; Cin = C; mul = mul_out;
+        }
+        launch_conv_post(E, v_post_, d_wav, d_len, 256, 32, (long)T * 256, (long)32 * T * 256, wav_bstride, 0.01f, B, maxT * 256, st_);
+        HIP_CHECK(hipEventRecord(ev_vb_, st_));
+        voc_timed_ = true;
+        stats_.vocoder_batches++;
+    }
+    void vocode_finished(const std::vector<Seq*>& ready) {
+        const int B = (int)ready.size();
+        std::vector<int> nl(B), rows(B), cond(B);
+        int max_samples = 0;
+        for (int b = 0; b < B; ++b) {
+            nl[b] = (int)ready[b]->tokens.size();
+            rows[b] = ready[b]->slot;
+            cond[b] = ready[b]->spk_row;
+            max_samples = std::max(max_samples, frames_for(nl[b]) * 256);
+        }
+        tmp_wav_.ensure((size_t)B * max_samples * 4);
+        run_vocoder(B, nl, latents_.as<float>(), (long)kMaxLatRows * kHidden, &rows, cond, tmp_wav_.as<float>(), max_samples);
+        HIP_CHECK(hipStreamSynchronize(st_));
+        collect_conv_events();
+        for (int b = 0; b < B; ++b) {
+            Seq* s = ready[b];
+            const int ns = frames_for(nl[b]) * 256;
+            s->wav.resize(ns);
+            HIP_CHECK(hipMemcpy(s->wav.data(), tmp_wav_.as<float>() + (long)b * max_samples, (size_t)ns * 4, hipMemcpyDeviceToHost));
+            s->latents.resize((size_t)nl[b] * kHidden);
+            HIP_CHECK(hipMemcpy(s->latents.data(), latents_.as<float>() + (long)s->slot * kMaxLatRows * kHidden,
+                                s->latents.size() * 4, hipMemcpyDeviceToHost));
+            stats_.samples_generated += ns;
+            std::lock_guard<std::mutex> lk(mu_);
+            slot_owner_[s->slot] = nullptr;
+            s->slot = -1;
+            s->state = SeqState::DONE;
+            done_.push_back(s);
+            finished_total_++;
+        }
+    }
+
+    aur_config cfg_;
+    int device_;
+    hipStream_t st_ = nullptr;
+    hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr, ev_va_ = nullptr, ev_vb_ = nullptr;
+    bool voc_timed_ = false;
+    std::unordered_map<std::string, Tensor> w_;
+    bool gpt_ready_ = false, voc_ready_ = false;
+    std::vector<LayerW> layers_;
+    const float *wte_ = nullptr, *wpe_ = nullptr, *lnfw_ = nullptr, *lnfb_ = nullptr, *fnw_ = nullptr, *fnb_ = nullptr,
+                *headT_ = nullptr, *headb_ = nullptr, *text_emb_ = nullptr, *text_pos_ = nullptr;
+    int text_vocab_ = 0, text_positions_ = 0;
+    // KV pool
+    DevBuf kv_;
+    long n_blocks_ = 0, kv_layer_stride_ = 0;
+    std::vector<int> free_blocks_;
+    std::vector<int> h_block_tables_;
+    // per-slot device state
+    DevBuf slot_tok_, slot_pos_, slot_kvpos_, slot_ngen_, slot_finished_, temperature_, top_p_, top_k_, rep_, max_tokens_,
+        ignore_stop_, seed_, block_tables_, seen_, latents_;
+    DevBuf spk_table_, spk_emb_, voc_cond_, zero_bias_;
+    std::map<uint64_t, int> spk_rows_;
+    // row workspace
+    int rows_cap_ = 0;
+    DevBuf h_, xn_, qbuf_, att_, act_, P_, P2_, ybuf_;
+    DevBuf i_row_slot_, i_row_pos_, i_desc_, i_sample_row_, i_sample_slot_, i_next_kvpos_, i_out_tok_, i_init_;
+    PinBuf pin_;
+    DevBuf dbg_lnf_, dbg_logits_;
+    bool dbg_capture_ = false;
+    // vocoder
+    ConvLayer v_pre_, v_ups_[4], v_c1_[4][3][3], v_c2_[4][3][3];
+    const float* v_post_ = nullptr;
+    DevBuf v_meta_, v_z_, v_s0_, v_A_, v_B_, v_C_, v_D_, v_E_, tmp_lat_, tmp_wav_;
+    std::vector<ConvEvent> conv_events_;
+    std::vector<int> h_meta_;
+    size_t n_conv_events_ = 0;
+    // sequences
+    std::mutex mu_;
+    uint64_t next_id_ = 1;
+    std::unordered_map<uint64_t, std::unique_ptr<Seq>> seqs_;
+    std::deque<Seq*> waiting_, done_;
+    std::vector<Seq*> slot_owner_;
+    int64_t finished_total_ = 0;
+    aur_stats stats_{};
+};
+
+}  // namespace aur
+
+// ================================================================================================ C ABI
+struct aur_engine {
+    aur::Engine impl;
+    aur_engine(const aur_config& c, int dev) : impl(c, dev) {}
+};
+
+template <class F>
+static int guarded(F&& f) {
+    try {
+        f();
+        return AUR_OK;
+    } catch (const aur::HipError& e) {
+        aur::g_last_error = e.what();
+        const std::string m = e.what();
+        return (m.rfind("requirement failed", 0) == 0 || m.rfind("weight", 0) == 0) ? AUR_E_INVALID : AUR_E_HIP;
+    } catch (const std::bad_alloc&) {
+        aur::g_last_error = "out of host memory";
+        return AUR_E_NOMEM;
+    } catch (const std::exception& e) {
+        aur::g_last_error = e.what();
+        return AUR_E_INVALID;
+    }
+}
+#define CHECK_PTR(p)                                    \
+    if (!(p)) {                                         \
+        aur::g_last_error = "null argument: " #p;       \
+        return AUR_E_INVALID;                           \
+    }
+
+extern "C" {
+
+const char* aur_last_error(void) { return aur::g_last_error.c_str(); }
+int aur_version(void) { return 1; }
+
+int aur_engine_create(const aur_config* cfg, int device_id, aur_engine** out) {
+    CHECK_PTR(cfg);
+    CHECK_PTR(out);
+    *out = nullptr;
+    return guarded([&] {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+            throw aur::HipError("no HIP device visible: the MI355X path has no CPU fallback");
+        AUR_REQUIRE(device_id >= 0 && device_id < n, "device_id out of range");
+        *out = new aur_engine(*cfg, device_id);
+    });
+}
+int aur_engine_destroy(aur_engine* e) {
+    CHECK_PTR(e);
+    return guarded([&] { delete e; });
+}
+int aur_load_weights(aur_engine* e, const aur_tensor_desc* t, size_t n) {
+    CHECK_PTR(e);
+    CHECK_PTR(t);
+    return guarded([&] { e->impl.load(t, n); });
+}
+int aur_set_conditioning(aur_engine* e, uint64_t key, const float* gpt_cond, const float* spk) {
+    CHECK_PTR(e);
+    CHECK_PTR(gpt_cond);
+    CHECK_PTR(spk);
+    return guarded([&] { e->impl.set_conditioning(key, gpt_cond, spk, false); });
+}
+int aur_set_conditioning_device(aur_engine* e, uint64_t key, const float* d_gpt_cond, const float* d_spk) {
+    CHECK_PTR(e);
+    CHECK_PTR(d_gpt_cond);
+    CHECK_PTR(d_spk);
+    return guarded([&] { e->impl.set_conditioning(key, d_gpt_cond, d_spk, true); });
+}
+int aur_submit(aur_engine* e, const aur_seq_desc* seq, uint64_t* seq_id) {
+    CHECK_PTR(e);
+    CHECK_PTR(seq);
+    CHECK_PTR(seq_id);
+    return guarded([&] { *seq_id = e->impl.submit(*seq); });
+}
+int aur_step(aur_engine* e, int32_t* n_live, int32_t* n_finished_total) {
+    CHECK_PTR(e);
+    return guarded([&] { e->impl.step(n_live, n_finished_total); });
+}
+int aur_poll_finished(aur_engine* e, aur_result* out, size_t cap, size_t* n) {
+    CHECK_PTR(e);
+    CHECK_PTR(out);
+    CHECK_PTR(n);
+    return guarded([&] { *n = e->impl.poll(out, cap); });
+}
+int aur_release(aur_engine* e, uint64_t seq_id) {
+    CHECK_PTR(e);
+    return guarded([&] { e->impl.release(seq_id); });
+}
+int aur_vocode(aur_engine* e, const float* latents, const int32_t* n_lat, int32_t B, int32_t t_max,
+               uint64_t speaker_key, float* wav_out, int64_t wav_stride, int32_t* n_samples_out) {
+    CHECK_PTR(e);
+    CHECK_PTR(latents);
+    CHECK_PTR(n_lat);
+    CHECK_PTR(wav_out);
+    return guarded([&] { e->impl.vocode_host(latents, n_lat, B, t_max, speaker_key, wav_out, wav_stride, n_samples_out); });
+}
+int aur_sync(aur_engine* e) {
+    CHECK_PTR(e);
+    return guarded([&] { e->impl.sync(); });
+}
+int aur_get_stats(aur_engine* e, aur_stats* out) {
+    CHECK_PTR(e);
+    CHECK_PTR(out);
+    return guarded([&] { *out = e->impl.stats(); });
+}
+int aur_reset_stats(aur_engine* e) {
+    CHECK_PTR(e);
+    return guarded([&] { e->impl.reset_stats(); });
+}
+int aur_dbg_gemm(aur_engine* e, const float* X, const float* W, float* out, int32_t M, int32_t N, int32_t K, int32_t kw) {
+    CHECK_PTR(e);
+    return guarded([&] { e->impl.dbg_gemm(X, W, out, M, N, K, kw); });
+}
+int aur_dbg_layernorm(aur_engine* e, const float* h, const float* gamma, const float* beta, float* out, int32_t M) {
+    CHECK_PTR(e);
+    return guarded([&] { e->impl.dbg_layernorm(h, gamma, beta, out, M); });
+}
+int aur_dbg_conv1d(aur_engine* e, const float* x, const float* wp, const float* bias, const float* res, float* out,
+                   const int32_t* lens, int32_t B, int32_t Cin, int32_t Mtot, int32_t Cout, int32_t L, int32_t KS,
+                   int32_t DIL, int32_t padl, float slope, int32_t ups_s, int32_t ups_p) {
+    CHECK_PTR(e);
+    return guarded([&] { e->impl.dbg_conv1d(x, wp, bias, res, out, lens, B, Cin, Mtot, Cout, L, KS, DIL, padl, slope, ups_s, ups_p); });
+}
+int aur_dbg_prefill(aur_engine* e, const int32_t* text_ids, int32_t n_text, uint64_t speaker_key, float repetition_penalty,
+                    float* lnf_rows_out, float* logits_out) {
+    CHECK_PTR(e);
+    CHECK_PTR(text_ids);
+    return guarded([&] { e->impl.dbg_prefill(text_ids, n_text, speaker_key, repetition_penalty, lnf_rows_out, logits_out); });
+}
+int aur_dbg_sample(aur_engine* e, const float* logits, int32_t B, float temperature, float top_p, int32_t top_k,
+                   float repetition_penalty, const uint8_t* seen, uint32_t seed, int32_t step, int32_t* tokens_out) {
+    CHECK_PTR(e);
+    CHECK_PTR(logits);
+    CHECK_PTR(tokens_out);
+    return guarded([&] { e->impl.dbg_sample(logits, B, temperature, top_p, top_k, repetition_penalty, seen, seed, step, tokens_out); });
+}
+
+}  // extern "C"

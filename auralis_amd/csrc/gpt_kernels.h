@@ -1,0 +1,77 @@
+// Launch wrappers for the xtts2-gpt token-loop kernels (gpt_kernels.hip).
+#pragma once
+#include "common.h"
+
+namespace aur {
+
+constexpr int kHidden = 1024;
+constexpr int kHeads = 16;
+constexpr int kHeadDim = 64;
+constexpr int kKvBlockTokens = 16;                                    // paged-KV block size (vLLM default)
+constexpr long kKvBlockElems = 2L * kHeads * kKvBlockTokens * kHeadDim;  // one layer, K and V
+
+// Split-K weight-streaming GEMM on exact-f32 MFMA (16x16x4):
+//   P[s][m][n] = sum_{k in slice s} X[m][k] * W[k][n],   W row-major [K][N] (HF Conv1D layout on disk)
+// slices = K / (4*kw).  N % 64 == 0, kw % 16 == 0.  P is [slices][M][N].
+void launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M, int N, int K, int kw,
+                        hipStream_t st);
+int gemm_pick_kw(int M, int K);
+
+// h[m] += sum_s P[s][m] + bias (if S > 0); out[m] = LayerNorm(h[m]; gamma, beta, eps).  Rows of 1024.
+void launch_rows_ln(const float* P, int S, const float* bias, float* h, const float* gamma, const float* beta,
+                    float* out, int M, float eps, hipStream_t st);
+
+// act[m][n] = gelu_new(sum_s P[s][m][n] + bias[n])
+void launch_bias_gelu(const float* P, int S, const float* bias, float* act, int M, int N, hipStream_t st);
+
+// qkv = sum_s P[s] + bias;  q -> qbuf[m][1024];  k,v -> paged cache of this layer at (slot, pos)
+void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, float* kv_layer,
+                         const int* row_slot, const int* row_pos, const int* slot_kvpos,
+                         const int* block_tables, int max_blocks, int M, hipStream_t st);
+
+// causal attention of every row against its sequence's paged K/V (keys 0..pos), 16 heads x 64
+void launch_paged_attention(const float* qbuf, const float* kv_layer, const int* row_slot, const int* row_pos,
+                            const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
+                            hipStream_t st);
+
+// prompt rows: desc[m] = {kind, a, b, _}: kind 0 -> spk_cond[b][a][:], 1 -> text_emb[a]+text_pos[b], 2 -> wte[a]+wpe[b]
+void launch_embed_prompt(const int4* desc, const float* spk_cond, const float* text_emb, const float* text_pos,
+                         const float* wte, const float* wpe, float* h, int M, hipStream_t st);
+// decode rows: h[m] = wte[tok[slot]] + wpe[pos[slot]]
+void launch_embed_decode(const int* row_slot, const int* slot_tok, const int* slot_pos, const float* wte,
+                         const float* wpe, float* h, int M, hipStream_t st);
+
+// y[j] = final_norm(xn[sample_row[j]]);  latents[slot][lat_idx[slot]] = final_norm(y[j])   (double final_norm,
+// XTTSv2.py:685-687 on top of vllm_mm_gpt.py:671)
+void launch_final_norm(const float* xn, const int* sample_row, const int* sample_slot, const float* gamma,
+                       const float* beta, float* ybuf, float* latents, long lat_slot_stride,
+                       const int* slot_ngen, int max_lat_rows, int Ms, float eps, hipStream_t st);
+
+struct SamplerArgs {
+    const float* P;          // [S][Ms][Npad] logits slabs
+    int S, Ms, Npad, V;
+    const float* bias;       // [Npad]
+    const int* sample_slot;  // [Ms]
+    const int* next_kvpos;   // [Ms] or nullptr (decode: kvpos += 1)
+    // per-slot state
+    unsigned char* seen;     // [slots][V_pad=1040]
+    int* slot_tok;
+    int* slot_pos;
+    int* slot_kvpos;
+    int* slot_ngen;
+    int* slot_finished;
+    const float* temperature;
+    const float* top_p;
+    const int* top_k;
+    const float* rep_penalty;
+    const int* max_tokens;
+    const int* ignore_stop;
+    const unsigned* seed;
+    int* out_tok;            // [Ms]
+    float* dbg_logits;       // optional [Ms][V] penalised logits
+    int stop_token;
+};
+void launch_sampler(const SamplerArgs& a, hipStream_t st);
+constexpr int kSeenStride = 1040;
+
+}  // namespace aur

@@ -1,0 +1,595 @@
+// xtts2-gpt token-loop kernels for gfx950 (MI355X): fp32 storage, exact-f32 MFMA GEMMs, paged KV.
+//
+// Reference arithmetic: src/auralis/models/xttsv2/components/vllm_mm_gpt.py (GPT2Model.forward 787-849,
+// compute_logits 664-688, sample 691-712), components/vllm/hijack.py:49-88 (repetition penalty), and the
+// vLLM 0.6.4.post1 GPT2Block / Sampler semantics restated in SURVEY.md Appendix A2-A5.
+#include "gpt_kernels.h"
+
+namespace aur {
+
+// ------------------------------------------------------------------------------------------------
+// Split-K weight-streaming GEMM.  One workgroup = 4 waves = one 64x64 output tile over a K-range of 4*kw;
+// wave w streams rows [kbeg + w*kw, +kw) of W straight from HBM into registers as float4 (16 lanes x 16 B =
+// one 256-B row segment, 4 rows per instruction) — no LDS round trip for an operand that is read once.
+// MFMA v_mfma_f32_16x16x4_f32 with a permuted K and N order so that the float4 loads ARE the fragments:
+//   step (s', c):  A[i][k'] = X[m][kb + 4k' + s'],  B[k'][j'] = W[kb + 4k' + s'][n0 + 4j' + c]
+//   D[i][j'] accumulates column n0 + 4j' + c, i.e. lane j' owns 4 consecutive columns across c = 0..3.
+__global__ __launch_bounds__(256) void gemm_splitk_kernel(const float* __restrict__ X, int ldx,
+                                                          const float* __restrict__ W, float* __restrict__ P,
+                                                          int M, int N, int kw) {
+    __shared__ __attribute__((aligned(16))) float red[3][64][68];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.x * 64, s = blockIdx.y, m0 = blockIdx.z * 64;
+    const int kbeg = (s * 4 + wv) * kw;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[mt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float* wp = W + (long)(kbeg + 4 * q) * N + n0 + 4 * i;
+    const float* xp[4];
+    bool xv[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int r = m0 + 16 * mt + i;
+        xv[mt] = r < M;
+        xp[mt] = X + (long)(xv[mt] ? r : 0) * ldx + kbeg + 4 * q;
+    }
+
+#pragma unroll 2
+    for (int kb = 0; kb < kw; kb += 16) {
+        f32x4 bf[4], af[4];
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) bf[sp] = *reinterpret_cast<const f32x4*>(wp + (long)(kb + sp) * N);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            af[mt] = *reinterpret_cast<const f32x4*>(xp[mt] + kb);
+            if (!xv[mt]) af[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][sp], bf[sp][c], acc[mt][c], 0, 0, 0);
+    }
+
+    // in-block reduction over the 4 K-slices: waves 1..3 park their tiles in LDS, wave 0 adds and stores.
+    if (wv > 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * mt + 4 * q + r;
+                f32x4 v = {acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+                *reinterpret_cast<f32x4*>(&red[wv - 1][row][4 * i]) = v;
+            }
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * mt + 4 * q + r;
+                f32x4 v = {acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+                v += *reinterpret_cast<const f32x4*>(&red[0][row][4 * i]);
+                v += *reinterpret_cast<const f32x4*>(&red[1][row][4 * i]);
+                v += *reinterpret_cast<const f32x4*>(&red[2][row][4 * i]);
+                if (m0 + row < M)
+                    *reinterpret_cast<f32x4*>(P + ((long)s * M + m0 + row) * N + n0 + 4 * i) = v;
+            }
+    }
+}
+
+int gemm_pick_kw(int M, int K) { return (M <= 128) ? 64 : K / 4; }
+
+void launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M, int N, int K, int kw,
+                        hipStream_t st) {
+    AUR_REQUIRE(N % 64 == 0 && kw % 16 == 0 && K % (4 * kw) == 0 && ldx % 4 == 0, "gemm: shape");
+    dim3 grid(N / 64, K / (4 * kw), (M + 63) / 64);
+    hipLaunchKernelGGL(gemm_splitk_kernel, grid, dim3(256), 0, st, X, ldx, W, P, M, N, kw);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// residual + LayerNorm rows (one wave per 1024-wide row; statistics via wavefront shuffles)
+__global__ __launch_bounds__(256) void rows_ln_kernel(const float* __restrict__ P, int S,
+                                                      const float* __restrict__ bias, float* __restrict__ h,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ out,
+                                                      int M, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    f32x4 v[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int n = 4 * (lane + 64 * u);
+        v[u] = *reinterpret_cast<const f32x4*>(h + (long)row * kHidden + n);
+        if (S > 0) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(P + (long)row * kHidden + n);
+            for (int s = 1; s < S; ++s) t += *reinterpret_cast<const f32x4*>(P + ((long)s * M + row) * kHidden + n);
+            t += *reinterpret_cast<const f32x4*>(bias + n);
+            v[u] += t;
+            *reinterpret_cast<f32x4*>(h + (long)row * kHidden + n) = v[u];
+        }
+        sum += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+    }
+    const float mean = wave_sum(sum) * (1.0f / kHidden);
+    float sq = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float d = v[u][c] - mean;
+            sq = fmaf(d, d, sq);
+        }
+    const float var = wave_sum(sq) * (1.0f / kHidden);
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int n = 4 * (lane + 64 * u);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + n);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + n);
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = (v[u][c] - mean) * rstd * g[c] + b[c];
+        *reinterpret_cast<f32x4*>(out + (long)row * kHidden + n) = o;
+    }
+}
+
+void launch_rows_ln(const float* P, int S, const float* bias, float* h, const float* gamma, const float* beta,
+                    float* out, int M, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(rows_ln_kernel, dim3((M + 3) / 4), dim3(256), 0, st, P, S, bias, h, gamma, beta, out, M, eps);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias_gelu_kernel(const float* __restrict__ P, int S,
+                                                        const float* __restrict__ bias, float* __restrict__ act,
+                                                        int M, int N) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // float4 index
+    const long total = (long)M * N / 4;
+    if (idx >= total) return;
+    const int n = (int)((idx * 4) % N);
+    f32x4 t = *reinterpret_cast<const f32x4*>(P + idx * 4);
+    for (int s = 1; s < S; ++s) t += *reinterpret_cast<const f32x4*>(P + (long)s * M * N + idx * 4);
+    t += *reinterpret_cast<const f32x4*>(bias + n);
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = gelu_new(t[c]);
+    *reinterpret_cast<f32x4*>(act + idx * 4) = o;
+}
+
+void launch_bias_gelu(const float* P, int S, const float* bias, float* act, int M, int N, hipStream_t st) {
+    const long total = (long)M * N / 4;
+    hipLaunchKernelGGL(bias_gelu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, S, bias, act, M, N);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// paged KV layout of one layer: [block][K|V][head][token_in_block(16)][64]
+__device__ __forceinline__ long kv_offset(int blk, int kv, int head, int tok) {
+    return (((long)blk * 2 + kv) * kHeads + head) * (kKvBlockTokens * kHeadDim) + (long)tok * kHeadDim;
+}
+
+__global__ __launch_bounds__(256) void qkv_epilogue_kernel(const float* __restrict__ P, int S,
+                                                           const float* __restrict__ bias, float* __restrict__ qbuf,
+                                                           float* __restrict__ kv_layer,
+                                                           const int* __restrict__ row_slot,
+                                                           const int* __restrict__ row_pos,
+                                                           const int* __restrict__ slot_kvpos,
+                                                           const int* __restrict__ block_tables, int max_blocks,
+                                                           int M) {
+    const int m = blockIdx.x;
+    const int slot = row_slot[m];
+    const int pos = row_pos ? row_pos[m] : slot_kvpos[slot];
+    const int blk = block_tables[(long)slot * max_blocks + pos / kKvBlockTokens];
+    const int tok = pos % kKvBlockTokens;
+    constexpr int N = 3 * kHidden;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int n = 4 * (threadIdx.x + 256 * u);
+        f32x4 t = *reinterpret_cast<const f32x4*>(P + (long)m * N + n);
+        for (int s = 1; s < S; ++s) t += *reinterpret_cast<const f32x4*>(P + ((long)s * M + m) * N + n);
+        t += *reinterpret_cast<const f32x4*>(bias + n);
+        if (u == 0) {
+            *reinterpret_cast<f32x4*>(qbuf + (long)m * kHidden + n) = t;
+        } else {
+            const int d = n - u * kHidden;
+            const int head = d / kHeadDim, dd = d % kHeadDim;
+            *reinterpret_cast<f32x4*>(kv_layer + kv_offset(blk, u - 1, head, tok) + dd) = t;
+        }
+    }
+}
+
+void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, float* kv_layer,
+                         const int* row_slot, const int* row_pos, const int* slot_kvpos,
+                         const int* block_tables, int max_blocks, int M, hipStream_t st) {
+    hipLaunchKernelGGL(qkv_epilogue_kernel, dim3(M), dim3(256), 0, st, P, S, bias, qbuf, kv_layer, row_slot, row_pos,
+                       slot_kvpos, block_tables, max_blocks, M);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Paged causal attention: one workgroup per (row, head).  16 lanes x float4 span the 64-wide head; a wave
+// reads 4 consecutive cached tokens (1 KiB contiguous) per instruction; 4 waves stride the context.
+// Scores are reduced with wavefront shuffles; online softmax per 16-lane group; groups merged through LDS.
+__global__ __launch_bounds__(256) void paged_attention_kernel(const float* __restrict__ qbuf,
+                                                              const float* __restrict__ kv_layer,
+                                                              const int* __restrict__ row_slot,
+                                                              const int* __restrict__ row_pos,
+                                                              const int* __restrict__ slot_kvpos,
+                                                              const int* __restrict__ block_tables, int max_blocks,
+                                                              float* __restrict__ out) {
+    __shared__ float part_o[16][kHeadDim];
+    __shared__ float part_m[16], part_l[16];
+    const int m = blockIdx.x, head = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g = lane >> 4, d4 = lane & 15;
+    const int slot = row_slot[m];
+    const int pos = row_pos ? row_pos[m] : slot_kvpos[slot];
+    const int n_keys = pos + 1;
+    const int* bt = block_tables + (long)slot * max_blocks;
+
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(qbuf + (long)m * kHidden + head * kHeadDim + d4 * 4);
+    float mi = -INFINITY, li = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int t0 = 0; t0 < n_keys; t0 += 16) {
+        const int t = t0 + wv * 4 + g;
+        const bool valid = t < n_keys;
+        f32x4 k4 = {0.f, 0.f, 0.f, 0.f}, v4 = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            const int blk = bt[t / kKvBlockTokens];
+            const long off = kv_offset(blk, 0, head, t % kKvBlockTokens) + d4 * 4;
+            k4 = *reinterpret_cast<const f32x4*>(kv_layer + off);
+            v4 = *reinterpret_cast<const f32x4*>(kv_layer + off + (long)kHeads * kKvBlockTokens * kHeadDim);
+        }
+        float sc = (qv[0] * k4[0] + qv[1] * k4[1]) + (qv[2] * k4[2] + qv[3] * k4[3]);
+        sc += __shfl_xor(sc, 8, 64);
+        sc += __shfl_xor(sc, 4, 64);
+        sc += __shfl_xor(sc, 2, 64);
+        sc += __shfl_xor(sc, 1, 64);
+        sc *= 0.125f;   // 1/sqrt(64)
+        if (valid) {
+            const float mn = fmaxf(mi, sc);
+            const float alpha = expf(mi - mn);   // mi = -inf on first use -> 0
+            const float p = expf(sc - mn);
+            li = li * alpha + p;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = o[c] * alpha + p * v4[c];
+            mi = mn;
+        }
+    }
+    const int pidx = wv * 4 + g;
+    *reinterpret_cast<f32x4*>(&part_o[pidx][d4 * 4]) = o;
+    if (d4 == 0) {
+        part_m[pidx] = mi;
+        part_l[pidx] = li;
+    }
+    __syncthreads();
+    if (threadIdx.x < kHeadDim) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) mx = fmaxf(mx, part_m[p]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const float w = expf(part_m[p] - mx);
+            L += part_l[p] * w;
+            O += part_o[p][threadIdx.x] * w;
+        }
+        out[(long)m * kHidden + head * kHeadDim + threadIdx.x] = O / L;
+    }
+}
+
+void launch_paged_attention(const float* qbuf, const float* kv_layer, const int* row_slot, const int* row_pos,
+                            const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(paged_attention_kernel, dim3(M, kHeads), dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos,
+                       slot_kvpos, block_tables, max_blocks, out);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_prompt_kernel(const int4* __restrict__ desc,
+                                                           const float* __restrict__ spk_cond,
+                                                           const float* __restrict__ text_emb,
+                                                           const float* __restrict__ text_pos,
+                                                           const float* __restrict__ wte,
+                                                           const float* __restrict__ wpe, float* __restrict__ h) {
+    const int m = blockIdx.x;
+    const int4 d = desc[m];
+    const int n = 4 * threadIdx.x;
+    f32x4 v;
+    if (d.x == 0) {
+        v = *reinterpret_cast<const f32x4*>(spk_cond + ((long)d.z * 32 + d.y) * kHidden + n);
+    } else if (d.x == 1) {
+        v = *reinterpret_cast<const f32x4*>(text_emb + (long)d.y * kHidden + n) +
+            *reinterpret_cast<const f32x4*>(text_pos + (long)d.z * kHidden + n);
+    } else {
+        v = *reinterpret_cast<const f32x4*>(wte + (long)d.y * kHidden + n) +
+            *reinterpret_cast<const f32x4*>(wpe + (long)d.z * kHidden + n);
+    }
+    *reinterpret_cast<f32x4*>(h + (long)m * kHidden + n) = v;
+}
+
+void launch_embed_prompt(const int4* desc, const float* spk_cond, const float* text_emb, const float* text_pos,
+                         const float* wte, const float* wpe, float* h, int M, hipStream_t st) {
+    hipLaunchKernelGGL(embed_prompt_kernel, dim3(M), dim3(256), 0, st, desc, spk_cond, text_emb, text_pos, wte, wpe, h);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void embed_decode_kernel(const int* __restrict__ row_slot,
+                                                           const int* __restrict__ slot_tok,
+                                                           const int* __restrict__ slot_pos,
+                                                           const float* __restrict__ wte,
+                                                           const float* __restrict__ wpe, float* __restrict__ h) {
+    const int m = blockIdx.x;
+    const int slot = row_slot[m];
+    const int n = 4 * threadIdx.x;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(wte + (long)slot_tok[slot] * kHidden + n) +
+                    *reinterpret_cast<const f32x4*>(wpe + (long)slot_pos[slot] * kHidden + n);
+    *reinterpret_cast<f32x4*>(h + (long)m * kHidden + n) = v;
+}
+
+void launch_embed_decode(const int* row_slot, const int* slot_tok, const int* slot_pos, const float* wte,
+                         const float* wpe, float* h, int M, hipStream_t st) {
+    hipLaunchKernelGGL(embed_decode_kernel, dim3(M), dim3(256), 0, st, row_slot, slot_tok, slot_pos, wte, wpe, h);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ln_wave(f32x4 (&v)[4], const float* gamma, const float* beta, int lane, float eps) {
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sum += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+    const float mean = wave_sum(sum) * (1.0f / kHidden);
+    float sq = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float d = v[u][c] - mean;
+            sq = fmaf(d, d, sq);
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) * (1.0f / kHidden) + eps);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int n = 4 * (lane + 64 * u);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + n);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + n);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[u][c] = (v[u][c] - mean) * rstd * g[c] + b[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void final_norm_kernel(const float* __restrict__ xn,
+                                                         const int* __restrict__ sample_row,
+                                                         const int* __restrict__ sample_slot,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ ybuf,
+                                                         float* __restrict__ latents, long lat_slot_stride,
+                                                         const int* __restrict__ slot_ngen, int max_lat_rows,
+                                                         int Ms, float eps) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= Ms) return;
+    const int row = sample_row[j];
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(xn + (long)row * kHidden + 4 * (lane + 64 * u));
+    ln_wave(v, gamma, beta, lane, eps);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(ybuf + (long)j * kHidden + 4 * (lane + 64 * u)) = v[u];
+    const int slot = sample_slot[j];
+    const int idx = slot_ngen[slot];
+    if (latents && idx < max_lat_rows) {
+        ln_wave(v, gamma, beta, lane, eps);
+        float* dst = latents + (long)slot * lat_slot_stride + (long)idx * kHidden;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(dst + 4 * (lane + 64 * u)) = v[u];
+    }
+}
+
+void launch_final_norm(const float* xn, const int* sample_row, const int* sample_slot, const float* gamma,
+                       const float* beta, float* ybuf, float* latents, long lat_slot_stride,
+                       const int* slot_ngen, int max_lat_rows, int Ms, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(final_norm_kernel, dim3((Ms + 3) / 4), dim3(256), 0, st, xn, sample_row, sample_slot, gamma, beta,
+                       ybuf, latents, lat_slot_stride, slot_ngen, max_lat_rows, Ms, eps);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused sampler: slab-sum + bias -> repetition penalty -> greedy argmax | (/T -> top-k -> top-p -> softmax ->
+// exponential-race argmax), then per-slot state update.  V = 1026 fits one workgroup.
+__device__ __forceinline__ unsigned lowbias32(unsigned x) {
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float exp_noise(unsigned seed, unsigned step, unsigned v) {
+    const unsigned a = lowbias32(v * 0x9E3779B1u + seed);
+    const unsigned b = lowbias32(a ^ (step * 0x85EBCA77u + 0x165667B1u));
+    const float u = ((float)(b >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    return -logf(u);
+}
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+    const unsigned u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __uint_as_float(u);
+}
+
+// block-wide argmax with "first index wins" tie rule
+__device__ __forceinline__ int block_argmax(float val, int idx, float* sv, int* si) {
+    const int tid = threadIdx.x;
+    sv[tid] = val;
+    si[tid] = idx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float ov = sv[tid + s];
+            const int oi = si[tid + s];
+            if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) {
+                sv[tid] = ov;
+                si[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const int r = si[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
+    __shared__ float z[1040];
+    __shared__ unsigned long long keys[2048];
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    __shared__ float sh_f[4];
+    __shared__ int sh_i[2];
+    const int j = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int slot = a.sample_slot[j];
+    const int V = a.V;
+    const float pen = a.rep_penalty[slot];
+    const unsigned char* seen = a.seen + (long)slot * kSeenStride;
+
+    for (int v = tid; v < V; v += 256) {
+        float s = a.P[(long)j * a.Npad + v];
+        for (int sl = 1; sl < a.S; ++sl) s += a.P[((long)sl * a.Ms + j) * a.Npad + v];
+        s += a.bias[v];
+        if (pen != 1.0f && seen[v]) s = (s > 0.f) ? s / pen : s * pen;
+        z[v] = s;
+        if (a.dbg_logits) a.dbg_logits[(long)j * V + v] = s;
+    }
+    __syncthreads();
+
+    const float T = a.temperature[slot];
+    int tok;
+    if (T < 1e-5f) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int v = tid; v < V; v += 256)
+            if (z[v] > bv) {
+                bv = z[v];
+                bi = v;
+            }
+        tok = block_argmax(bv, bi, sv, si);
+    } else {
+        for (int v = tid; v < V; v += 256) z[v] = z[v] / T;
+        __syncthreads();
+        for (int e = tid; e < 2048; e += 256)
+            keys[e] = (e < V) ? (((unsigned long long)f2ord(z[e]) << 32) | (unsigned)e) : 0ull;
+        __syncthreads();
+        for (int k = 2; k <= 2048; k <<= 1)
+            for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                for (int e = tid; e < 2048; e += 256) {
+                    const int x = e ^ jj;
+                    if (x > e) {
+                        const bool up = (e & k) == 0;
+                        const unsigned long long ka = keys[e], kb = keys[x];
+                        if ((ka < kb) == up) {
+                            keys[e] = kb;
+                            keys[x] = ka;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        // top-k threshold (ties at the k-th value are kept)
+        const int topk = a.top_k[slot];
+        if (tid == 0) {
+            int n1 = V;
+            float thr = -INFINITY;
+            if (topk > 0 && topk < V) {
+                thr = ord2f((unsigned)(keys[topk - 1] >> 32));
+                n1 = topk;
+                while (n1 < V && ord2f((unsigned)(keys[n1] >> 32)) == thr) ++n1;
+            }
+            sh_f[0] = thr;
+            sh_i[0] = n1;
+        }
+        __syncthreads();
+        const float thr = sh_f[0];
+        const int n1 = sh_i[0];
+        for (int v = tid; v < V; v += 256)
+            if (z[v] < thr) z[v] = -INFINITY;
+        __syncthreads();
+        const float maxv = ord2f((unsigned)(keys[0] >> 32));
+        // top-p on the ascending-sorted softmax: mask cumsum <= 1-p, never the largest
+        const float topp = a.top_p[slot];
+        if (topp < 1.0f && tid == 0) {
+            float sum = 0.f;
+            for (int r = 0; r < n1; ++r) sum += expf(ord2f((unsigned)(keys[r] >> 32)) - maxv);
+            const float lim = 1.0f - topp;
+            double c = 0.0;
+            for (int r = n1 - 1; r >= 1; --r) {
+                const float pr = expf(ord2f((unsigned)(keys[r] >> 32)) - maxv) / sum;
+                c += (double)pr;
+                if ((float)c <= lim)
+                    z[(unsigned)(keys[r] & 0xffffffffull)] = -INFINITY;
+                else
+                    break;
+            }
+        }
+        __syncthreads();
+        // softmax over the survivors, then argmax(probs / Exp(1))
+        float part = 0.f;
+        for (int v = tid; v < V; v += 256) part += expf(z[v] - maxv);
+        sv[tid] = part;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) sv[tid] += sv[tid + s];
+            __syncthreads();
+        }
+        const float sum2 = sv[0];
+        __syncthreads();
+        const unsigned seed = a.seed[slot];
+        const unsigned step = (unsigned)a.slot_ngen[slot];
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int v = tid; v < V; v += 256) {
+            const float p = expf(z[v] - maxv) / sum2;
+            const float qv = p / exp_noise(seed, step, (unsigned)v);
+            if (qv > bv) {
+                bv = qv;
+                bi = v;
+            }
+        }
+        tok = block_argmax(bv, bi, sv, si);
+    }
+
+    if (tid == 0) {
+        a.out_tok[j] = tok;
+        a.seen[(long)slot * kSeenStride + tok] = 1;
+        const int ng = a.slot_ngen[slot] + 1;
+        a.slot_ngen[slot] = ng;
+        a.slot_tok[slot] = tok;
+        a.slot_pos[slot] = ng;   // k-th generated token enters at mel position k (vllm_mm_gpt.py:480)
+        a.slot_kvpos[slot] = a.next_kvpos ? a.next_kvpos[j] : a.slot_kvpos[slot] + 1;
+        const bool stop = (tok == a.stop_token) && !a.ignore_stop[slot];
+        if (stop || ng >= a.max_tokens[slot]) a.slot_finished[slot] = 1;
+    }
+}
+
+void launch_sampler(const SamplerArgs& a, hipStream_t st) {
+    AUR_REQUIRE(a.V <= 1040, "sampler: V <= 1040");
+    hipLaunchKernelGGL(sampler_kernel, dim3(a.Ms), dim3(256), 0, st, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace aur

@@ -1,0 +1,51 @@
+// Launch wrappers for the HiFi-GAN vocoder kernels (vocoder_kernels.hip).
+#pragma once
+#include "common.h"
+
+namespace aur {
+
+// One masked 1-D convolution evaluated as an implicit GEMM on fp32 MFMA (32x32x2):
+//   y[b][v][q] = sum_{ci<Cin} sum_{j<KS} Wp[v][ci][j] * lrelu(x[b][ci][q + j*DIL - padl], slope)
+// with x == 0 outside [0, len_b).  `v` indexes "virtual" output channels: for a plain Conv1d v == co;
+// for the polyphase form of ConvTranspose1d (stride s, pad p) v = co*s + r and the value lands at
+// t = q*s + r - p.  Epilogue adds bias[co], optional per-(b,co) conditioning, optional residual, and
+// optionally folds the 3-way multi-receptive-field mean.
+struct ConvArgs {
+    const float* x;         // [B][Cin][x_stride]
+    const float* wp;        // packed [Mtot/MT][Cin][KS][MT]
+    const float* bias;      // [Cout] or nullptr
+    const float* cond;      // cond[cond_row[b]*cond_stride + co] or nullptr (1x1 speaker conditioning, precomputed)
+    const int* cond_row;    // [B] row of the conditioning table per utterance
+    long cond_stride;
+    const float* res;       // [B][Cout][o_stride] or nullptr (same layout as out)
+    float* mrf;             // [B][Cout][o_stride] accumulator for mrf_mode != 0
+    float* out;             // [B][Cout][o_stride]
+    const int* base_len;    // [B] vocoder frames T' per utterance
+    int len_mul;            // valid input length = base_len[b] * len_mul
+    int Cin, Mtot, Cout;
+    long x_stride, o_stride;       // elements between channel rows
+    long x_bstride, o_bstride;     // elements between batch items
+    int padl;
+    float slope;            // 1.0f = identity
+    int ups_s, ups_p;       // ups_s == 0: plain conv
+    int mrf_mode;           // 0 none; 1 mrf = v; 2 mrf += v; 3 out = (mrf + v) / 3
+    int max_len;            // max over batch of valid input length (grid sizing)
+    int B;
+};
+
+void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st);
+
+// z[b][c][j] = interp(interp(latents[b]^T, x4), x24000/22050)[c][j]   (hifigan_decoder.py:787-800)
+void launch_interp2(const float* lat, long lat_bstride, const int* lat_row, const int* n_lat, const int* base_len, float* z,
+                    long z_stride, long z_bstride, int C, int B, int max_len, hipStream_t st);
+
+// wav[b][t] = tanh(sum_{ci,j} w[ci][j] * lrelu(x[b][ci][t+j-3], slope))   (conv_post, no bias)
+void launch_conv_post(const float* x, const float* w, float* wav, const int* base_len, int len_mul, int Cin,
+                      long x_stride, long x_bstride, long wav_bstride, float slope, int B, int max_len,
+                      hipStream_t st);
+
+// y[b][r] = bias[r] + sum_k W[r][k] * g[b][k]      (1x1 conditioning convs on the speaker embedding)
+void launch_gemv_rows(const float* W, const float* bias, const float* g, float* y, int R, int K, int B,
+                      long g_bstride, long y_bstride, hipStream_t st);
+
+}  // namespace aur

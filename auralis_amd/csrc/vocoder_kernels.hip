@@ -1,0 +1,292 @@
+// HiFi-GAN vocoder kernels for gfx950 (MI355X).  fp32 in, fp32 accumulate, exact-f32 MFMA.
+//
+// Reference arithmetic: src/auralis/models/xttsv2/components/tts/layers/xtts/hifigan_decoder.py
+//   ResBlock1.forward 76-91, HifiganGenerator.forward 228-260, HifiDecoder.forward 776-802.
+//
+// conv1d_mfma_kernel: one workgroup (4 waves) produces a [MT virtual channels] x [NT positions] output
+// tile of one utterance.  Input channels are consumed in chunks of CK: the activated, zero-masked
+// input window x[CK][NT + (KS-1)*DIL] and the packed weights Wp[CK][KS][MT] are staged in LDS, then
+// every (channel pair, tap) is one K=2 step of v_mfma_f32_32x32x2_f32:
+//   A[i = lane&31][k = lane>>5] = Wp[ci0+cc+k][j][m*32 + i]       (consecutive lanes -> consecutive LDS words)
+//   B[k = lane>>5][n = lane&31] = xs[cc+k][col + j*DIL + n]      (consecutive lanes -> consecutive LDS words)
+// Each wave keeps a 64x64 (MT=64) or 32x128 (MT=32) accumulator tile in registers: 4 MFMAs per
+// 4 LDS dword reads.  D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#include "vocoder_kernels.h"
+
+namespace aur {
+
+template <int KS, int DIL, int MT, int CK>
+__global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
+    constexpr int WM = MT / 32;            // 32-row tiles per wave
+    constexpr int WN = (MT == 64) ? 2 : 4; // 32-col tiles per wave
+    constexpr int NTW = 32 * WN;
+    constexpr int NT = 4 * NTW;
+    constexpr int HALO = (KS - 1) * DIL;
+    constexpr int XROW = NT + HALO;
+    __shared__ __attribute__((aligned(16))) float xs[CK][XROW];
+    __shared__ __attribute__((aligned(16))) float ws[CK * KS][MT];
+
+    const int b = blockIdx.z;
+    const int mtile = blockIdx.y;
+    const int q0 = blockIdx.x * NT;
+    const int len_in = a.base_len[b] * a.len_mul;
+    const int n_q = a.ups_s ? len_in + 1 : len_in;   // polyphase needs q == len_in for the tail phases
+    if (q0 >= n_q) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int l31 = lane & 31;
+    const int hi = lane >> 5;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const float* xb = a.x + (long)b * a.x_bstride;
+    const float slope = a.slope;
+    const float4* wsrc_tile = reinterpret_cast<const float4*>(a.wp + (long)mtile * a.Cin * KS * MT);
+
+    for (int ci0 = 0; ci0 < a.Cin; ci0 += CK) {
+        __syncthreads();   // previous chunk fully consumed
+        // ---- stage activated, masked input window
+#pragma unroll 1
+        for (int c = 0; c < CK; ++c) {
+            const float* xr = xb + (long)(ci0 + c) * a.x_stride;
+            for (int i = tid; i < XROW; i += 256) {
+                const int t = q0 - a.padl + i;
+                float v = 0.f;
+                if (t >= 0 && t < len_in) v = xr[t];
+                xs[c][i] = lrelu(v, slope);
+            }
+        }
+        // ---- stage packed weights (contiguous CK*KS*MT floats)
+        {
+            const float4* src = wsrc_tile + (long)ci0 * KS * MT / 4;
+            float4* dst = reinterpret_cast<float4*>(&ws[0][0]);
+            constexpr int N4 = CK * KS * MT / 4;
+            for (int i = tid; i < N4; i += 256) dst[i] = src[i];
+        }
+        __syncthreads();
+        // ---- MFMA over (channel pair, tap)
+#pragma unroll 2
+        for (int cc = 0; cc < CK; cc += 2) {
+            const float* xrow = &xs[cc + hi][wv * NTW + l31];
+            const float* wrow = &ws[(cc + hi) * KS][l31];
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                float av[WM], bv[WN];
+#pragma unroll
+                for (int m = 0; m < WM; ++m) av[m] = wrow[j * MT + m * 32];
+#pragma unroll
+                for (int n = 0; n < WN; ++n) bv[n] = xrow[j * DIL + n * 32];
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int n = 0; n < WN; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue
+    const long ob = (long)b * a.o_bstride;
+    const int len_out = a.ups_s ? len_in * a.ups_s : len_in;
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int v = mtile * MT + m * 32 + row;
+            int co, toff;
+            if (a.ups_s) {
+                co = v / a.ups_s;
+                toff = (v - co * a.ups_s) - a.ups_p;
+            } else {
+                co = v;
+                toff = 0;
+            }
+            float add = a.bias ? a.bias[co] : 0.f;
+            if (a.cond) add += a.cond[(long)a.cond_row[b] * a.cond_stride + co];
+#pragma unroll
+            for (int n = 0; n < WN; ++n) {
+                const int q = q0 + wv * NTW + n * 32 + l31;
+                const int t = a.ups_s ? q * a.ups_s + toff : q;
+                if (q < n_q && t >= 0 && t < len_out) {
+                    const long off = ob + (long)co * a.o_stride + t;
+                    float val = acc[m][n][r] + add;
+                    if (a.res) val += a.res[off];
+                    if (a.mrf_mode == 0) {
+                        a.out[off] = val;
+                    } else if (a.mrf_mode == 1) {
+                        a.mrf[off] = val;
+                    } else if (a.mrf_mode == 2) {
+                        a.mrf[off] = a.mrf[off] + val;
+                    } else {
+                        a.out[off] = (a.mrf[off] + val) / 3.0f;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int KS, int DIL, int MT, int CK>
+static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
+    constexpr int NT = (MT == 64) ? 256 : 512;
+    AUR_REQUIRE(a.Cin % CK == 0, "conv: Cin % CK");
+    AUR_REQUIRE(a.Mtot % MT == 0, "conv: Mtot % MT");
+    const int n_q = a.ups_s ? a.max_len + 1 : a.max_len;
+    dim3 grid((n_q + NT - 1) / NT, a.Mtot / MT, a.B);
+    hipLaunchKernelGGL((conv1d_mfma_kernel<KS, DIL, MT, CK>), grid, dim3(256), 0, st, a);
+}
+
+template <int KS, int DIL, int CK>
+static void launch_conv_mt(const ConvArgs& a, hipStream_t st) {
+    if (a.Mtot % 64 == 0)
+        launch_conv_t<KS, DIL, 64, CK>(a, st);
+    else
+        launch_conv_t<KS, DIL, 32, CK>(a, st);
+}
+
+void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
+    const int key = KS * 16 + DIL;
+    switch (key) {
+        case 2 * 16 + 1: launch_conv_mt<2, 1, 16>(a, st); break;
+        case 3 * 16 + 1: launch_conv_mt<3, 1, 16>(a, st); break;
+        case 3 * 16 + 3: launch_conv_mt<3, 3, 16>(a, st); break;
+        case 3 * 16 + 5: launch_conv_mt<3, 5, 16>(a, st); break;
+        case 7 * 16 + 1: launch_conv_mt<7, 1, 8>(a, st); break;
+        case 7 * 16 + 3: launch_conv_mt<7, 3, 8>(a, st); break;
+        case 7 * 16 + 5: launch_conv_mt<7, 5, 8>(a, st); break;
+        case 11 * 16 + 1: launch_conv_mt<11, 1, 8>(a, st); break;
+        case 11 * 16 + 3: launch_conv_mt<11, 3, 8>(a, st); break;
+        case 11 * 16 + 5: launch_conv_mt<11, 5, 8>(a, st); break;
+        default: throw HipError("launch_conv1d: unsupported (kernel,dilation)");
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Two chained linear interpolations (align_corners=False), closed form of SURVEY A7'(i).
+//   scale r = float32(1/s); src = max(r*(j+0.5)-0.5, 0); i0 = floor(src); i1 = min(i0+1, L-1)
+__device__ __forceinline__ void lin_src(float r, int j, int L, int& i0, int& i1, float& lam) {
+    float src = r * ((float)j + 0.5f) - 0.5f;
+    src = fmaxf(src, 0.f);
+    i0 = (int)floorf(src);
+    i1 = min(i0 + 1, L - 1);
+    lam = src - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void interp2_kernel(const float* __restrict__ lat, long lat_bstride,
+                                                      const int* __restrict__ lat_row,
+                                                      const int* __restrict__ n_lat,
+                                                      const int* __restrict__ base_len, float* __restrict__ z,
+                                                      long z_stride, long z_bstride, int C, float r1, float r2) {
+    const int b = blockIdx.z;
+    const int c = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int L0 = n_lat[b];
+    const int L1 = 4 * L0;
+    const int L2 = base_len[b];
+    if (j >= L2) return;
+    const float* x = lat + (long)(lat_row ? lat_row[b] : b) * lat_bstride + c;   // x[k] = x[k*C]
+    int i0, i1;
+    float lam2;
+    lin_src(r2, j, L1, i0, i1, lam2);
+    float y[2];
+    const int idx[2] = {i0, i1};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int k0, k1;
+        float lam1;
+        lin_src(r1, idx[u], L0, k0, k1, lam1);
+        y[u] = (1.0f - lam1) * x[(long)k0 * C] + lam1 * x[(long)k1 * C];
+    }
+    z[(long)b * z_bstride + (long)c * z_stride + j] = (1.0f - lam2) * y[0] + lam2 * y[1];
+}
+
+void launch_interp2(const float* lat, long lat_bstride, const int* lat_row, const int* n_lat, const int* base_len, float* z,
+                    long z_stride, long z_bstride, int C, int B, int max_len, hipStream_t st) {
+    const float r1 = (float)(1.0 / (1024.0 / 256.0));
+    const float r2 = (float)(1.0 / (24000.0 / 22050.0));
+    dim3 grid((max_len + 255) / 256, C, B);
+    hipLaunchKernelGGL(interp2_kernel, grid, dim3(256), 0, st, lat, lat_bstride, lat_row, n_lat, base_len, z, z_stride,
+                       z_bstride, C, r1, r2);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_post (Cin -> 1, k7, no bias) + tanh.  Cin <= 32.  HBM-bound: reads Cin floats per sample.
+__global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ wav, const int* __restrict__ base_len,
+                                                        int len_mul, int Cin, long x_stride, long x_bstride,
+                                                        long wav_bstride, float slope) {
+    constexpr int NT = 256, KS = 7, MAXC = 32;
+    __shared__ float xs[MAXC][NT + KS - 1];
+    __shared__ float wsm[MAXC * KS];
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * NT;
+    const int len = base_len[b] * len_mul;
+    if (t0 >= len) return;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < Cin * KS; i += 256) wsm[i] = w[i];
+    const float* xb = x + (long)b * x_bstride;
+    for (int c = 0; c < Cin; ++c) {
+        const float* xr = xb + (long)c * x_stride;
+        for (int i = tid; i < NT + KS - 1; i += 256) {
+            const int t = t0 - 3 + i;
+            float v = (t >= 0 && t < len) ? xr[t] : 0.f;
+            xs[c][i] = lrelu(v, slope);
+        }
+    }
+    __syncthreads();
+    const int t = t0 + tid;
+    if (t >= len) return;
+    float s = 0.f;
+    for (int c = 0; c < Cin; ++c) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j) s = fmaf(wsm[c * KS + j], xs[c][tid + j], s);
+    }
+    wav[(long)b * wav_bstride + t] = tanhf(s);
+}
+
+void launch_conv_post(const float* x, const float* w, float* wav, const int* base_len, int len_mul, int Cin,
+                      long x_stride, long x_bstride, long wav_bstride, float slope, int B, int max_len,
+                      hipStream_t st) {
+    AUR_REQUIRE(Cin <= 32, "conv_post: Cin <= 32");
+    dim3 grid((max_len + 255) / 256, B);
+    hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), 0, st, x, w, wav, base_len, len_mul, Cin, x_stride,
+                       x_bstride, wav_bstride, slope);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// y[b][r] = bias[r] + W[r][:] . g[b][:]   one wave per output row.
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                        const float* __restrict__ g, float* __restrict__ y, int R,
+                                                        int K, long g_bstride, long y_bstride) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const float* wr = W + (long)r * K;
+    const float* gb = g + (long)b * g_bstride;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s = fmaf(wr[k], gb[k], s);
+    s = wave_sum(s);
+    if (lane == 0) y[(long)b * y_bstride + r] = s + (bias ? bias[r] : 0.f);
+}
+
+void launch_gemv_rows(const float* W, const float* bias, const float* g, float* y, int R, int K, int B,
+                      long g_bstride, long y_bstride, hipStream_t st) {
+    dim3 grid((R + 3) / 4, B);
+    hipLaunchKernelGGL(gemv_rows_kernel, grid, dim3(256), 0, st, W, bias, g, y, R, K, g_bstride, y_bstride);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace aur

@@ -1,0 +1,161 @@
+/* auralis_amd.h — C ABI of the MI355X-native XTTSv2 generate_speech() hot path.
+ *
+ * Drop-in boundary for astramind-ai/Auralis (v0.2.8.post2).  The reference has no native code: its
+ * engine plugin is the Python class XTTSv2Engine (src/auralis/models/xttsv2/XTTSv2.py:39) behind
+ * BaseAsyncTTSEngine (src/auralis/models/base.py:57).  Each entry point below replaces the Python/vLLM
+ * mechanism cited next to it; the ctypes binding a maintainer would add is shown in INTEGRATION.md and
+ * shipped as auralis_amd/_lib.py.
+ *
+ * Conventions: every function returns 0 on success or a negative AUR_E_* code; the message of the last
+ * failure on the calling thread is aur_last_error().  No exception crosses the boundary.  Handles are
+ * opaque and owned by the library.  Pointers passed in are caller-owned HOST pointers borrowed for the
+ * duration of the call unless the name says _device.  All floating-point tensors are fp32, row-major.
+ * Threading: one driver thread per engine calls aur_step(); aur_submit()/aur_poll_finished()/
+ * aur_release() may be called from other threads (internally serialised).
+ */
+#ifndef AURALIS_AMD_H
+#define AURALIS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AUR_OK 0
+#define AUR_E_INVALID (-1)   /* bad argument / unknown id / shape mismatch */
+#define AUR_E_HIP (-2)       /* HIP runtime or kernel failure */
+#define AUR_E_STATE (-3)     /* call not valid in the current state (e.g. weights not loaded) */
+#define AUR_E_NOMEM (-4)
+
+typedef struct aur_engine aur_engine;
+
+/* Engine geometry.  Replaces the AsyncEngineArgs built in XTTSv2Engine.init_vllm_engine
+ * (XTTSv2.py:198-232: max_model_len 1047, max_num_seqs = concurrency, block size 16). */
+typedef struct aur_config {
+    int32_t n_layer;          /* GPT blocks (30 for XTTSv2; tests may use fewer) */
+    int32_t max_seqs;         /* concurrent sequences (continuous-batching slots) */
+    int32_t max_prefill_rows; /* cap on prompt rows prefetched in one step (0 = default 8192) */
+    int32_t max_speakers;     /* speaker-conditioning table entries (0 = default 64) */
+    int32_t vocoder_min_batch;/* hold finished sequences until this many are ready (0/1 = vocode at once) */
+    int32_t profile;          /* 1 = record HIP events around the vocoder conv launches (aur_stats) */
+} aur_config;
+
+/* One named fp32 tensor.  Names are the packed names produced by auralis_amd/weights.py from the
+ * reference's on-disk keys (checkpoint_converter.py:225-284; loaders XTTSv2.py:288-301,
+ * vllm_mm_gpt.py:714-733). */
+typedef struct aur_tensor_desc {
+    const char* name;
+    const float* data;
+    int64_t numel;
+} aur_tensor_desc;
+
+/* One sequence = one <=250-char text chunk.  Replaces TokensPrompt + ExtendedSamplingParams built in
+ * XTTSv2Engine.get_generation_context (XTTSv2.py:727-756) and the text embedding of
+ * prepare_text_tokens_async (XTTSv2.py:506-543). */
+typedef struct aur_seq_desc {
+    const int32_t* text_ids;  /* BPE ids incl. [START]/[STOP] (XTTSv2.py:520-521) */
+    int32_t n_text;
+    uint64_t speaker_key;     /* conditioning previously registered with aur_set_conditioning */
+    float temperature;        /* < 1e-5 => greedy (vLLM _SAMPLING_EPS) */
+    float top_p;
+    int32_t top_k;            /* <= 0 disables */
+    float repetition_penalty; /* hijack.py:49-88 semantics, 1.0 disables */
+    int32_t max_tokens;       /* gpt_max_audio_tokens (605) */
+    uint32_t seed;            /* per-sequence noise stream (new surface; reference has none) */
+    int32_t ignore_stop;      /* 1 = fixed-length mode for timing (stop id does not end the sequence) */
+} aur_seq_desc;
+
+/* Finished sequence.  Pointers stay valid until aur_release(seq_id).  Replaces the RequestOutput consumed at
+ * XTTSv2.py:785 and the TTSOutput array built at XTTSv2.py:804-811. */
+typedef struct aur_result {
+    uint64_t seq_id;
+    int32_t n_tokens;
+    const int32_t* tokens;    /* mel token ids, stop id included when emitted */
+    int32_t n_samples;
+    const float* wav;         /* 24 kHz mono PCM in [-1, 1] */
+    int32_t n_latent_rows;
+    const float* latents;     /* [n_tokens][1024] vocoder input (final_norm applied twice), may be NULL */
+    int32_t error;            /* 0 or AUR_E_* if this sequence failed */
+} aur_result;
+
+typedef struct aur_stats {
+    int64_t steps;                 /* aur_step calls that did work */
+    int64_t prefill_rows;          /* prompt rows processed */
+    int64_t decode_rows;           /* decode rows processed (one per live sequence per step) */
+    int64_t tokens_generated;
+    int64_t samples_generated;
+    int64_t vocoder_batches;
+    /* profile == 1 only: HIP-event time of the MFMA conv launches of the vocoder */
+    int64_t conv_launches;
+    double conv_ms;
+    double conv_flops;             /* algorithmic FLOPs of those launches */
+    double conv_bytes;             /* algorithmic (layer-granular) HBM bytes of those launches */
+    double vocoder_ms;             /* whole vocoder batches (interp .. conv_post), event-timed */
+    double gpt_ms;                 /* prefill + decode + sampling, event-timed per step */
+    int64_t kv_blocks_total;
+    int64_t kv_blocks_free;
+} aur_stats;
+
+const char* aur_last_error(void);
+int aur_version(void);
+
+int aur_engine_create(const aur_config* cfg, int device_id, aur_engine** out);
+int aur_engine_destroy(aur_engine* e);
+
+/* Upload packed weights (may be called several times; later names overwrite earlier ones). */
+int aur_load_weights(aur_engine* e, const aur_tensor_desc* tensors, size_t n);
+
+/* Register/replace the conditioning of one speaker: gpt_cond_latent [32][1024] and speaker embedding
+ * [512] (outputs of XTTSv2Engine.get_conditioning_latents, XTTSv2.py:409-468).  Also precomputes the
+ * vocoder's 1x1 conditioning convs (hifigan_decoder.py:243-251) for this speaker on the GPU. */
+int aur_set_conditioning(aur_engine* e, uint64_t speaker_key, const float* gpt_cond, const float* spk_emb);
+/* Same with DEVICE pointers (e.g. the receive buffer of an RCCL broadcast). */
+int aur_set_conditioning_device(aur_engine* e, uint64_t speaker_key, const float* d_gpt_cond,
+                                const float* d_spk_emb);
+
+/* Queue a sequence (replaces llm_engine.generate, XTTSv2.py:752). */
+int aur_submit(aur_engine* e, const aur_seq_desc* seq, uint64_t* seq_id);
+
+/* One continuous-batching iteration: admit + prefill waiting sequences, one decode step for every live
+ * sequence, fused sampling, and vocoding of sequences that finished (replaces vLLM's engine step, the
+ * second pass of get_model_logits XTTSv2.py:617-687 and the HiFi-GAN call XTTSv2.py:804).
+ * n_live = sequences still waiting/decoding/vocoding after the step. */
+int aur_step(aur_engine* e, int32_t* n_live, int32_t* n_finished_total);
+
+int aur_poll_finished(aur_engine* e, aur_result* out, size_t cap, size_t* n);
+int aur_release(aur_engine* e, uint64_t seq_id);
+
+/* Standalone vocoder (HifiDecoder.forward, hifigan_decoder.py:776-802) for parity tests and for callers
+ * that bring their own latents: latents [B][t_max][1024], n_lat[B] valid rows each; wav_out [B][wav_stride]. */
+int aur_vocode(aur_engine* e, const float* latents, const int32_t* n_lat, int32_t B, int32_t t_max,
+               uint64_t speaker_key, float* wav_out, int64_t wav_stride, int32_t* n_samples_out);
+
+int aur_sync(aur_engine* e);
+int aur_get_stats(aur_engine* e, aur_stats* out);
+int aur_reset_stats(aur_engine* e);
+
+/* ---- per-kernel entry points used by the parity tests (host pointers) ------------------------------- */
+/* out[M][N] = X[M][K] @ W[K][N] via the split-K MFMA kernel + slab sum (kw = 0 picks the default). */
+int aur_dbg_gemm(aur_engine* e, const float* X, const float* W, float* out, int32_t M, int32_t N, int32_t K,
+                 int32_t kw);
+/* out[M][1024] = LayerNorm(h) rows */
+int aur_dbg_layernorm(aur_engine* e, const float* h, const float* gamma, const float* beta, float* out,
+                      int32_t M);
+/* Generic masked conv on packed weights: x [B][Cin][L]; out [B][Cout][L*max(1,ups_s)]; see vocoder_kernels.h */
+int aur_dbg_conv1d(aur_engine* e, const float* x, const float* wp, const float* bias, const float* res,
+                   float* out, const int32_t* lens, int32_t B, int32_t Cin, int32_t Mtot, int32_t Cout,
+                   int32_t L, int32_t KS, int32_t DIL, int32_t padl, float slope, int32_t ups_s, int32_t ups_p);
+/* Prefill one prompt and return ln_f rows [n_rows][1024] and the penalised logits [1026] of the last row. */
+int aur_dbg_prefill(aur_engine* e, const int32_t* text_ids, int32_t n_text, uint64_t speaker_key,
+                    float repetition_penalty, float* lnf_rows_out, float* logits_out);
+/* Run the fused sampler on given logits rows [B][1026] (greedy if temperature < 1e-5). */
+int aur_dbg_sample(aur_engine* e, const float* logits, int32_t B, float temperature, float top_p, int32_t top_k,
+                   float repetition_penalty, const uint8_t* seen /*[B][1026] or NULL*/, uint32_t seed,
+                   int32_t step, int32_t* tokens_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AURALIS_AMD_H */

@@ -1,0 +1,52 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def dims():
+    from auralis_amd.config import XTTSDims
+    return XTTSDims()
+
+
+@pytest.fixture(scope="session")
+def xtts_sd(dims):
+    from auralis_amd.checkpoint import make_synthetic_xtts
+    return make_synthetic_xtts(dims, seed=1234)
+
+
+@pytest.fixture(scope="session")
+def conditioning(dims):
+    from auralis_amd.checkpoint import make_synthetic_conditioning
+    return make_synthetic_conditioning(dims)
+
+
+def _gpt_sd(dims, n_layer):
+    from auralis_amd.checkpoint import make_synthetic_gpt
+    return make_synthetic_gpt(dims.gpt, seed=1234, n_layer=n_layer)
+
+
+@pytest.fixture(scope="session")
+def gpt_sd_small(dims):
+    """Full-width GPT with 3 layers: same kernels and shapes per layer, oracle runs in seconds."""
+    return _gpt_sd(dims, 3)
+
+
+@pytest.fixture(scope="session")
+def gpt_sd_full(dims):
+    return _gpt_sd(dims, 30)
+
+
+@pytest.fixture(scope="session")
+def lib_path():
+    from auralis_amd.build import build
+    return build()
