@@ -70,6 +70,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
+    # torch first: it bundles its own libamdhip64; loading ours after it makes both share ONE HIP runtime
+    # (loading the system runtime first and torch's second leaves the process with no visible device).
+    import torch  # noqa: F401
     p = path or LIB_PATH
     if not os.path.isfile(p):
         raise FileNotFoundError(

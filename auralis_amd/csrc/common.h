@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -27,6 +28,26 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
     do {                                                                                \
         if (!(cond)) throw ::aur::HipError(std::string("requirement failed: ") + (msg)); \
     } while (0)
+
+// AUR_DEBUG_SYNC=1: print each launch before it is issued and synchronise after it (fault localisation).
+inline bool debug_sync() {
+    static const bool on = [] {
+        const char* e = getenv("AUR_DEBUG_SYNC");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+inline void trace_launch(const char* name) {
+    if (debug_sync()) {
+        (void)hipDeviceSynchronize();   // a fault of the previous launch surfaces before this line prints
+        fprintf(stderr, "[aur] launch %s\n", name);
+        fflush(stderr);
+    }
+}
+inline void post_launch(const char* name, hipStream_t st) {
+    hip_check(hipGetLastError(), name, __FILE__, __LINE__);
+    if (debug_sync()) hip_check(hipStreamSynchronize(st), name, __FILE__, __LINE__);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

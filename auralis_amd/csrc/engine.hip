@@ -414,15 +414,18 @@ public:
     // ------------------------------------------------------------------ debug entry points
     void dbg_gemm(const float* X, const float* Wm, float* out, int M, int N, int K, int kw) {
         use();
-        if (kw <= 0) kw = gemm_pick_kw(M, K);
-        const int S = K / (4 * kw);
+        GemmPlan pl = gemm_plan(M, K);
+        if (kw > 0) {   // explicit kw: force the split form with that slice width
+            pl.kw = kw; pl.slices = K / (4 * kw); pl.fused = false; pl.slabs = pl.slices;
+        }
+        const int S = pl.slabs;
         DevBuf dx, dw, dp, dout;
         dx.ensure((size_t)M * K * 4);
         dw.ensure((size_t)K * N * 4);
         dp.ensure((size_t)S * M * N * 4);
         HIP_CHECK(hipMemcpy(dx.p, X, (size_t)M * K * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(dw.p, Wm, (size_t)K * N * 4, hipMemcpyHostToDevice));
-        launch_gemm_splitk(dx.as<float>(), K, dw.as<float>(), dp.as<float>(), M, N, K, kw, st_);
+        launch_gemm_splitk(dx.as<float>(), K, dw.as<float>(), dp.as<float>(), M, N, K, pl, st_);
         HIP_CHECK(hipStreamSynchronize(st_));
         std::vector<float> hp((size_t)S * M * N);
         HIP_CHECK(hipMemcpy(hp.data(), dp.p, hp.size() * 4, hipMemcpyDeviceToHost));
@@ -612,19 +615,19 @@ private:
         const int* bt = block_tables_.as<int>();
         const int* kvpos = slot_kvpos_.as<int>();
         launch_rows_ln(nullptr, 0, nullptr, h, layers_[0].ln1w, layers_[0].ln1b, xn, M, 1e-5f, st_);
-        const int kw1 = gemm_pick_kw(M, kHidden), S1 = kHidden / (4 * kw1);
-        const int kw4 = gemm_pick_kw(M, 4 * kHidden), S4 = 4 * kHidden / (4 * kw4);
+        const GemmPlan p1 = gemm_plan(M, kHidden), p4 = gemm_plan(M, 4 * kHidden);
+        const int S1 = p1.slabs, S4 = p4.slabs;
         for (int l = 0; l < cfg_.n_layer; ++l) {
             const LayerW& L = layers_[l];
             float* kvl = kv_.as<float>() + (long)l * kv_layer_stride_;
-            launch_gemm_splitk(xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, kw1, st_);
+            launch_gemm_splitk(xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, p1, st_);
             launch_qkv_epilogue(P, S1, L.bqkv, qbuf_.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, st_);
             launch_paged_attention(qbuf_.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, att_.as<float>(), M, st_);
-            launch_gemm_splitk(att_.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, kw1, st_);
+            launch_gemm_splitk(att_.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, p1, st_);
             launch_rows_ln(P, S1, L.bproj, h, L.ln2w, L.ln2b, xn, M, 1e-5f, st_);
-            launch_gemm_splitk(xn, kHidden, L.wfc, P, M, 4 * kHidden, kHidden, kw1, st_);
+            launch_gemm_splitk(xn, kHidden, L.wfc, P, M, 4 * kHidden, kHidden, p1, st_);
             launch_bias_gelu(P, S1, L.bfc, act_.as<float>(), M, 4 * kHidden, st_);
-            launch_gemm_splitk(act_.as<float>(), 4 * kHidden, L.wproj2, P, M, kHidden, 4 * kHidden, kw4, st_);
+            launch_gemm_splitk(act_.as<float>(), 4 * kHidden, L.wproj2, P, M, kHidden, 4 * kHidden, p4, st_);
             const bool last = (l + 1 == cfg_.n_layer);
             launch_rows_ln(P, S4, L.bproj2, h, last ? lnfw_ : layers_[l + 1].ln1w, last ? lnfb_ : layers_[l + 1].ln1b,
                            xn, M, 1e-5f, st_);
@@ -662,8 +665,9 @@ private:
             HIP_CHECK(hipMemcpyAsync(i_next_kvpos_.p, next_kvpos->data(), (size_t)Ms * 4, hipMemcpyHostToDevice, st_));
         launch_final_norm(xn_.as<float>(), i_sample_row_.as<int>(), i_sample_slot_.as<int>(), fnw_, fnb_, ybuf_.as<float>(),
                           latents_.as<float>(), (long)kMaxLatRows * kHidden, slot_ngen_.as<int>(), kMaxLatRows, Ms, 1e-5f, st_);
-        const int kw = 64, S = kHidden / (4 * kw);
-        launch_gemm_splitk(ybuf_.as<float>(), kHidden, headT_, P2_.as<float>(), Ms, kHeadPad, kHidden, kw, st_);
+        const GemmPlan ph = gemm_plan(Ms, kHidden);
+        const int S = ph.slabs;
+        launch_gemm_splitk(ybuf_.as<float>(), kHidden, headT_, P2_.as<float>(), Ms, kHeadPad, kHidden, ph, st_);
         SamplerArgs a = sampler_args(P2_.as<float>(), S, Ms, kHeadPad, headb_, next_kvpos ? i_next_kvpos_.as<int>() : nullptr);
         launch_sampler(a, st_);
         int* pin = pin_.as<int>();
@@ -686,6 +690,7 @@ private:
     void init_slots(const std::vector<SlotInit>& init) {
         i_init_.ensure(init.size() * sizeof(SlotInit));
         HIP_CHECK(hipMemcpyAsync(i_init_.p, init.data(), init.size() * sizeof(SlotInit), hipMemcpyHostToDevice, st_));
+        trace_launch("init_slots_kernel");
         hipLaunchKernelGGL(init_slots_kernel, dim3((unsigned)init.size()), dim3(256), 0, st_, i_init_.as<SlotInit>(),
                            slot_tok_.as<int>(), slot_pos_.as<int>(), slot_kvpos_.as<int>(), slot_ngen_.as<int>(),
                            slot_finished_.as<int>(), temperature_.as<float>(), top_p_.as<float>(), top_k_.as<int>(),
@@ -723,6 +728,10 @@ private:
         HIP_CHECK(hipMemcpyAsync(i_desc_.p, desc.data(), (size_t)M * sizeof(int4), hipMemcpyHostToDevice, st_));
         HIP_CHECK(hipMemcpyAsync(i_row_slot_.p, row_slot.data(), (size_t)M * 4, hipMemcpyHostToDevice, st_));
         HIP_CHECK(hipMemcpyAsync(i_row_pos_.p, row_pos.data(), (size_t)M * 4, hipMemcpyHostToDevice, st_));
+        if (debug_sync())
+            fprintf(stderr, "[aur] prefill M=%d desc=%p spk=%p temb=%p tpos=%p wte=%p wpe=%p h=%p d0=(%d,%d,%d) dl=(%d,%d,%d)\n", M,
+                    i_desc_.p, spk_table_.p, (const void*)text_emb_, (const void*)text_pos_, (const void*)wte_, (const void*)wpe_, h_.p,
+                    desc[0].x, desc[0].y, desc[0].z, desc[M - 1].x, desc[M - 1].y, desc[M - 1].z);
         launch_embed_prompt(i_desc_.as<int4>(), spk_table_.as<float>(), text_emb_, text_pos_, wte_, wpe_, h_.as<float>(), M, st_);
         forward_rows(M, i_row_slot_.as<int>(), i_row_pos_.as<int>());
         if (dbg_capture_) {

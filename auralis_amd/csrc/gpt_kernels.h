@@ -12,10 +12,16 @@ constexpr long kKvBlockElems = 2L * kHeads * kKvBlockTokens * kHeadDim;  // one 
 
 // Split-K weight-streaming GEMM on exact-f32 MFMA (16x16x4):
 //   P[s][m][n] = sum_{k in slice s} X[m][k] * W[k][n],   W row-major [K][N] (HF Conv1D layout on disk)
-// slices = K / (4*kw).  N % 64 == 0, kw % 16 == 0.  P is [slices][M][N].
-void launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M, int N, int K, int kw,
+// N % 64 == 0, kw % 16 == 0.  P is [slabs][M][N] (see GemmPlan).
+struct GemmPlan {
+    int kw;      // K per wave (4 waves per workgroup => slices of 4*kw)
+    int slices;  // K / (4*kw)
+    bool fused;  // slice loop inside the kernel (one output slab) instead of one slab per slice
+    int slabs;   // slabs the epilogue has to sum
+};
+GemmPlan gemm_plan(int M, int K);
+void launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M, int N, int K, const GemmPlan& pl,
                         hipStream_t st);
-int gemm_pick_kw(int M, int K);
 
 // h[m] += sum_s P[s][m] + bias (if S > 0); out[m] = LayerNorm(h[m]; gamma, beta, eps).  Rows of 1024.
 void launch_rows_ln(const float* P, int S, const float* bias, float* h, const float* gamma, const float* beta,

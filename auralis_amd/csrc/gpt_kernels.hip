@@ -14,85 +14,117 @@ namespace aur {
 // MFMA v_mfma_f32_16x16x4_f32 with a permuted K and N order so that the float4 loads ARE the fragments:
 //   step (s', c):  A[i][k'] = X[m][kb + 4k' + s'],  B[k'][j'] = W[kb + 4k' + s'][n0 + 4j' + c]
 //   D[i][j'] accumulates column n0 + 4j' + c, i.e. lane j' owns 4 consecutive columns across c = 0..3.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void gemm_splitk_kernel(const float* __restrict__ X, int ldx,
                                                           const float* __restrict__ W, float* __restrict__ P,
-                                                          int M, int N, int kw) {
+                                                          int M, int N, int kw, int n_slices) {
     __shared__ __attribute__((aligned(16))) float red[3][64][68];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * 64, s = blockIdx.y, m0 = blockIdx.z * 64;
-    const int kbeg = (s * 4 + wv) * kw;
+    const int n0 = blockIdx.x * 64, m0 = blockIdx.z * 64;
+    // FUSED: this workgroup walks every K-slice and adds the slice results in slice order, which is exactly the
+    // order the split form + epilogue slab-sum uses -> bitwise identical results for any batch size.
+    const int s_begin = FUSED ? 0 : blockIdx.y, s_end = FUSED ? n_slices : blockIdx.y + 1;
 
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[mt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const float* wp = W + (long)(kbeg + 4 * q) * N + n0 + 4 * i;
     const float* xp[4];
     bool xv[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int r = m0 + 16 * mt + i;
         xv[mt] = r < M;
-        xp[mt] = X + (long)(xv[mt] ? r : 0) * ldx + kbeg + 4 * q;
+        xp[mt] = X + (long)(xv[mt] ? r : 0) * ldx + 4 * q;
     }
+    f32x4 total[4][4];
 
-#pragma unroll 2
-    for (int kb = 0; kb < kw; kb += 16) {
-        f32x4 bf[4], af[4];
-#pragma unroll
-        for (int sp = 0; sp < 4; ++sp) bf[sp] = *reinterpret_cast<const f32x4*>(wp + (long)(kb + sp) * N);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            af[mt] = *reinterpret_cast<const f32x4*>(xp[mt] + kb);
-            if (!xv[mt]) af[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int sp = 0; sp < 4; ++sp)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][sp], bf[sp][c], acc[mt][c], 0, 0, 0);
-    }
-
-    // in-block reduction over the 4 K-slices: waves 1..3 park their tiles in LDS, wave 0 adds and stores.
-    if (wv > 0) {
+    for (int s = s_begin; s < s_end; ++s) {
+        const int kbeg = (s * 4 + wv) * kw;
+        f32x4 acc[4][4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * mt + 4 * q + r;
-                f32x4 v = {acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
-                *reinterpret_cast<f32x4*>(&red[wv - 1][row][4 * i]) = v;
+            for (int c = 0; c < 4; ++c) acc[mt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* wp = W + (long)(kbeg + 4 * q) * N + n0 + 4 * i;
+        for (int kb = 0; kb < kw; kb += 16) {
+            f32x4 bf[4], af[4];
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) bf[sp] = *reinterpret_cast<const f32x4*>(wp + (long)(kb + sp) * N);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                af[mt] = *reinterpret_cast<const f32x4*>(xp[mt] + kbeg + kb);
+                if (!xv[mt]) af[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][sp], bf[sp][c], acc[mt][c], 0, 0, 0);
+        }
+        // in-block reduction over the 4 wave K-slices: waves 1..3 park their tiles in LDS, wave 0 adds.
+        if (wv > 0) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * mt + 4 * q + r;
+                    f32x4 v = {acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+                    *reinterpret_cast<f32x4*>(&red[wv - 1][row][4 * i]) = v;
+                }
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * mt + 4 * q + r;
+                    f32x4 v = {acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+                    v += *reinterpret_cast<const f32x4*>(&red[0][row][4 * i]);
+                    v += *reinterpret_cast<const f32x4*>(&red[1][row][4 * i]);
+                    v += *reinterpret_cast<const f32x4*>(&red[2][row][4 * i]);
+                    if (FUSED) {
+                        total[mt][r] = (s == 0) ? v : total[mt][r] + v;
+                    } else if (m0 + row < M) {
+                        *reinterpret_cast<f32x4*>(P + ((long)s * M + m0 + row) * N + n0 + 4 * i) = v;
+                    }
+                }
+        }
+        if (FUSED) __syncthreads();   // LDS tiles consumed before the next slice overwrites them
     }
-    __syncthreads();
-    if (wv == 0) {
+    if (FUSED && wv == 0) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * mt + 4 * q + r;
-                f32x4 v = {acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
-                v += *reinterpret_cast<const f32x4*>(&red[0][row][4 * i]);
-                v += *reinterpret_cast<const f32x4*>(&red[1][row][4 * i]);
-                v += *reinterpret_cast<const f32x4*>(&red[2][row][4 * i]);
-                if (m0 + row < M)
-                    *reinterpret_cast<f32x4*>(P + ((long)s * M + m0 + row) * N + n0 + 4 * i) = v;
+                if (m0 + row < M) *reinterpret_cast<f32x4*>(P + (long)(m0 + row) * N + n0 + 4 * i) = total[mt][r];
             }
     }
 }
 
-int gemm_pick_kw(int M, int K) { return (M <= 128) ? 64 : K / 4; }
+// K is always cut into slices of 4*64; M <= 128 writes one slab per slice (more workgroups for the
+// weight-streaming decode regime), larger M fuses the slice loop in-kernel (one slab, same arithmetic order).
+GemmPlan gemm_plan(int M, int K) {
+    GemmPlan p;
+    p.kw = 64;
+    p.slices = K / (4 * p.kw);
+    p.fused = M > 128;
+    p.slabs = p.fused ? 1 : p.slices;
+    return p;
+}
 
-void launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M, int N, int K, int kw,
+void launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M, int N, int K, const GemmPlan& pl,
                         hipStream_t st) {
-    AUR_REQUIRE(N % 64 == 0 && kw % 16 == 0 && K % (4 * kw) == 0 && ldx % 4 == 0, "gemm: shape");
-    dim3 grid(N / 64, K / (4 * kw), (M + 63) / 64);
-    hipLaunchKernelGGL(gemm_splitk_kernel, grid, dim3(256), 0, st, X, ldx, W, P, M, N, kw);
+    AUR_REQUIRE(N % 64 == 0 && pl.kw % 16 == 0 && K == pl.slices * 4 * pl.kw && ldx % 4 == 0, "gemm: shape");
+    trace_launch("gemm_splitk_kernel");
+    if (pl.fused) {
+        dim3 grid(N / 64, 1, (M + 63) / 64);
+        hipLaunchKernelGGL(gemm_splitk_kernel<true>, grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.kw, pl.slices);
+    } else {
+        dim3 grid(N / 64, pl.slices, (M + 63) / 64);
+        hipLaunchKernelGGL(gemm_splitk_kernel<false>, grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.kw, pl.slices);
+    }
     HIP_CHECK(hipGetLastError());
 }
 
@@ -146,6 +178,7 @@ __global__ __launch_bounds__(256) void rows_ln_kernel(const float* __restrict__ 
 
 void launch_rows_ln(const float* P, int S, const float* bias, float* h, const float* gamma, const float* beta,
                     float* out, int M, float eps, hipStream_t st) {
+    trace_launch("rows_ln_kernel");
     hipLaunchKernelGGL(rows_ln_kernel, dim3((M + 3) / 4), dim3(256), 0, st, P, S, bias, h, gamma, beta, out, M, eps);
     HIP_CHECK(hipGetLastError());
 }
@@ -169,6 +202,7 @@ __global__ __launch_bounds__(256) void bias_gelu_kernel(const float* __restrict_
 
 void launch_bias_gelu(const float* P, int S, const float* bias, float* act, int M, int N, hipStream_t st) {
     const long total = (long)M * N / 4;
+    trace_launch("bias_gelu_kernel");
     hipLaunchKernelGGL(bias_gelu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, S, bias, act, M, N);
     HIP_CHECK(hipGetLastError());
 }
@@ -212,6 +246,7 @@ __global__ __launch_bounds__(256) void qkv_epilogue_kernel(const float* __restri
 void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, float* kv_layer,
                          const int* row_slot, const int* row_pos, const int* slot_kvpos,
                          const int* block_tables, int max_blocks, int M, hipStream_t st) {
+    trace_launch("qkv_epilogue_kernel");
     hipLaunchKernelGGL(qkv_epilogue_kernel, dim3(M), dim3(256), 0, st, P, S, bias, qbuf, kv_layer, row_slot, row_pos,
                        slot_kvpos, block_tables, max_blocks, M);
     HIP_CHECK(hipGetLastError());
@@ -292,6 +327,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
 void launch_paged_attention(const float* qbuf, const float* kv_layer, const int* row_slot, const int* row_pos,
                             const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
                             hipStream_t st) {
+    trace_launch("paged_attention_kernel");
     hipLaunchKernelGGL(paged_attention_kernel, dim3(M, kHeads), dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos,
                        slot_kvpos, block_tables, max_blocks, out);
     HIP_CHECK(hipGetLastError());
@@ -307,21 +343,20 @@ __global__ __launch_bounds__(256) void embed_prompt_kernel(const int4* __restric
     const int m = blockIdx.x;
     const int4 d = desc[m];
     const int n = 4 * threadIdx.x;
-    f32x4 v;
-    if (d.x == 0) {
-        v = *reinterpret_cast<const f32x4*>(spk_cond + ((long)d.z * 32 + d.y) * kHidden + n);
-    } else if (d.x == 1) {
-        v = *reinterpret_cast<const f32x4*>(text_emb + (long)d.y * kHidden + n) +
-            *reinterpret_cast<const f32x4*>(text_pos + (long)d.z * kHidden + n);
-    } else {
-        v = *reinterpret_cast<const f32x4*>(wte + (long)d.y * kHidden + n) +
-            *reinterpret_cast<const f32x4*>(wpe + (long)d.z * kHidden + n);
-    }
+    // NOTE: written with pointer selects instead of a 3-way if/else: hipcc (ROCm 7.2) left the store address
+    // register undefined on the third arm of the branchy form (seen in the .s; aperture violation on gfx950).
+    const float* pa = (d.x == 0) ? spk_cond + ((long)d.z * 32 + d.y) * kHidden
+                                 : ((d.x == 1) ? text_emb + (long)d.y * kHidden : wte + (long)d.y * kHidden);
+    const float* pb = (d.x == 1) ? text_pos + (long)d.z * kHidden : wpe + (long)d.z * kHidden;
+    f32x4 v = *reinterpret_cast<const f32x4*>(pa + n);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(pb + n);
+    if (d.x != 0) v += w;
     *reinterpret_cast<f32x4*>(h + (long)m * kHidden + n) = v;
 }
 
 void launch_embed_prompt(const int4* desc, const float* spk_cond, const float* text_emb, const float* text_pos,
                          const float* wte, const float* wpe, float* h, int M, hipStream_t st) {
+    trace_launch("embed_prompt_kernel");
     hipLaunchKernelGGL(embed_prompt_kernel, dim3(M), dim3(256), 0, st, desc, spk_cond, text_emb, text_pos, wte, wpe, h);
     HIP_CHECK(hipGetLastError());
 }
@@ -341,6 +376,7 @@ __global__ __launch_bounds__(256) void embed_decode_kernel(const int* __restrict
 
 void launch_embed_decode(const int* row_slot, const int* slot_tok, const int* slot_pos, const float* wte,
                          const float* wpe, float* h, int M, hipStream_t st) {
+    trace_launch("embed_decode_kernel");
     hipLaunchKernelGGL(embed_decode_kernel, dim3(M), dim3(256), 0, st, row_slot, slot_tok, slot_pos, wte, wpe, h);
     HIP_CHECK(hipGetLastError());
 }
@@ -401,6 +437,7 @@ __global__ __launch_bounds__(256) void final_norm_kernel(const float* __restrict
 void launch_final_norm(const float* xn, const int* sample_row, const int* sample_slot, const float* gamma,
                        const float* beta, float* ybuf, float* latents, long lat_slot_stride,
                        const int* slot_ngen, int max_lat_rows, int Ms, float eps, hipStream_t st) {
+    trace_launch("final_norm_kernel");
     hipLaunchKernelGGL(final_norm_kernel, dim3((Ms + 3) / 4), dim3(256), 0, st, xn, sample_row, sample_slot, gamma, beta,
                        ybuf, latents, lat_slot_stride, slot_ngen, max_lat_rows, Ms, eps);
     HIP_CHECK(hipGetLastError());
@@ -482,7 +519,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
     int tok;
     if (T < 1e-5f) {
         float bv = -INFINITY;
-        int bi = 0x7fffffff;
+        int bi = 0;   // NaN/-inf rows fall back to id 0 instead of indexing out of range
         for (int v = tid; v < V; v += 256)
             if (z[v] > bv) {
                 bv = z[v];
@@ -561,7 +598,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
         const unsigned seed = a.seed[slot];
         const unsigned step = (unsigned)a.slot_ngen[slot];
         float bv = -INFINITY;
-        int bi = 0x7fffffff;
+        int bi = 0;   // NaN/-inf rows fall back to id 0 instead of indexing out of range
         for (int v = tid; v < V; v += 256) {
             const float p = expf(z[v] - maxv) / sum2;
             const float qv = p / exp_noise(seed, step, (unsigned)v);
@@ -588,6 +625,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
 
 void launch_sampler(const SamplerArgs& a, hipStream_t st) {
     AUR_REQUIRE(a.V <= 1040, "sampler: V <= 1040");
+    trace_launch("sampler_kernel");
     hipLaunchKernelGGL(sampler_kernel, dim3(a.Ms), dim3(256), 0, st, a);
     HIP_CHECK(hipGetLastError());
 }

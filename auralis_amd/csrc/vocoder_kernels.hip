@@ -142,6 +142,7 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
     AUR_REQUIRE(a.Mtot % MT == 0, "conv: Mtot % MT");
     const int n_q = a.ups_s ? a.max_len + 1 : a.max_len;
     dim3 grid((n_q + NT - 1) / NT, a.Mtot / MT, a.B);
+    trace_launch("conv1d_mfma_kernel");
     hipLaunchKernelGGL((conv1d_mfma_kernel<KS, DIL, MT, CK>), grid, dim3(256), 0, st, a);
 }
 
@@ -215,6 +216,7 @@ void launch_interp2(const float* lat, long lat_bstride, const int* lat_row, cons
     const float r1 = (float)(1.0 / (1024.0 / 256.0));
     const float r2 = (float)(1.0 / (24000.0 / 22050.0));
     dim3 grid((max_len + 255) / 256, C, B);
+    trace_launch("interp2_kernel");
     hipLaunchKernelGGL(interp2_kernel, grid, dim3(256), 0, st, lat, lat_bstride, lat_row, n_lat, base_len, z, z_stride,
                        z_bstride, C, r1, r2);
     HIP_CHECK(hipGetLastError());
@@ -260,6 +262,7 @@ void launch_conv_post(const float* x, const float* w, float* wav, const int* bas
                       hipStream_t st) {
     AUR_REQUIRE(Cin <= 32, "conv_post: Cin <= 32");
     dim3 grid((max_len + 255) / 256, B);
+    trace_launch("conv_post_kernel");
     hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), 0, st, x, w, wav, base_len, len_mul, Cin, x_stride,
                        x_bstride, wav_bstride, slope);
     HIP_CHECK(hipGetLastError());
@@ -285,6 +288,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict_
 void launch_gemv_rows(const float* W, const float* bias, const float* g, float* y, int R, int K, int B,
                       long g_bstride, long y_bstride, hipStream_t st) {
     dim3 grid((R + 3) / 4, B);
+    trace_launch("gemv_rows_kernel");
     hipLaunchKernelGGL(gemv_rows_kernel, grid, dim3(256), 0, st, W, bias, g, y, R, K, g_bstride, y_bstride);
     HIP_CHECK(hipGetLastError());
 }

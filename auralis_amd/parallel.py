@@ -1,0 +1,62 @@
+"""Multi-GPU: utterance-level data parallelism, one process (one engine) per GPU.
+
+The path shards by independent units (each <=250-char chunk is its own sequence with its own KV and sampler
+state); the only shared datum is the speaker conditioning, sent with ONE collective: a broadcast of
+{gpt_cond_latent [32,1024], speaker_embedding [512]} = 133 120 B from the rank that computed it.  On the GPU
+box the backend is "nccl" (= RCCL over xGMI) and the receive buffer is handed to the engine as a device
+pointer (aur_set_conditioning_device); on CPU (gloo, used by the world_size-2 tests) it goes through host memory.
+The reference has no counterpart (it forwards tensor_parallel_size to vLLM, XTTSv2.py:214-215, default 1).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+COND_ELEMS = 32 * 1024
+SPK_ELEMS = 512
+PAYLOAD_BYTES = (COND_ELEMS + SPK_ELEMS) * 4
+
+
+def pack_conditioning(gpt_cond_latent: torch.Tensor, speaker_embedding: torch.Tensor) -> torch.Tensor:
+    return torch.cat([gpt_cond_latent.reshape(-1).float(), speaker_embedding.reshape(-1).float()])
+
+
+def broadcast_conditioning(engine, speaker_key: int, gpt_cond_latent: Optional[torch.Tensor],
+                           speaker_embedding: Optional[torch.Tensor], src: int = 0,
+                           device: Optional[torch.device] = None) -> torch.Tensor:
+    """Broadcast one speaker's conditioning from `src` and register it with the local engine.
+
+    Non-source ranks pass None for the tensors.  Returns the flat [33280] buffer (on `device`).
+    """
+    import torch.distributed as dist
+    device = device or torch.device("cpu")
+    buf = torch.empty(COND_ELEMS + SPK_ELEMS, dtype=torch.float32, device=device)
+    if dist.get_rank() == src:
+        buf.copy_(pack_conditioning(gpt_cond_latent, speaker_embedding))
+    dist.broadcast(buf, src=src)
+    if engine is not None:
+        if buf.is_cuda:
+            torch.cuda.synchronize(buf.device)
+            engine.set_conditioning_device(speaker_key, buf.data_ptr(), buf.data_ptr() + COND_ELEMS * 4)
+        else:
+            engine.set_conditioning(speaker_key, buf[:COND_ELEMS].numpy(), buf[COND_ELEMS:].numpy())
+    return buf
+
+
+def shard_units(n_units: int, world: int, rank: int, per_gpu_batch: int = 64) -> List[int]:
+    """Indices of the units (utterance chunks) owned by `rank`: blocks of `per_gpu_batch` dealt round-robin,
+    so that C4 (512 utterances, 64/GPU x 8) gives every GPU one full batch and long-form streams stay ordered
+    inside a block.  No data-path collective: results return per GPU over PCIe."""
+    out = []
+    for start in range(0, n_units, per_gpu_batch):
+        if (start // per_gpu_batch) % world == rank:
+            out.extend(range(start, min(n_units, start + per_gpu_batch)))
+    return out
+
+
+def merge_ordered(per_rank: Sequence[Sequence[tuple]]) -> List[tuple]:
+    """Re-order (unit_index, payload) pairs from all ranks by unit index (what _yield_ordered_outputs does for
+    chunk outputs in the reference, two_phase_scheduler.py:308-388)."""
+    flat = [x for r in per_rank for x in r]
+    return sorted(flat, key=lambda t: t[0])

@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — realtime-factor / audio-samples-per-second of the generate_speech() hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input: BASELINE.json configs[2]
+(64 concurrent 200-char utterances, shared speaker latent, temperature 0.75 / top_p 0.85 / top_k 50 /
+repetition penalty 5.0) per GPU: 70 text tokens -> prefill of 103 rows -> 280 mel tokens (fixed-length
+mode) -> latent stash -> HiFi-GAN -> 312 064 samples per utterance, waveforms copied to host.
+Weights (seeded synthetic, true shapes) and speaker conditioning are resident in HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+Multi-GPU: utterances are independent, so each rank runs its own 64-way batch (weak scaling); the only
+collective is one RCCL broadcast of the speaker conditioning (133 120 B) from rank 0 before the timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_MFMA_PEAK_TFLOPS = 157.3  # exact-f32 MFMA / vector peak
+
+
+def cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, n_tokens: int):
+    """Time the CPU oracle (kind 'port') on a bounded sample of the same workload: ONE utterance, greedy,
+    n_tokens mel tokens (prefill + decode + literal second pass + vocoder)."""
+    from oracle import xtts_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    gpt = O.GPTOracle(gpt_sd, xtts_sd)
+    w = O.vocoder_effective_weights(xtts_sd)
+    c = gpt.build_cond(cond, text_ids)
+    t0 = time.perf_counter()
+    out = gpt.generate(c, O.SamplingCfg(temperature=0.0, max_tokens=n_tokens, ignore_stop=True))
+    t1 = time.perf_counter()
+    lat = gpt.second_pass_latents(c, out["tokens"])
+    t2 = time.perf_counter()
+    wav = O.hifi_decoder_forward(w, lat, spk)
+    t3 = time.perf_counter()
+    n = wav.numel()
+    return {
+        "value": n / (t3 - t0), "unit": "audio-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"1 utterance, 70 text tokens, {n_tokens} mel tokens greedy -> {n} samples: prefill+decode "
+                  f"{t1 - t0:.2f}s, second pass {t2 - t1:.2f}s, vocoder {t3 - t2:.2f}s (torch CPU fp32 oracle)",
+        "rtf": (t3 - t0) / (n / 24000.0),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
+    ap.add_argument("--tokens", type=int, default=280, help="mel tokens per utterance (fixed-length mode)")
+    ap.add_argument("--layers", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tokens", type=int, default=64)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+
+    from auralis_amd._lib import NativeEngine
+    from auralis_amd.checkpoint import (make_synthetic_conditioning, make_synthetic_gpt, make_synthetic_text_ids,
+                                        make_synthetic_xtts)
+    from auralis_amd.config import XTTSDims
+    from auralis_amd.parallel import broadcast_conditioning
+    from auralis_amd.weights import pack_all
+
+    dims = XTTSDims()
+    gpt_sd = make_synthetic_gpt(dims.gpt, seed=1234, n_layer=args.layers)
+    xtts_sd = make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd)
+    eng = NativeEngine(n_layer=args.layers, max_seqs=args.batch, device=local_rank, profile=True)
+    eng.load_weights(pack_all(gpt_sd, xtts_sd))
+
+    # speaker conditioning: computed on rank 0, RCCL-broadcast over xGMI, registered from the device buffer
+    cond, spk = make_synthetic_conditioning(dims)
+    SPK = 1
+    if world > 1:
+        broadcast_conditioning(eng, SPK, cond if rank == 0 else None, spk if rank == 0 else None, src=0,
+                               device=torch.device("cuda", local_rank))
+    else:
+        eng.set_conditioning(SPK, cond.numpy(), spk.numpy())
+    text_ids = make_synthetic_text_ids(dims, n_text=70, seed=11)
+
+    def one_step(step_idx: int):
+        for b in range(args.batch):
+            eng.submit(text_ids, SPK, temperature=0.75, top_p=0.85, top_k=50, repetition_penalty=5.0,
+                       max_tokens=args.tokens, seed=(rank * 100003 + step_idx * 1009 + b), ignore_stop=True)
+        outs = eng.run_until_done()
+        assert len(outs) == args.batch
+        return sum(len(o["wav"]) for o in outs)
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        eng.sync()
+
+    for w in range(args.warmup):
+        one_step(-1 - w)
+    eng.reset_stats()
+    fence()
+    t0 = time.perf_counter()
+    samples = 0
+    for k in range(args.steps):
+        samples += one_step(k)
+    fence()
+    dt = time.perf_counter() - t0
+    st = eng.stats()
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+        s = torch.tensor([samples], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(s, op=torch.distributed.ReduceOp.SUM)
+        samples = float(s.item())
+
+    if rank == 0:
+        audio_s = samples / 24000.0
+        conv_s = st["conv_ms"] * 1e-3
+        n_launch = max(1, st["conv_launches"])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.isfile(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("conv1d_mfma_kernel_bytes_per_launch")
+            except Exception:
+                traffic = None
+        ach_gbps = st["conv_bytes"] / conv_s / 1e9 if conv_s > 0 else 0.0
+        line = {
+            "metric": "audio_samples_per_s (64-way batch; rtf = wall_s / audio_s alongside)",
+            "value": samples / dt, "unit": "audio-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "rtf": dt / audio_s, "audio_sec_per_wall_sec": audio_s / dt,
+            "config": {"workload": f"{args.batch} concurrent 200-char utterances per GPU (70 text tokens -> "
+                                   f"{args.tokens} mel tokens fixed-length -> {dims.voc.samples_for_latents(args.tokens)} "
+                                   f"samples each), T=0.75 top_p=0.85 top_k=50 rep_pen=5.0, shared speaker latent, "
+                                   f"continuous batching; BASELINE.json configs[2]",
+                       "utterances_per_gpu": args.batch, "mel_tokens": args.tokens, "gpt_layers": args.layers,
+                       "parallelism": f"dp{world} (independent utterances, 1 RCCL broadcast of conditioning)"},
+            "roofline": {
+                "kernel": "conv1d_mfma_kernel (HiFi-GAN convs, all instantiations; dominant kernel family)",
+                "bound": "hbm", "achieved": ach_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": ach_gbps / HBM_PEAK_GBPS, "traffic": traffic,
+                "avg_launch_ms": st["conv_ms"] / n_launch, "launches": st["conv_launches"],
+                "algorithmic_bytes_per_launch": st["conv_bytes"] / n_launch,
+                "note": "north_star grades the vocoder against HBM; with exact-f32 MFMA it is ALU-bound: see mfma_f32",
+                "mfma_f32": {"achieved": st["conv_flops"] / conv_s / 1e12 if conv_s > 0 else 0.0,
+                             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": (st["conv_flops"] / conv_s / 1e12 / FP32_MFMA_PEAK_TFLOPS) if conv_s > 0 else 0.0},
+            },
+            "breakdown_ms_per_step": {"gpt": st["gpt_ms"] / args.steps, "vocoder": st["vocoder_ms"] / args.steps,
+                                      "vocoder_convs": st["conv_ms"] / args.steps,
+                                      "gpt_ms_per_decode_step": st["gpt_ms"] / max(1, st["steps"])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, args.cpu_tokens)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

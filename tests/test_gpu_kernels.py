@@ -1,0 +1,137 @@
+"""GPU: each HIP kernel family against plain torch-CPU fp32 through the C-ABI debug entry points."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from auralis_amd import weights as Wt
+from tests.gpu_util import make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e, *_ = make_engine(1, max_seqs=8)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("M,N,K,kw", [(64, 1024, 1024, 64), (5, 3072, 1024, 64), (64, 1024, 4096, 64),
+                                      (103, 4096, 1024, 64), (300, 1024, 1024, 256), (130, 1088, 1024, 64),
+                                      (1, 1024, 1024, 16), (300, 1024, 1024, 0), (200, 1024, 4096, 0)])
+def test_gemm_splitk(eng, M, N, K, kw):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    X = torch.randn(M, K, generator=g)
+    W = torch.randn(K, N, generator=g) * 0.05          # asymmetric, non-square: catches transposes
+    ref = (X.double() @ W.double()).float().numpy()
+    got = eng.dbg_gemm(X.numpy(), W.numpy(), kw)
+    err = np.abs(got - ref).max()
+    assert err < 2e-4 * max(1.0, np.abs(ref).max()), err
+
+
+def test_gemm_is_batch_invariant_bitwise(eng):
+    """Fused-slice form (M > 128) and split form (M <= 128) add the K-slices in the same order."""
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(200, 4096, generator=g)
+    W = torch.randn(4096, 1024, generator=g) * 0.05
+    big = eng.dbg_gemm(X.numpy(), W.numpy(), 0)
+    small = eng.dbg_gemm(X[:50].numpy(), W.numpy(), 0)
+    assert np.array_equal(big[:50], small)
+
+
+def test_layernorm(eng):
+    g = torch.Generator().manual_seed(0)
+    h = torch.randn(37, 1024, generator=g) * 3 + 0.5
+    gamma = torch.randn(1024, generator=g)
+    beta = torch.randn(1024, generator=g)
+    ref = F.layer_norm(h, (1024,), gamma, beta, 1e-5).numpy()
+    got = eng.dbg_layernorm(h.numpy(), gamma.numpy(), beta.numpy())
+    assert np.abs(got - ref).max() < 2e-5
+
+
+CONV_CASES = [(64, 32, 3, 1), (64, 32, 3, 3), (64, 32, 3, 5), (128, 16, 7, 1), (64, 16, 7, 3), (64, 16, 7, 5),
+              (64, 16, 11, 1), (64, 16, 11, 3), (64, 16, 11, 5), (32, 32, 3, 1), (32, 32, 7, 5), (32, 32, 11, 5),
+              (32, 32, 11, 1)]
+
+
+@pytest.mark.parametrize("cout,cin,k,d", CONV_CASES)
+def test_conv1d_mfma(eng, cout, cin, k, d):
+    g = torch.Generator().manual_seed(cout + cin * k + d)
+    B, L = 2, 700
+    lens = [700, 389]                                    # ragged batch: per-utterance zero padding
+    w = torch.randn(cout, cin, k, generator=g) / (cin * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    x = torch.randn(B, cin, L, generator=g)
+    res = torch.randn(B, cout, L, generator=g)
+    pad = (k - 1) // 2 * d
+    got = eng.dbg_conv1d(x.numpy(), Wt.pack_conv(w).numpy(), b.numpy(), res.numpy(), lens, k, d, pad, 0.1, cout)
+    for bi, ln in enumerate(lens):
+        ref = F.conv1d(F.leaky_relu(x[bi:bi + 1, :, :ln], 0.1), w, b, dilation=d, padding=pad)[0] + res[bi, :, :ln]
+        err = (torch.from_numpy(got[bi, :, :ln]) - ref).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), (bi, err)
+        assert np.all(got[bi, :, ln:] == 0.0)            # nothing written past the utterance
+
+
+@pytest.mark.parametrize("cin,cout,s,k", [(64, 32, 8, 16), (32, 32, 2, 4), (512, 256, 8, 16)])
+def test_conv_transpose_polyphase(eng, cin, cout, s, k):
+    g = torch.Generator().manual_seed(cin + s)
+    B, L = 2, 300
+    lens = [300, 77]
+    w = torch.randn(cin, cout, k, generator=g) / (cin * k / s) ** 0.5
+    b = torch.randn(cout, generator=g)
+    x = torch.randn(B, cin, L, generator=g)
+    wp = Wt.pack_conv(Wt.polyphase_convT(w, s))
+    got = eng.dbg_conv1d(x.numpy(), wp.numpy(), b.numpy(), None, lens, 2, 1, 1, 0.1, cout, ups_s=s, ups_p=(k - s) // 2)
+    for bi, ln in enumerate(lens):
+        ref = F.conv_transpose1d(F.leaky_relu(x[bi:bi + 1, :, :ln], 0.1), w, b, stride=s, padding=(k - s) // 2)[0]
+        err = (torch.from_numpy(got[bi, :, :ln * s]) - ref).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), (bi, err)
+
+
+def test_sampler_greedy_and_penalty(eng):
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(6, 1026, generator=g)
+    toks = eng.dbg_sample(logits.numpy(), 0.0, 0.85, 50)
+    assert list(toks) == logits.argmax(dim=1).tolist()
+    # repetition penalty applies in greedy mode too (hijack.py:49-88)
+    seen = np.zeros((6, 1026), dtype=np.uint8)
+    for r in range(6):
+        seen[r, int(logits[r].argmax())] = 1
+    toks2 = eng.dbg_sample(logits.numpy(), 0.0, 0.85, 50, repetition_penalty=5.0, seen=seen)
+    from oracle import xtts_oracle as O
+    for r in range(6):
+        z = O.apply_repetition_penalty(logits[r], np.nonzero(seen[r])[0].tolist(), 5.0)
+        assert toks2[r] == int(z.argmax())
+
+
+@pytest.mark.parametrize("T,top_k,top_p", [(0.75, 50, 0.85), (1.0, -1, 0.5), (0.3, 5, 1.0), (1.3, 1026, 0.99)])
+def test_sampler_matches_oracle_with_shared_noise(eng, T, top_k, top_p):
+    from oracle import xtts_oracle as O
+    g = torch.Generator().manual_seed(int(T * 100) + top_k)
+    B = 8
+    logits = torch.randn(B, 1026, generator=g) * 2.0
+    seed, step = 1000, 3
+    toks = eng.dbg_sample(logits.numpy(), T, top_p, top_k, seed=seed, step=step)
+    agree = 0
+    for r in range(B):
+        noise = O.exp_noise(seed + r, step, 1026)
+        agree += int(toks[r] == O.sample_token(logits[r], T, top_k, top_p, noise))
+    assert agree == B, (agree, toks)
+
+
+def test_sampler_distribution_chi2(eng):
+    """Exponential-race sampling reproduces softmax(top-k) frequencies (chi-square over 4000 draws)."""
+    z = np.full(1026, -30.0, dtype=np.float32)
+    p = np.array([0.4, 0.3, 0.2, 0.1])
+    z[:4] = np.log(p)
+    counts = np.zeros(4)
+    B = 8
+    for it in range(500):
+        toks = eng.dbg_sample(np.tile(z, (B, 1)), 1.0, 1.0, 4, seed=it * 64, step=it)
+        for t in toks:
+            assert t < 4
+            counts[t] += 1
+    n = counts.sum()
+    chi2 = float(((counts - n * p) ** 2 / (n * p)).sum())
+    assert chi2 < 16.3, (chi2, counts)     # 3 dof, p = 0.001

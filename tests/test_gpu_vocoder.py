@@ -1,0 +1,73 @@
+"""GPU: HIP vocoder vs (a) golden vectors produced by the REFERENCE HifiDecoder, (b) the oracle at other sizes,
+(c) size-independent properties at the BASELINE utterance length."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import SPK_KEY, make_engine, rms
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "vocoder_T*.npz")))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    e, gpt_sd, xtts_sd, cond, spk = make_engine(1, max_seqs=2)
+    yield e, xtts_sd, spk
+    e.close()
+
+
+def _check(got, ref):
+    assert got.shape == ref.shape
+    err = rms(got - ref)
+    sig = rms(ref)
+    # north_star: <= 1e-3 RMS on the waveform; synthetic weights give a quiet signal, so also bound the
+    # error relative to the signal
+    assert err <= 1e-3 and err <= 1e-2 * sig, (err, sig)
+    return err, sig
+
+
+@pytest.mark.parametrize("path", GOLDEN)
+def test_vocoder_matches_reference_golden(ctx, path):
+    e, _, _ = ctx
+    g = np.load(path)
+    wav = e.vocode(g["latents"], None, SPK_KEY)[0]
+    err, sig = _check(wav, g["wav"])
+    assert err < 1e-5, err          # fp32 MFMA is an exact-f32 fma chain: expect ~1e-7
+
+
+def test_vocoder_ragged_batch_matches_oracle(ctx):
+    from oracle import xtts_oracle as O
+    e, xtts_sd, spk = ctx
+    w = O.vocoder_effective_weights(xtts_sd)
+    gen = torch.Generator().manual_seed(9)
+    lens = [31, 7, 18]
+    lat = torch.zeros(3, 31, 1024)
+    for b, n in enumerate(lens):
+        lat[b, :n] = torch.randn(n, 1024, generator=gen)
+    wavs = e.vocode(lat.numpy(), lens, SPK_KEY)
+    for b, n in enumerate(lens):
+        ref = O.hifi_decoder_forward(w, lat[b:b + 1, :n], spk).reshape(-1).numpy()
+        _check(wavs[b], ref)
+
+
+def test_vocoder_full_length_properties(ctx, dims):
+    """280 latent frames (the 200-char utterance of BASELINE configs): length, range, determinism, batch invariance."""
+    e, _, _ = ctx
+    gen = torch.Generator().manual_seed(1)
+    lat = torch.randn(1, 280, 1024, generator=gen).numpy()
+    w1 = e.vocode(lat, None, SPK_KEY)[0]
+    assert w1.shape == (dims.voc.samples_for_latents(280),) == (312064,)
+    assert np.isfinite(w1).all() and np.abs(w1).max() <= 1.0
+    w2 = e.vocode(lat, None, SPK_KEY)[0]
+    assert np.array_equal(w1, w2)
+    both = e.vocode(np.concatenate([lat, lat[:, ::-1].copy()], axis=0), None, SPK_KEY)
+    assert np.array_equal(both[0], w1)
+    # locality: the first samples do not depend on frames far away (receptive field << 140 frames)
+    lat3 = lat.copy()
+    lat3[0, 200:] = 0.0
+    w3 = e.vocode(lat3, None, SPK_KEY)[0]
+    assert np.array_equal(w3[:100000], w1[:100000])
