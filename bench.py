@@ -31,27 +31,40 @@ HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.
 FP32_MFMA_PEAK_TFLOPS = 157.3  # exact-f32 MFMA / vector peak
 
 
-def cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, n_tokens: int):
+def _log(msg: str):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, n_tokens: int, budget_s: float = 20.0):
     """Time the CPU oracle (kind 'port') on a bounded sample of the same workload: ONE utterance, greedy,
-    n_tokens mel tokens (prefill + decode + literal second pass + vocoder)."""
+    up to n_tokens mel tokens (prefill + decode + literal second pass + vocoder).  The decode loop stops early
+    when `budget_s` is used up, so the leg is bounded whatever the host looks like."""
     from oracle import xtts_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(cores, 64)))
     gpt = O.GPTOracle(gpt_sd, xtts_sd)
     w = O.vocoder_effective_weights(xtts_sd)
     c = gpt.build_cond(cond, text_ids)
     t0 = time.perf_counter()
-    out = gpt.generate(c, O.SamplingCfg(temperature=0.0, max_tokens=n_tokens, ignore_stop=True))
+    out = gpt.generate(c, O.SamplingCfg(temperature=0.0, max_tokens=8, ignore_stop=True))
+    t_probe = time.perf_counter() - t0
+    # scale the sample so that prefill + decode + second pass + vocoder stay near the budget
+    per_tok = max(1e-3, t_probe / 8.0)
+    n = int(max(8, min(n_tokens, budget_s / (3.0 * per_tok))))
+    _log(f"cpu_baseline: probe 8 tokens in {t_probe:.2f}s on {torch.get_num_threads()} threads -> sample {n} tokens")
+    t0 = time.perf_counter()
+    out = gpt.generate(c, O.SamplingCfg(temperature=0.0, max_tokens=n, ignore_stop=True))
     t1 = time.perf_counter()
     lat = gpt.second_pass_latents(c, out["tokens"])
     t2 = time.perf_counter()
     wav = O.hifi_decoder_forward(w, lat, spk)
     t3 = time.perf_counter()
-    n = wav.numel()
+    ns = wav.numel()
     return {
-        "value": n / (t3 - t0), "unit": "audio-samples/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"1 utterance, 70 text tokens, {n_tokens} mel tokens greedy -> {n} samples: prefill+decode "
+        "value": ns / (t3 - t0), "unit": "audio-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"1 utterance, 70 text tokens, {n} mel tokens greedy -> {ns} samples: prefill+decode "
                   f"{t1 - t0:.2f}s, second pass {t2 - t1:.2f}s, vocoder {t3 - t2:.2f}s (torch CPU fp32 oracle)",
-        "rtf": (t3 - t0) / (n / 24000.0),
+        "rtf": (t3 - t0) / (ns / 24000.0),
     }
 
 
@@ -87,10 +100,12 @@ def main():
     from auralis_amd.weights import pack_all
 
     dims = XTTSDims()
+    _log("building synthetic checkpoint")
     gpt_sd = make_synthetic_gpt(dims.gpt, seed=1234, n_layer=args.layers)
     xtts_sd = make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd)
     eng = NativeEngine(n_layer=args.layers, max_seqs=args.batch, device=local_rank, profile=True)
     eng.load_weights(pack_all(gpt_sd, xtts_sd))
+    _log("weights resident")
 
     # speaker conditioning: computed on rank 0, RCCL-broadcast over xGMI, registered from the device buffer
     cond, spk = make_synthetic_conditioning(dims)
@@ -106,7 +121,7 @@ def main():
         for b in range(args.batch):
             eng.submit(text_ids, SPK, temperature=0.75, top_p=0.85, top_k=50, repetition_penalty=5.0,
                        max_tokens=args.tokens, seed=(rank * 100003 + step_idx * 1009 + b), ignore_stop=True)
-        outs = eng.run_until_done()
+        outs = eng.run_until_done(max_steps=args.tokens + 16)
         assert len(outs) == args.batch
         return sum(len(o["wav"]) for o in outs)
 
@@ -118,12 +133,14 @@ def main():
 
     for w in range(args.warmup):
         one_step(-1 - w)
+        _log(f"warmup step {w} done")
     eng.reset_stats()
     fence()
     t0 = time.perf_counter()
     samples = 0
     for k in range(args.steps):
         samples += one_step(k)
+        _log(f"timed step {k} done at +{time.perf_counter() - t0:.3f}s")
     fence()
     dt = time.perf_counter() - t0
     st = eng.stats()
