@@ -415,8 +415,10 @@ public:
     void dbg_gemm(const float* X, const float* Wm, float* out, int M, int N, int K, int kw) {
         use();
         GemmPlan pl = gemm_plan(M, K);
-        if (kw > 0) {   // explicit kw: force the split form with that slice width
-            pl.kw = kw; pl.slices = K / (4 * kw); pl.fused = false; pl.slabs = pl.slices;
+        if (kw == 1) {   // kw == 1: force the split (one slab per slice) form; kw == 2: force the fused form
+            pl.fused = false; pl.slabs = pl.slices;
+        } else if (kw == 2) {
+            pl.fused = true; pl.slabs = 1;
         }
         const int S = pl.slabs;
         DevBuf dx, dw, dp, dout;

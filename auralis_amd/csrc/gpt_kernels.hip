@@ -15,74 +15,83 @@ namespace aur {
 //   step (s', c):  A[i][k'] = X[m][kb + 4k' + s'],  B[k'][j'] = W[kb + 4k' + s'][n0 + 4j' + c]
 //   D[i][j'] accumulates column n0 + 4j' + c, i.e. lane j' owns 4 consecutive columns across c = 0..3.
 template <bool FUSED>
-__global__ __launch_bounds__(256) void gemm_splitk_kernel(const float* __restrict__ X, int ldx,
+__global__ __launch_bounds__(512) void gemm_splitk_kernel(const float* __restrict__ X, int ldx,
                                                           const float* __restrict__ W, float* __restrict__ P,
-                                                          int M, int N, int kw, int n_slices) {
-    __shared__ __attribute__((aligned(16))) float red[3][64][68];
+                                                          int M, int N, int n_slices) {
+    // 8 waves: wave = (K-quarter ks, M-half mh).  Each wave streams its 64 weight rows x 64 columns once
+    // (16 float4 loads issued back to back, so one HBM latency covers the whole slice) and multiplies them
+    // with its 32 activation rows.  Reduction order per output element is ((k0 + k1) + k2) + k3.
+    constexpr int KW = 64;
+    __shared__ __attribute__((aligned(16))) float red[2][3][32][68];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ks = wv & 3, mh = wv >> 2;
     const int i = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * 64, m0 = blockIdx.z * 64;
-    // FUSED: this workgroup walks every K-slice and adds the slice results in slice order, which is exactly the
-    // order the split form + epilogue slab-sum uses -> bitwise identical results for any batch size.
+    const int n0 = blockIdx.x * 64, m0 = blockIdx.z * 64 + mh * 32;
     const int s_begin = FUSED ? 0 : blockIdx.y, s_end = FUSED ? n_slices : blockIdx.y + 1;
 
-    const float* xp[4];
-    bool xv[4];
+    const float* xp[2];
+    bool xv[2];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < 2; ++mt) {
         const int r = m0 + 16 * mt + i;
         xv[mt] = r < M;
         xp[mt] = X + (long)(xv[mt] ? r : 0) * ldx + 4 * q;
     }
-    f32x4 total[4][4];
+    f32x4 total[2][4];
 
     for (int s = s_begin; s < s_end; ++s) {
-        const int kbeg = (s * 4 + wv) * kw;
-        f32x4 acc[4][4];
+        const int kbeg = (s * 4 + ks) * KW;
+        const float* wp = W + (long)(kbeg + 4 * q) * N + n0 + 4 * i;
+        f32x4 bf[4][4], af[4][2];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp)
+                bf[kb][sp] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + (long)(16 * kb + sp) * N));
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                // rows >= M alias row 0: their products land in output rows that are never stored
+                af[kb][mt] = *reinterpret_cast<const f32x4*>(xp[mt] + kbeg + 16 * kb);
+            }
+        }
+        // keep every load above this line: hipcc otherwise sinks each load next to its first use and the wave
+        // pays one HBM round trip per load instead of one per slice
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[mt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* wp = W + (long)(kbeg + 4 * q) * N + n0 + 4 * i;
-        for (int kb = 0; kb < kw; kb += 16) {
-            f32x4 bf[4], af[4];
 #pragma unroll
-            for (int sp = 0; sp < 4; ++sp) bf[sp] = *reinterpret_cast<const f32x4*>(wp + (long)(kb + sp) * N);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                af[mt] = *reinterpret_cast<const f32x4*>(xp[mt] + kbeg + kb);
-                if (!xv[mt]) af[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
             for (int sp = 0; sp < 4; ++sp)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-                        acc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][sp], bf[sp][c], acc[mt][c], 0, 0, 0);
-        }
-        // in-block reduction over the 4 wave K-slices: waves 1..3 park their tiles in LDS, wave 0 adds.
-        if (wv > 0) {
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kb][mt][sp], bf[kb][sp][c], acc[mt][c], 0, 0, 0);
+        if (ks > 0) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * mt + 4 * q + r;
                     f32x4 v = {acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
-                    *reinterpret_cast<f32x4*>(&red[wv - 1][row][4 * i]) = v;
+                    *reinterpret_cast<f32x4*>(&red[mh][ks - 1][row][4 * i]) = v;
                 }
         }
         __syncthreads();
-        if (wv == 0) {
+        if (ks == 0) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * mt + 4 * q + r;
                     f32x4 v = {acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
-                    v += *reinterpret_cast<const f32x4*>(&red[0][row][4 * i]);
-                    v += *reinterpret_cast<const f32x4*>(&red[1][row][4 * i]);
-                    v += *reinterpret_cast<const f32x4*>(&red[2][row][4 * i]);
+                    v += *reinterpret_cast<const f32x4*>(&red[mh][0][row][4 * i]);
+                    v += *reinterpret_cast<const f32x4*>(&red[mh][1][row][4 * i]);
+                    v += *reinterpret_cast<const f32x4*>(&red[mh][2][row][4 * i]);
                     if (FUSED) {
                         total[mt][r] = (s == 0) ? v : total[mt][r] + v;
                     } else if (m0 + row < M) {
@@ -92,9 +101,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_kernel(const float* __restric
         }
         if (FUSED) __syncthreads();   // LDS tiles consumed before the next slice overwrites them
     }
-    if (FUSED && wv == 0) {
+    if (FUSED && ks == 0) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * mt + 4 * q + r;
@@ -116,14 +125,14 @@ GemmPlan gemm_plan(int M, int K) {
 
 void launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M, int N, int K, const GemmPlan& pl,
                         hipStream_t st) {
-    AUR_REQUIRE(N % 64 == 0 && pl.kw % 16 == 0 && K == pl.slices * 4 * pl.kw && ldx % 4 == 0, "gemm: shape");
+    AUR_REQUIRE(N % 64 == 0 && pl.kw == 64 && K == pl.slices * 4 * pl.kw && ldx % 4 == 0, "gemm: shape");
     trace_launch("gemm_splitk_kernel");
     if (pl.fused) {
         dim3 grid(N / 64, 1, (M + 63) / 64);
-        hipLaunchKernelGGL(gemm_splitk_kernel<true>, grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.kw, pl.slices);
+        hipLaunchKernelGGL(gemm_splitk_kernel<true>, grid, dim3(512), 0, st, X, ldx, W, P, M, N, pl.slices);
     } else {
         dim3 grid(N / 64, pl.slices, (M + 63) / 64);
-        hipLaunchKernelGGL(gemm_splitk_kernel<false>, grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.kw, pl.slices);
+        hipLaunchKernelGGL(gemm_splitk_kernel<false>, grid, dim3(512), 0, st, X, ldx, W, P, M, N, pl.slices);
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -135,51 +144,57 @@ __global__ __launch_bounds__(256) void rows_ln_kernel(const float* __restrict__ 
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float* __restrict__ out,
                                                       int M, float eps) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= M) return;
-    f32x4 v[4];
-    float sum = 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int n = 4 * (lane + 64 * u);
-        v[u] = *reinterpret_cast<const f32x4*>(h + (long)row * kHidden + n);
-        if (S > 0) {
-            f32x4 t = *reinterpret_cast<const f32x4*>(P + (long)row * kHidden + n);
-            for (int s = 1; s < S; ++s) t += *reinterpret_cast<const f32x4*>(P + ((long)s * M + row) * kHidden + n);
-            t += *reinterpret_cast<const f32x4*>(bias + n);
-            v[u] += t;
-            *reinterpret_cast<f32x4*>(h + (long)row * kHidden + n) = v[u];
+    // one workgroup per row: 256 lanes x float4 = 1024; slab loads are independent (unrolled), statistics go
+    // wave shuffle -> 4-entry LDS
+    __shared__ float part[2][4];
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = 4 * tid;
+    f32x4 v = *reinterpret_cast<const f32x4*>(h + (long)row * kHidden + n);
+    if (S > 0) {
+        const float* p0 = P + (long)row * kHidden + n;
+        const long sstride = (long)M * kHidden;
+        f32x4 t = *reinterpret_cast<const f32x4*>(p0);
+        int s = 1;
+        for (; s + 3 < S; s += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p0 + s * sstride);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p0 + (s + 1) * sstride);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(p0 + (s + 2) * sstride);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(p0 + (s + 3) * sstride);
+            t += a; t += b; t += c; t += d;
         }
-        sum += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+        for (; s < S; ++s) t += *reinterpret_cast<const f32x4*>(p0 + s * sstride);
+        t += *reinterpret_cast<const f32x4*>(bias + n);
+        v += t;
+        *reinterpret_cast<f32x4*>(h + (long)row * kHidden + n) = v;
     }
-    const float mean = wave_sum(sum) * (1.0f / kHidden);
+    float sum = wave_sum((v[0] + v[1]) + (v[2] + v[3]));
+    if (lane == 0) part[0][wv] = sum;
+    __syncthreads();
+    const float mean = ((part[0][0] + part[0][1]) + (part[0][2] + part[0][3])) * (1.0f / kHidden);
     float sq = 0.f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float d = v[u][c] - mean;
-            sq = fmaf(d, d, sq);
-        }
-    const float var = wave_sum(sq) * (1.0f / kHidden);
-    const float rstd = 1.0f / sqrtf(var + eps);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int n = 4 * (lane + 64 * u);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + n);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + n);
-        f32x4 o;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) o[c] = (v[u][c] - mean) * rstd * g[c] + b[c];
-        *reinterpret_cast<f32x4*>(out + (long)row * kHidden + n) = o;
+    for (int c = 0; c < 4; ++c) {
+        const float d = v[c] - mean;
+        sq = fmaf(d, d, sq);
     }
+    sq = wave_sum(sq);
+    if (lane == 0) part[1][wv] = sq;
+    __syncthreads();
+    const float var = ((part[1][0] + part[1][1]) + (part[1][2] + part[1][3])) * (1.0f / kHidden);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + n);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + n);
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = (v[c] - mean) * rstd * g[c] + b[c];
+    *reinterpret_cast<f32x4*>(out + (long)row * kHidden + n) = o;
 }
 
 void launch_rows_ln(const float* P, int S, const float* bias, float* h, const float* gamma, const float* beta,
                     float* out, int M, float eps, hipStream_t st) {
     trace_launch("rows_ln_kernel");
-    hipLaunchKernelGGL(rows_ln_kernel, dim3((M + 3) / 4), dim3(256), 0, st, P, S, bias, h, gamma, beta, out, M, eps);
+    hipLaunchKernelGGL(rows_ln_kernel, dim3(M), dim3(256), 0, st, P, S, bias, h, gamma, beta, out, M, eps);
     HIP_CHECK(hipGetLastError());
 }
 

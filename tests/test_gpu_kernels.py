@@ -17,9 +17,11 @@ def eng():
     e.close()
 
 
-@pytest.mark.parametrize("M,N,K,kw", [(64, 1024, 1024, 64), (5, 3072, 1024, 64), (64, 1024, 4096, 64),
-                                      (103, 4096, 1024, 64), (300, 1024, 1024, 256), (130, 1088, 1024, 64),
-                                      (1, 1024, 1024, 16), (300, 1024, 1024, 0), (200, 1024, 4096, 0)])
+# kw: 0 = engine's plan (split for M <= 128, fused above), 1 = force split form, 2 = force fused form
+@pytest.mark.parametrize("M,N,K,kw", [(64, 1024, 1024, 0), (5, 3072, 1024, 0), (64, 1024, 4096, 0),
+                                      (103, 4096, 1024, 0), (300, 1024, 1024, 1), (130, 1088, 1024, 0),
+                                      (1, 1024, 1024, 2), (33, 1024, 1024, 0), (300, 1024, 1024, 0),
+                                      (200, 1024, 4096, 0)])
 def test_gemm_splitk(eng, M, N, K, kw):
     g = torch.Generator().manual_seed(M * 7 + N)
     X = torch.randn(M, K, generator=g)
