@@ -1,0 +1,141 @@
+"""TTSOutput — container for synthesized audio, API-compatible with the reference on the path's surface
+(src/auralis/common/definitions/output.py:16-329: array, sample_rate, start_time, token_length, combine_outputs,
+to_tensor, to_bytes, save, resample, get_info, from_tensor, from_file, change_speed).  Codec back-ends differ:
+the reference goes through torchaudio/librosa/sounddevice (absent offline); wav / raw PCM are written natively,
+other formats raise."""
+from __future__ import annotations
+
+import io
+import wave
+from dataclasses import dataclass
+from pathlib import Path
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+
+
+@dataclass
+class TTSOutput:
+    array: Union[np.ndarray, bytes]
+    sample_rate: int = 24000
+    bit_depth: int = 32
+    bit_rate: int = 192
+    compression: int = 10
+    channel: int = 1
+    start_time: Optional[float] = None
+    end_time: Optional[float] = None
+    token_length: Optional[int] = None
+
+    def __post_init__(self):
+        if isinstance(self.array, np.ndarray):
+            self.array = np.asarray(self.array, dtype=np.float32).reshape(-1)
+
+    # -- construction ---------------------------------------------------------------------------------
+    @staticmethod
+    def combine_outputs(outputs: List["TTSOutput"]) -> "TTSOutput":
+        """Concatenate chunk outputs in order; sample rate of the first (output.py:95-111)."""
+        if not outputs:
+            raise ValueError("combine_outputs needs at least one output")
+        return TTSOutput(array=np.concatenate([o.array for o in outputs]), sample_rate=outputs[0].sample_rate,
+                         token_length=sum(o.token_length or 0 for o in outputs) or None,
+                         start_time=outputs[0].start_time)
+
+    @classmethod
+    def from_tensor(cls, tensor, sample_rate: int = 24000) -> "TTSOutput":
+        arr = tensor.detach().cpu().numpy() if hasattr(tensor, "detach") else np.asarray(tensor)
+        return cls(array=arr.squeeze(), sample_rate=sample_rate)
+
+    @classmethod
+    def from_file(cls, filename: Union[str, Path]) -> "TTSOutput":
+        with wave.open(str(filename), "rb") as w:
+            n, sw, ch, sr = w.getnframes(), w.getsampwidth(), w.getnchannels(), w.getframerate()
+            raw = w.readframes(n)
+        if sw == 2:
+            a = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+        elif sw == 4:
+            a = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+        else:
+            raise ValueError(f"unsupported sample width {sw}")
+        if ch > 1:
+            a = a.reshape(-1, ch).mean(axis=1)
+        return cls(array=a, sample_rate=sr)
+
+    # -- views ----------------------------------------------------------------------------------------
+    def to_tensor(self):
+        import torch
+        return torch.from_numpy(np.asarray(self.array))
+
+    def get_info(self) -> Tuple[int, int, float]:
+        n = len(self.array)
+        return n, self.sample_rate, n / float(self.sample_rate)
+
+    def to_bytes(self, format: str = "wav", sample_width: int = 2) -> bytes:
+        fmt = format.lower()
+        pcm = np.clip(np.asarray(self.array, dtype=np.float32), -1.0, 1.0)
+        if sample_width == 2:
+            data = (pcm * 32767.0).astype("<i2").tobytes()
+        elif sample_width == 4:
+            data = (pcm.astype(np.float64) * 2147483647.0).astype("<i4").tobytes()
+        else:
+            raise ValueError("sample_width must be 2 or 4")
+        if fmt in ("pcm", "raw"):
+            return data
+        if fmt == "wav":
+            buf = io.BytesIO()
+            with wave.open(buf, "wb") as w:
+                w.setnchannels(1)
+                w.setsampwidth(sample_width)
+                w.setframerate(self.sample_rate)
+                w.writeframes(data)
+            return buf.getvalue()
+        raise ValueError(f"format '{format}' needs an external codec (reference uses torchaudio); wav/pcm are built in")
+
+    def save(self, filename: Union[str, Path], sample_rate: Optional[int] = None, format: Optional[str] = None) -> None:
+        out = self if sample_rate in (None, self.sample_rate) else self.resample(sample_rate)
+        fmt = format or (Path(str(filename)).suffix.lstrip(".") or "wav")
+        Path(str(filename)).write_bytes(out.to_bytes(format=fmt))
+
+    # -- transforms -----------------------------------------------------------------------------------
+    def resample(self, new_sample_rate: int) -> "TTSOutput":
+        if new_sample_rate == self.sample_rate:
+            return self
+        from math import gcd
+
+        from scipy.signal import resample_poly
+        g = gcd(int(new_sample_rate), int(self.sample_rate))
+        y = resample_poly(np.asarray(self.array, dtype=np.float64), new_sample_rate // g, self.sample_rate // g)
+        return TTSOutput(array=y.astype(np.float32), sample_rate=new_sample_rate, token_length=self.token_length)
+
+    def change_speed(self, speed_factor: float) -> "TTSOutput":
+        """Time-stretch with an STFT phase vocoder (n_fft 2048, hop 512) and peak-normalise, as the reference does
+        through librosa (output.py:40-92)."""
+        if speed_factor <= 0:
+            raise ValueError("Speed factor must be positive")
+        if speed_factor == 1.0:
+            return self
+        from scipy.signal import istft, stft
+        n_fft, hop = 2048, 512
+        x = np.asarray(self.array, dtype=np.float32)
+        _, _, D = stft(x, nperseg=n_fft, noverlap=n_fft - hop, window="hann", boundary="zeros", padded=True)
+        n_frames = D.shape[1]
+        steps = np.arange(0, n_frames - 1, speed_factor)
+        phase_adv = np.linspace(0, np.pi * hop, D.shape[0])
+        phase = np.angle(D[:, 0])
+        out = np.zeros((D.shape[0], len(steps)), dtype=np.complex128)
+        Dp = np.pad(D, ((0, 0), (0, 2)))
+        for i, st in enumerate(steps):
+            k = int(st)
+            a = st - k
+            mag = (1 - a) * np.abs(Dp[:, k]) + a * np.abs(Dp[:, k + 1])
+            out[:, i] = mag * np.exp(1j * phase)
+            dphi = np.angle(Dp[:, k + 1]) - np.angle(Dp[:, k]) - phase_adv
+            dphi -= 2 * np.pi * np.round(dphi / (2 * np.pi))
+            phase += phase_adv + dphi
+        _, y = istft(out, nperseg=n_fft, noverlap=n_fft - hop, window="hann")
+        peak = np.max(np.abs(y)) if y.size else 0.0
+        if peak > 0:
+            y = y / peak
+        return TTSOutput(array=y.astype(np.float32), sample_rate=self.sample_rate)
+
+    def play(self) -> None:
+        raise RuntimeError("audio playback needs sounddevice (not part of the synthesis path)")

@@ -1,0 +1,161 @@
+"""XTTSv2Engine — the reference's engine plugin (src/auralis/models/xttsv2/XTTSv2.py:39-820) re-based on the HIP
+library: same public methods, same return shapes; vLLM, the second GPT pass and the torch HiFi-GAN are replaced by
+aur_submit / aur_step / aur_poll_finished.
+
+Out of scope this round: computing conditioning from reference audio (ConditioningEncoder,
+PerceiverResampler, ResNetSpeakerEncoder).  `speaker_files` may therefore be (a) a path to an .npz with
+`gpt_cond_latent` [1,32,1024] and `speaker_embedding` [1,512,1], or (b) a dict / tuple holding those arrays;
+audio files raise NotImplementedError with that explanation."""
+from __future__ import annotations
+
+import asyncio
+import hashlib
+import json
+import os
+import time
+from typing import Any, AsyncGenerator, List, Optional, Tuple
+
+import numpy as np
+
+from .driver import EngineDriver
+from .engine_base import BaseAsyncTTSEngine, ConditioningConfig, register_model
+from .output import TTSOutput
+from .requests import TTSRequest
+from .text import XTTSTokenizer
+
+
+class ChunkHandle:
+    """Opaque per-chunk "token generator" handed to the facade (the reference passes a vLLM async generator)."""
+
+    def __init__(self, future: "asyncio.Future", request_id: str, n_text: int):
+        self.future = future
+        self.request_id = request_id
+        self.n_text = n_text
+
+
+class XTTSv2Engine(BaseAsyncTTSEngine):
+    model_type = "xtts"
+
+    def __init__(self, native_engine: Any, tokenizer: XTTSTokenizer, max_concurrency: int = 10,
+                 gpt_max_audio_tokens: int = 605):
+        self.native = native_engine
+        self.tokenizer = tokenizer
+        self.max_concurrency = max_concurrency
+        self.gpt_max_audio_tokens = gpt_max_audio_tokens
+        self.driver = EngineDriver(native_engine)
+        self._speakers = {}
+        self._seed_counter = 0
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, max_concurrency: int = 10, device: int = 0,
+                        **kwargs) -> "XTTSv2Engine":
+        """Load a checkpoint directory in the reference's on-disk format (checkpoint.py docstring).  kwargs the
+        reference forwards to vLLM (tensor_parallel_size, pipeline_parallel_size, gpt_model, torch_dtype, device_map;
+        XTTSv2.py:235-243) are accepted; tp/pp other than 1 are rejected (the path shards by utterance)."""
+        from .._lib import NativeEngine
+        from ..checkpoint import load_checkpoint
+        from ..weights import pack_all
+        if kwargs.get("tensor_parallel_size", 1) != 1 or kwargs.get("pipeline_parallel_size", 1) != 1:
+            raise ValueError("the MI355X path replicates the 0.4 B-parameter model per GPU; use one engine per GPU")
+        gpt_sd, xtts_sd = load_checkpoint(pretrained_model_name_or_path)
+        n_layer = 1 + max(int(k.split(".")[2]) for k in gpt_sd if k.startswith("gpt.h."))
+        native = NativeEngine(n_layer=n_layer, max_seqs=max(1, max_concurrency), device=device)
+        native.load_weights(pack_all(gpt_sd, xtts_sd))
+        tok_file = None
+        for cand in ("tokenizer.json", os.path.join("gpt", "tokenizer.json")):
+            p = os.path.join(pretrained_model_name_or_path, cand)
+            if os.path.isfile(p):
+                tok_file = p
+        vocab = xtts_sd["text_embedding.weight"].shape[0]
+        return cls(native, XTTSTokenizer(tok_file, vocab_size=vocab), max_concurrency=max_concurrency)
+
+    @property
+    def conditioning_config(self) -> ConditioningConfig:
+        return ConditioningConfig(speaker_embeddings=True, gpt_like_decoder_conditioning=True)
+
+    @property
+    def device(self):
+        return "cuda"
+
+    @property
+    def dtype(self):
+        return "float32"
+
+    def get_memory_usage_curve(self):
+        """KV blocks per concurrent sequence (replaces the vLLM gpu_memory_utilization heuristic, XTTSv2.py:152-171)."""
+        s = self.native.stats()
+        per_seq_mb = 66 * 2 * 16 * 16 * 64 * 4 * self.native.n_layer / 2 ** 20
+        return {"kv_mb_per_sequence": per_seq_mb, "kv_blocks_total": s.get("kv_blocks_total", 0)}
+
+    # ------------------------------------------------------------------ conditioning
+    async def get_audio_conditioning(self, audio_reference, max_ref_length=30, gpt_cond_len=6, gpt_cond_chunk_len=6,
+                                     librosa_trim_db=None, sound_norm_refs=False, load_sr=22050):
+        """-> (gpt_cond_latent [1,32,1024], speaker_embedding [1,512,1]) as float32 numpy arrays."""
+        ref = audio_reference[0] if isinstance(audio_reference, (list, tuple)) and len(audio_reference) == 1 else audio_reference
+        if isinstance(ref, dict):
+            g, s = ref["gpt_cond_latent"], ref["speaker_embedding"]
+        elif isinstance(ref, (list, tuple)) and len(ref) == 2 and hasattr(ref[0], "shape"):
+            g, s = ref
+        elif isinstance(ref, str) and ref.endswith(".npz") and os.path.isfile(ref):
+            z = np.load(ref)
+            g, s = z["gpt_cond_latent"], z["speaker_embedding"]
+        else:
+            raise NotImplementedError(
+                "conditioning from reference audio (ConditioningEncoder / PerceiverResampler / ResNetSpeakerEncoder, "
+                "XTTSv2.py:409-468) is not built yet (SURVEY §8f #1): pass precomputed conditioning as an .npz path "
+                "or a dict with gpt_cond_latent [1,32,1024] and speaker_embedding [1,512,1]")
+        g = np.asarray(getattr(g, "numpy", lambda: g)(), dtype=np.float32).reshape(1, 32, 1024)
+        s = np.asarray(getattr(s, "numpy", lambda: s)(), dtype=np.float32).reshape(1, 512, 1)
+        return g, s
+
+    def _register_speaker(self, g: np.ndarray, s: np.ndarray) -> int:
+        key = int.from_bytes(hashlib.blake2b(g.tobytes() + s.tobytes(), digest_size=8).digest(), "little")
+        if key not in self._speakers:
+            self.native.set_conditioning(key, g, s)
+            self._speakers[key] = True
+        return key
+
+    # ------------------------------------------------------------------ phase 1
+    async def get_generation_context(self, request: TTSRequest, gpt_cond_latent=None, speaker_embeddings=None
+                                     ) -> Tuple[List[ChunkHandle], List[str], Any, Any]:
+        if gpt_cond_latent is None or speaker_embeddings is None:
+            gpt_cond_latent, speaker_embeddings = await self.get_audio_conditioning(
+                request.speaker_files, request.max_ref_length, request.gpt_cond_len, request.gpt_cond_chunk_len)
+        key = self._register_speaker(np.asarray(gpt_cond_latent, dtype=np.float32),
+                                     np.asarray(speaker_embeddings, dtype=np.float32))
+        chunks = self.tokenizer.batch_encode_with_split(request.text, request.language)
+        loop = asyncio.get_running_loop()
+        handles, ids = [], []
+        for idx, text_ids in enumerate(chunks):
+            if request.seed is None:
+                self._seed_counter += 1
+                seed = (hash(request.request_id) ^ self._seed_counter) & 0xFFFFFFFF
+            else:
+                seed = (request.seed + idx) & 0xFFFFFFFF
+            fut = self.driver.submit(loop, text_ids=text_ids, speaker_key=key, temperature=request.temperature,
+                                     top_p=request.top_p, top_k=request.top_k,
+                                     repetition_penalty=request.repetition_penalty,
+                                     max_tokens=self.gpt_max_audio_tokens, seed=seed)
+            rid = f"{request.request_id}_{idx}"
+            handles.append(ChunkHandle(fut, rid, len(text_ids)))
+            ids.append(rid)
+        return handles, ids, speaker_embeddings, gpt_cond_latent
+
+    # ------------------------------------------------------------------ phase 2
+    async def process_tokens_to_speech(self, generator: ChunkHandle, speaker_embeddings=None, multimodal_data=None,
+                                       request: Optional[TTSRequest] = None) -> AsyncGenerator[TTSOutput, None]:
+        assert speaker_embeddings is not None, "Speaker embeddings must be provided for speech generation with XTTSv2."
+        item = await generator.future
+        yield TTSOutput(array=item["wav"], sample_rate=24000,
+                        start_time=request.start_time if request is not None else None,
+                        token_length=int(len(item["tokens"])))
+
+    async def shutdown(self):
+        self.driver.shutdown()
+        close = getattr(self.native, "close", None)
+        if close:
+            close()
+
+
+register_model("xtts", XTTSv2Engine)

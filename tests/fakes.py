@@ -1,0 +1,53 @@
+"""Test doubles (CPU): a stand-in for NativeEngine with the same submit/step/poll surface and deterministic output."""
+import numpy as np
+
+
+class FakeNativeEngine:
+    n_layer = 1
+
+    def __init__(self, max_seqs=4, fail_on_step=None):
+        self.max_seqs = max_seqs
+        self.next_id = 1
+        self.waiting, self.running, self.done = [], [], []
+        self.speakers = {}
+        self.submitted = []
+        self.fail_on_step = fail_on_step
+        self.steps = 0
+
+    def set_conditioning(self, key, g, s):
+        self.speakers[key] = (np.array(g), np.array(s))
+
+    def submit(self, text_ids, speaker_key, temperature=0.75, top_p=0.85, top_k=50, repetition_penalty=5.0,
+               max_tokens=605, seed=0, ignore_stop=False):
+        assert speaker_key in self.speakers
+        sid = self.next_id
+        self.next_id += 1
+        n_steps = 1 + (sum(text_ids) % 5)          # finish out of submission order
+        self.waiting.append({"seq_id": sid, "ids": list(text_ids), "left": n_steps, "seed": seed})
+        self.submitted.append({"seq_id": sid, "text_ids": list(text_ids), "temperature": temperature, "seed": seed})
+        return sid
+
+    def step(self):
+        self.steps += 1
+        if self.fail_on_step is not None and self.steps >= self.fail_on_step:
+            raise RuntimeError("injected engine failure")
+        while self.waiting and len(self.running) < self.max_seqs:
+            self.running.append(self.waiting.pop(0))
+        for s in list(self.running):
+            s["left"] -= 1
+            if s["left"] <= 0:
+                self.running.remove(s)
+                n = len(s["ids"])
+                wav = np.full(n * 10, float(s["seq_id"]), dtype=np.float32)
+                self.done.append({"seq_id": s["seq_id"], "tokens": np.arange(n, dtype=np.int32), "wav": wav, "error": 0})
+        return len(self.waiting) + len(self.running), 0
+
+    def poll(self, cap=64, want_latents=True):
+        out, self.done = self.done, []
+        return out
+
+    def stats(self):
+        return {"kv_blocks_total": 0}
+
+    def close(self):
+        pass

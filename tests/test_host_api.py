@@ -1,0 +1,182 @@
+"""CPU: host-side mirror of the reference surface (TTSRequest / TTSOutput / scheduler / TTS facade / plugin API)
+against a fake engine — ordering, streaming, error propagation, 100k-char split (SURVEY §7 test list)."""
+import asyncio
+import os
+
+import numpy as np
+import pytest
+
+from auralis_amd import MODEL_REGISTRY, TTS, TTSOutput, TTSRequest
+from auralis_amd.api.driver import EngineDriver
+from auralis_amd.api.scheduler import TwoPhaseScheduler
+from auralis_amd.api.text import CHAR_LIMITS, XTTSTokenizer, split_sentence
+from auralis_amd.api.xtts_engine import XTTSv2Engine
+from tests.fakes import FakeNativeEngine
+
+COND = {"gpt_cond_latent": np.zeros((1, 32, 1024), np.float32), "speaker_embedding": np.ones((1, 512, 1), np.float32)}
+PARA = ("The quick brown fox jumps over the lazy dog near the river bank. It was a bright cold day in April, and the "
+        "clocks were striking thirteen! Who would have thought that such a thing could happen? Nobody, really; yet "
+        "here we are, walking slowly along the old road, counting the stones and the years that went by.")
+
+
+def test_request_defaults_match_reference():
+    r = TTSRequest(text="hello there, this is the test", speaker_files=["x.wav"])
+    assert (r.temperature, r.top_p, r.top_k, r.repetition_penalty) == (0.75, 0.85, 50, 5.0)
+    assert (r.max_ref_length, r.gpt_cond_len, r.gpt_cond_chunk_len, r.stream) == (60, 30, 4, False)
+    assert r.language == "en" and len(r.request_id) == 32
+
+
+@pytest.mark.parametrize("text,lang", [
+    ("Il était une fois dans une ville que nous ne connaissons pas, un homme qui avait des idées.", "fr"),
+    ("Es war einmal ein Mann, der nicht mit dem Zug fahren wollte und auch nicht zu Fuß gehen konnte.", "de"),
+    ("It was the best of times and it was the worst of times for all of them.", "en"),
+    ("Это было лучшее из времён", "ru"), ("这是一个测试", "zh-cn")])
+def test_language_autodetect(text, lang):
+    assert TTSRequest(text=text, speaker_files="x").language == lang
+
+
+def test_invalid_language_rejected():
+    with pytest.raises(ValueError):
+        TTSRequest(text="hi", speaker_files="x", language="xx")
+
+
+def test_output_roundtrip_and_transforms(tmp_path):
+    t = np.linspace(0, 1, 24000, dtype=np.float32)
+    o = TTSOutput(array=0.5 * np.sin(2 * np.pi * 440 * t))
+    assert o.get_info() == (24000, 24000, 1.0)
+    p = tmp_path / "a.wav"
+    o.save(p)
+    back = TTSOutput.from_file(p)
+    assert back.sample_rate == 24000 and np.abs(back.array - o.array).max() < 1e-4
+    assert len(o.resample(16000).array) == 16000
+    assert len(o.to_bytes("pcm")) == 48000
+    fast = o.change_speed(1.25)
+    assert abs(len(fast.array) - 24000 / 1.25) < 2500 and np.abs(fast.array).max() <= 1.0
+    both = TTSOutput.combine_outputs([o, o])
+    assert len(both.array) == 48000
+    with pytest.raises(ValueError):
+        o.to_bytes("mp3")
+
+
+def test_split_sentence_respects_limit_and_keeps_words():
+    text = " ".join([PARA] * 6)
+    for lang in ("en", "fr", "de"):
+        chunks = split_sentence(text, lang, CHAR_LIMITS[lang])
+        assert all(0 < len(c) <= CHAR_LIMITS[lang] for c in chunks)
+        assert "".join("".join(chunks).split()).replace(".", "") == "".join(text.split()).replace(".", "")
+    assert split_sentence("short text.", "en") == ["short text."]
+
+
+def test_tokenizer_contract():
+    tok = XTTSTokenizer(None, vocab_size=6681)
+    ids = tok.encode_chunk("Hello world", "en")
+    assert ids[0] == tok.bos_token_id and ids[-1] == tok.eos_token_id
+    assert all(0 <= i < 6681 for i in ids) and ids == tok.encode_chunk("Hello world", "en")
+    assert len(tok.batch_encode_with_split(" ".join([PARA] * 3), "en")) >= 3
+
+
+def test_split_requests_100k():
+    r = TTSRequest(text="a" * 250000, speaker_files="x", language="en")
+    subs = TTS.split_requests(r)
+    assert [len(s.text) for s in subs] == [100000, 100000, 50000]
+    assert len({s.request_id for s in subs}) == 3 and TTS.split_requests(TTSRequest(text="hi", speaker_files="x")) != []
+
+
+def test_scheduler_orders_outputs_and_propagates_errors():
+    async def first(inp):
+        return {"parallel_inputs": [{"i": i, "delay": d} for i, d in enumerate(inp)]}
+
+    async def second(g):
+        await asyncio.sleep(g["delay"])
+        if g["delay"] < 0:
+            raise RuntimeError("boom")
+        yield g["i"]
+
+    async def main():
+        s = TwoPhaseScheduler(second_phase_concurrency=2)
+        got = [x async for x in s.run([0.05, 0.0, 0.02, 0.0], first, second, "r")]
+        assert got == [0, 1, 2, 3]
+        with pytest.raises(RuntimeError):
+            async def bad(g):
+                raise RuntimeError("boom")
+                yield 0
+            [x async for x in s.run([0.0, 0.0], first, bad, "r2")]
+    asyncio.run(main())
+
+
+def test_driver_resolves_futures_and_fails_loudly():
+    async def main():
+        eng = FakeNativeEngine()
+        eng.set_conditioning(1, COND["gpt_cond_latent"], COND["speaker_embedding"])
+        d = EngineDriver(eng)
+        loop = asyncio.get_running_loop()
+        futs = [d.submit(loop, text_ids=[5, i, 7], speaker_key=1) for i in range(6)]
+        res = await asyncio.gather(*futs)
+        assert [r["seq_id"] for r in res] == [1, 2, 3, 4, 5, 6]
+        d.shutdown()
+        bad = FakeNativeEngine(fail_on_step=2)
+        bad.set_conditioning(1, COND["gpt_cond_latent"], COND["speaker_embedding"])
+        d2 = EngineDriver(bad)
+        f = d2.submit(loop, text_ids=[4, 4, 4, 4], speaker_key=1)
+        with pytest.raises(RuntimeError):
+            await f
+        d2.shutdown()
+    asyncio.run(main())
+
+
+def _tts(fake=None):
+    fake = fake or FakeNativeEngine(max_seqs=3)
+    eng = XTTSv2Engine(fake, XTTSTokenizer(None), max_concurrency=3)
+    return TTS(scheduler_max_concurrency=3).with_engine(eng), fake
+
+
+def test_generate_speech_combines_chunks_in_order():
+    tts, fake = _tts()
+    try:
+        text = " ".join([PARA] * 4)
+        out = tts.generate_speech(TTSRequest(text=text, speaker_files=[COND], language="en", seed=3))
+        n_chunks = len(fake.submitted)
+        assert n_chunks >= 4 and isinstance(out, TTSOutput)
+        # fake wav is constant = seq_id per chunk; combined audio must be in submission (= chunk) order
+        marks = [float(v) for v in out.array[np.r_[True, np.diff(out.array) != 0]]]
+        assert marks == [float(i + 1) for i in range(n_chunks)]
+        assert [s["seed"] for s in fake.submitted] == [3 + i for i in range(n_chunks)]
+        assert out.sample_rate == 24000
+    finally:
+        tts.close()
+
+
+def test_generate_speech_streaming_yields_per_chunk():
+    tts, fake = _tts()
+    try:
+        gen = tts.generate_speech(TTSRequest(text=" ".join([PARA] * 3), speaker_files=[COND], language="en", stream=True))
+        outs = list(gen)
+        assert len(outs) == len(fake.submitted) >= 3
+        assert [float(o.array[0]) for o in outs] == [float(i + 1) for i in range(len(outs))]
+        assert all(o.token_length and o.start_time for o in outs)
+    finally:
+        tts.close()
+
+
+def test_engine_failure_reaches_caller():
+    tts, _ = _tts(FakeNativeEngine(fail_on_step=1))
+    try:
+        with pytest.raises(RuntimeError):
+            tts.generate_speech(TTSRequest(text=PARA, speaker_files=[COND], language="en"))
+    finally:
+        tts.close()
+
+
+def test_audio_reference_files_not_silently_accepted():
+    tts, _ = _tts()
+    try:
+        with pytest.raises(NotImplementedError):
+            tts.generate_speech(TTSRequest(text="hello", speaker_files=["female.wav"], language="en"))
+    finally:
+        tts.close()
+
+
+def test_registry_and_from_pretrained_errors(tmp_path):
+    assert MODEL_REGISTRY["xtts"] is XTTSv2Engine
+    with pytest.raises(FileNotFoundError):
+        TTS().from_pretrained(str(tmp_path))

@@ -1,0 +1,58 @@
+"""CPU: the N>1 path (utterance sharding + the single conditioning broadcast) with world_size 2 over gloo."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from auralis_amd.parallel import PAYLOAD_BYTES, broadcast_conditioning, merge_ordered, shard_units
+from tests.fakes import FakeNativeEngine
+
+
+def test_payload_size_matches_survey():
+    assert PAYLOAD_BYTES == 133120
+
+
+def test_shard_units_partitions_everything():
+    for n, world in ((512, 8), (1900, 8), (64, 1), (10, 4), (130, 2)):
+        seen = []
+        for r in range(world):
+            seen += shard_units(n, world, r, per_gpu_batch=64)
+        assert sorted(seen) == list(range(n))
+    assert [len(shard_units(512, 8, r)) for r in range(8)] == [64] * 8      # BASELINE config 4
+
+
+def test_merge_ordered():
+    assert merge_ordered([[(2, "c"), (0, "a")], [(1, "b")]]) == [(0, "a"), (1, "b"), (2, "c")]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = FakeNativeEngine()
+    g = torch.arange(32 * 1024, dtype=torch.float32).reshape(1, 32, 1024) if rank == 0 else None
+    s = torch.linspace(0, 1, 512).reshape(1, 512, 1) if rank == 0 else None
+    broadcast_conditioning(eng, 7, g, s, src=0)
+    got_g, got_s = eng.speakers[7]
+    # every rank then works on its own shard; results are gathered only to check the ordering helper
+    mine = [(i, f"r{rank}") for i in shard_units(10, world, rank, per_gpu_batch=2)]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), g=got_g, s=got_s,
+             order=np.array([i for i, _ in merge_ordered(gathered)]))
+    dist.destroy_process_group()
+
+
+def test_broadcast_conditioning_gloo_world2(tmp_path):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        z = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(z["g"].reshape(-1), np.arange(32 * 1024, dtype=np.float32))
+        assert np.allclose(z["s"].reshape(-1), np.linspace(0, 1, 512, dtype=np.float32))
+        assert z["order"].tolist() == list(range(10))
