@@ -27,8 +27,28 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float ws[CK * KS][MT];
 
     const int b = blockIdx.z;
-    const int mtile = blockIdx.y;
-    const int q0 = blockIdx.x * NT;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest), so the
+    // gridDim.y co-tiles that read the SAME input window are mapped to ids that are 8 apart => same XCD/L2, adjacent
+    // in time.  Pure speed choice; any mapping is correct.
+    int mtile, ttile;
+    {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int L = blockIdx.x + gx * blockIdx.y;
+        const int g8 = (gx / 8) * 8;
+        if (gy == 1) {
+            mtile = 0;
+            ttile = L;
+        } else if (L < g8 * gy) {
+            const int xcd = L & 7, slot = L >> 3;
+            mtile = slot % gy;
+            ttile = (slot / gy) * 8 + xcd;
+        } else {
+            const int r = L - g8 * gy;
+            mtile = r % gy;
+            ttile = g8 + r / gy;
+        }
+    }
+    const int q0 = ttile * NT;
     const int len_in = a.base_len[b] * a.len_mul;
     const int n_q = a.ups_s ? len_in + 1 : len_in;   // polyphase needs q == len_in for the tail phases
     if (q0 >= n_q) return;
@@ -53,23 +73,44 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
 
     for (int ci0 = 0; ci0 < a.Cin; ci0 += CK) {
         __syncthreads();   // previous chunk fully consumed
-        // ---- stage activated, masked input window
-#pragma unroll 1
-        for (int c = 0; c < CK; ++c) {
-            const float* xr = xb + (long)(ci0 + c) * a.x_stride;
-            for (int i = tid; i < XROW; i += 256) {
-                const int t = q0 - a.padl + i;
-                float v = 0.f;
-                if (t >= 0 && t < len_in) v = xr[t];
-                xs[c][i] = lrelu(v, slope);
-            }
-        }
-        // ---- stage packed weights (contiguous CK*KS*MT floats)
+        // ---- stage activated, masked input window + packed weights: every global load of the chunk is issued
+        // before the first LDS store (one memory round trip per chunk instead of one per channel row)
         {
-            const float4* src = wsrc_tile + (long)ci0 * KS * MT / 4;
-            float4* dst = reinterpret_cast<float4*>(&ws[0][0]);
+            constexpr int XI = (XROW + 255) / 256;
             constexpr int N4 = CK * KS * MT / 4;
-            for (int i = tid; i < N4; i += 256) dst[i] = src[i];
+            constexpr int WI = (N4 + 255) / 256;
+            float xv[CK][XI];
+            float4 wv4[WI];
+            const float4* src = wsrc_tile + (long)ci0 * KS * MT / 4;
+#pragma unroll
+            for (int c = 0; c < CK; ++c) {
+                const float* xr = xb + (long)(ci0 + c) * a.x_stride;
+#pragma unroll
+                for (int it = 0; it < XI; ++it) {
+                    const int i = tid + it * 256;
+                    const int t = q0 - a.padl + i;
+                    xv[c][it] = (i < XROW && t >= 0 && t < len_in) ? xr[t] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < WI; ++it) {
+                const int i = tid + it * 256;
+                wv4[it] = (i < N4) ? src[i] : float4{0.f, 0.f, 0.f, 0.f};
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep every load above, every LDS store below (hipcc sinks loads)
+#pragma unroll
+            for (int c = 0; c < CK; ++c)
+#pragma unroll
+                for (int it = 0; it < XI; ++it) {
+                    const int i = tid + it * 256;
+                    if (i < XROW) xs[c][i] = lrelu(xv[c][it], slope);
+                }
+            float4* dst = reinterpret_cast<float4*>(&ws[0][0]);
+#pragma unroll
+            for (int it = 0; it < WI; ++it) {
+                const int i = tid + it * 256;
+                if (i < N4) dst[i] = wv4[it];
+            }
         }
         __syncthreads();
         // ---- MFMA over (channel pair, tap)
