@@ -16,7 +16,7 @@
 namespace aur {
 
 template <int KS, int DIL, int MT, int CK>
-__global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void conv1d_mfma_kernel(ConvArgs a) {
     constexpr int WM = MT / 32;            // 32-row tiles per wave
     constexpr int WN = (MT == 64) ? 2 : 4; // 32-col tiles per wave
     constexpr int NTW = 32 * WN;
@@ -24,7 +24,10 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
     constexpr int HALO = (KS - 1) * DIL;
     constexpr int XROW = NT + HALO;
     __shared__ __attribute__((aligned(16))) float xs[CK][XROW];
-    __shared__ __attribute__((aligned(16))) float ws[CK * KS][MT];
+    // weights: CK*KS rows of MT floats, rounded up to whole 256-thread float4 passes so the staging stores need no predicate
+    constexpr int WI_ = (CK * KS * MT / 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float ws_raw[WI_ * 1024];
+    float (*ws)[MT] = reinterpret_cast<float (*)[MT]>(ws_raw);
 
     const int b = blockIdx.z;
     // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest), so the
@@ -71,48 +74,57 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvArgs a) {
     const float slope = a.slope;
     const float4* wsrc_tile = reinterpret_cast<const float4*>(a.wp + (long)mtile * a.Cin * KS * MT);
 
-    for (int ci0 = 0; ci0 < a.Cin; ci0 += CK) {
-        __syncthreads();   // previous chunk fully consumed
-        // ---- stage activated, masked input window + packed weights: every global load of the chunk is issued
-        // before the first LDS store (one memory round trip per chunk instead of one per channel row)
-        {
-            constexpr int XI = (XROW + 255) / 256;
-            constexpr int N4 = CK * KS * MT / 4;
-            constexpr int WI = (N4 + 255) / 256;
-            float xv[CK][XI];
-            float4 wv4[WI];
-            const float4* src = wsrc_tile + (long)ci0 * KS * MT / 4;
+    // Software pipeline over channel chunks: the global loads of chunk i+1 are issued before the MFMA loop of chunk i
+    // and parked in registers; they are written to LDS after the loop (single LDS buffer, two barriers per chunk).
+    constexpr int XI = (XROW + 255) / 256;
+    constexpr int N4 = CK * KS * MT / 4;
+    constexpr int WI = (N4 + 255) / 256;
+    float xv[CK][XI];
+    // two half-size register arrays: hipcc left a 6-entry float4 array in scratch (112 B) for the k=11 kernels
+    constexpr int WH = (WI + 1) / 2;
+    float4 wva[WH], wvb[WH];
+    auto load_chunk = [&](int ci0) {
+        const float4* src = wsrc_tile + (long)ci0 * KS * MT / 4;
 #pragma unroll
-            for (int c = 0; c < CK; ++c) {
-                const float* xr = xb + (long)(ci0 + c) * a.x_stride;
+        for (int c = 0; c < CK; ++c) {
+            const float* xr = xb + (long)(ci0 + c) * a.x_stride;
 #pragma unroll
-                for (int it = 0; it < XI; ++it) {
-                    const int i = tid + it * 256;
-                    const int t = q0 - a.padl + i;
-                    xv[c][it] = (i < XROW && t >= 0 && t < len_in) ? xr[t] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < WI; ++it) {
-                const int i = tid + it * 256;
-                wv4[it] = (i < N4) ? src[i] : float4{0.f, 0.f, 0.f, 0.f};
-            }
-            __builtin_amdgcn_sched_barrier(0);   // keep every load above, every LDS store below (hipcc sinks loads)
-#pragma unroll
-            for (int c = 0; c < CK; ++c)
-#pragma unroll
-                for (int it = 0; it < XI; ++it) {
-                    const int i = tid + it * 256;
-                    if (i < XROW) xs[c][i] = lrelu(xv[c][it], slope);
-                }
-            float4* dst = reinterpret_cast<float4*>(&ws[0][0]);
-#pragma unroll
-            for (int it = 0; it < WI; ++it) {
-                const int i = tid + it * 256;
-                if (i < N4) dst[i] = wv4[it];
+            for (int it = 0; it < XI; ++it) {
+                // unconditional loads (clamped address): a predicated load makes hipcc drain vmcnt(0) in the middle
+                // of the prefetch block; masking happens when the value is written to LDS
+                const int t = q0 - a.padl + tid + it * 256;
+                xv[c][it] = xr[min(max(t, 0), len_in - 1)];
             }
         }
+#pragma unroll
+        for (int it = 0; it < WH; ++it) wva[it] = src[min(tid + it * 256, N4 - 1)];
+#pragma unroll
+        for (int it = WH; it < WI; ++it) wvb[it - WH] = src[min(tid + it * 256, N4 - 1)];
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int c = 0; c < CK; ++c)
+#pragma unroll
+            for (int it = 0; it < XI; ++it) {
+                const int i = tid + it * 256;
+                const int t = q0 - a.padl + i;
+                if (i < XROW) xs[c][i] = (t >= 0 && t < len_in) ? lrelu(xv[c][it], slope) : 0.f;
+            }
+        float4* dst = reinterpret_cast<float4*>(ws_raw);
+#pragma unroll
+        for (int it = 0; it < WH; ++it) dst[tid + it * 256] = wva[it];
+#pragma unroll
+        for (int it = WH; it < WI; ++it) dst[tid + it * 256] = wvb[it - WH];
+    };
+
+    load_chunk(0);
+    for (int ci0 = 0; ci0 < a.Cin; ci0 += CK) {
+        __builtin_amdgcn_sched_barrier(0);   // loads stay above, LDS stores below (hipcc sinks loads otherwise)
+        __syncthreads();                     // previous chunk fully consumed
+        store_chunk();
         __syncthreads();
+        if (ci0 + CK < a.Cin) load_chunk(ci0 + CK);
+        __builtin_amdgcn_sched_barrier(0);   // prefetch is in flight before the first MFMA
         // ---- MFMA over (channel pair, tap)
 #pragma unroll 2
         for (int cc = 0; cc < CK; cc += 2) {
@@ -205,9 +217,9 @@ void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
         case 7 * 16 + 1: launch_conv_mt<7, 1, 8>(a, st); break;
         case 7 * 16 + 3: launch_conv_mt<7, 3, 8>(a, st); break;
         case 7 * 16 + 5: launch_conv_mt<7, 5, 8>(a, st); break;
-        case 11 * 16 + 1: launch_conv_mt<11, 1, 8>(a, st); break;
-        case 11 * 16 + 3: launch_conv_mt<11, 3, 8>(a, st); break;
-        case 11 * 16 + 5: launch_conv_mt<11, 5, 8>(a, st); break;
+        case 11 * 16 + 1: launch_conv_mt<11, 1, 4>(a, st); break;
+        case 11 * 16 + 3: launch_conv_mt<11, 3, 4>(a, st); break;
+        case 11 * 16 + 5: launch_conv_mt<11, 5, 4>(a, st); break;
         default: throw HipError("launch_conv1d: unsupported (kernel,dilation)");
     }
     HIP_CHECK(hipGetLastError());
