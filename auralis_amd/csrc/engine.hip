@@ -107,6 +107,16 @@ __global__ __launch_bounds__(256) void init_slots_kernel(const SlotInit* __restr
     }
 }
 
+// Row workspace of one GPT forward chain (prefill uses chain 0; decode can run two chains on two streams).
+struct RowWs {
+    hipStream_t st = nullptr;
+    int rows_cap = 0;
+    DevBuf h, xn, qbuf, att, act, P, P2, ybuf;
+    DevBuf i_row_slot, i_row_pos, i_desc, i_sample_row, i_sample_slot, i_next_kvpos, i_out_tok;
+    PinBuf pin;
+    std::vector<int> sample_row, sample_slot;
+};
+
 enum class SeqState { WAITING, RUNNING, TOKENS_DONE, DONE, RELEASED };
 
 struct Seq {
@@ -121,6 +131,7 @@ struct Seq {
     std::vector<int32_t> tokens;
     std::vector<float> wav;
     std::vector<float> latents;
+    int pool_idx = -1;   // latent-pool entry once the tokens are done (vocoder stage)
     int error = 0;
 };
 
@@ -161,7 +172,17 @@ public:
         HIP_CHECK(hipMemsetAsync(zero_bias_.p, 0, 4096 * sizeof(float), st_));
         h_block_tables_.assign((size_t)S * kMaxBlocks, 0);
         slot_owner_.assign(S, nullptr);
-        pin_.ensure(((size_t)S * 2 + 16) * sizeof(int));
+        HIP_CHECK(hipStreamCreateWithFlags(&st2_, hipStreamDefault));
+        HIP_CHECK(hipStreamCreateWithFlags(&st_voc_, hipStreamDefault));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_lat_, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ev_voc_done_, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(ev_lat_, st_));
+        latpool_.ensure((size_t)2 * S * kMaxLatRows * kHidden * sizeof(float));
+        for (int i = 2 * S - 1; i >= 0; --i) latpool_free_.push_back(i);
+        HIP_CHECK(hipEventCreate(&ev_ws1_));
+        ws_[0].st = st_;
+        ws_[1].st = st2_;
+        if (const char* e = getenv("AUR_DECODE_STREAMS")) decode_streams_ = atoi(e);
         HIP_CHECK(hipEventCreate(&ev_a_));
         HIP_CHECK(hipEventCreate(&ev_b_));
         HIP_CHECK(hipStreamSynchronize(st_));
@@ -169,12 +190,18 @@ public:
     ~Engine() {
         (void)hipSetDevice(device_);
         (void)hipStreamSynchronize(st_);
+        (void)hipStreamSynchronize(st_voc_);
         for (auto& e : conv_events_) {
             (void)hipEventDestroy(e.a);
             (void)hipEventDestroy(e.b);
         }
         (void)hipEventDestroy(ev_a_);
         (void)hipEventDestroy(ev_b_);
+        (void)hipEventDestroy(ev_ws1_);
+        (void)hipEventDestroy(ev_lat_);
+        (void)hipEventDestroy(ev_voc_done_);
+        (void)hipStreamDestroy(st_voc_);
+        (void)hipStreamDestroy(st2_);
         (void)hipStreamDestroy(st_);
     }
 
@@ -289,6 +316,15 @@ public:
         use();
         ensure_gpt();
         bool worked = false;
+        // back-pressure: every running sequence must be able to park its latents when it finishes
+        while ((int)latpool_free_.size() < cfg_.max_seqs) {
+            if (voc_active_)
+                voc_poll(true);
+            else if (!voc_queue_.empty())
+                voc_launch();
+            else
+                break;
+        }
         // 1. admission + prefill
         std::vector<Seq*> admitted;
         {
@@ -338,25 +374,28 @@ public:
             stats_.gpt_ms += ms;
             stats_.steps++;
         }
-        // 3. vocode what finished
-        std::vector<Seq*> ready;
+        // 3. vocoder stage (asynchronous): finished sequences left their slots already (latents parked in the pool);
+        //    one vocoder batch is in flight on its own stream while the next GPT steps run on the main stream.
+        voc_poll(false);
         int running = 0;
-        for (int i = 0; i < cfg_.max_seqs; ++i) {
-            Seq* s = slot_owner_[i];
-            if (!s) continue;
-            if (s->state == SeqState::TOKENS_DONE) ready.push_back(s);
-            if (s->state == SeqState::RUNNING) ++running;
-        }
+        for (int i = 0; i < cfg_.max_seqs; ++i)
+            if (slot_owner_[i]) ++running;
         size_t n_wait;
         {
             std::lock_guard<std::mutex> lk(mu_);
             n_wait = waiting_.size();
         }
         const int minb = std::max(1, cfg_.vocoder_min_batch);
-        if (!ready.empty() && ((int)ready.size() >= minb || (running == 0 && n_wait == 0))) vocode_finished(ready);
+        if (!voc_active_ && !voc_queue_.empty() && ((int)voc_queue_.size() >= minb || (running == 0 && n_wait == 0)))
+            voc_launch();
+        if (running == 0 && n_wait == 0 && voc_active_) voc_poll(true);   // nothing else to do: wait for the batch
+        if (running == 0 && n_wait == 0 && !voc_active_ && !voc_queue_.empty()) {
+            voc_launch();
+            voc_poll(true);
+        }
         {
             std::lock_guard<std::mutex> lk(mu_);
-            int live = (int)waiting_.size();
+            int live = (int)waiting_.size() + (int)voc_queue_.size() + (voc_active_ ? (int)voc_batch_.size() : 0);
             for (int i = 0; i < cfg_.max_seqs; ++i)
                 if (slot_owner_[i]) ++live;
             if (n_live) *n_live = live;
@@ -372,6 +411,7 @@ public:
         const int row = speaker_row(key, false);
         AUR_REQUIRE(row >= 0, "unknown speaker_key");
         AUR_REQUIRE(B >= 1 && t_max >= 1, "B, t_max");
+        AUR_REQUIRE(!voc_active_, "vocoder stage busy");
         std::vector<int> nl(n_lat, n_lat + B), cond(B, row);
         int max_samples = 0;
         for (int b = 0; b < B; ++b) {
@@ -381,11 +421,11 @@ public:
         AUR_REQUIRE(wav_stride >= max_samples, "wav_stride too small");
         tmp_lat_.ensure((size_t)B * t_max * kHidden * sizeof(float));
         HIP_CHECK(hipMemcpyAsync(tmp_lat_.p, latents, (size_t)B * t_max * kHidden * sizeof(float),
-                                 hipMemcpyHostToDevice, st_));
+                                 hipMemcpyHostToDevice, st_voc_));
         tmp_wav_.ensure((size_t)B * max_samples * sizeof(float));
         run_vocoder(B, nl, tmp_lat_.as<float>(), (long)t_max * kHidden, nullptr, cond, tmp_wav_.as<float>(),
                     max_samples);
-        HIP_CHECK(hipStreamSynchronize(st_));
+        HIP_CHECK(hipStreamSynchronize(st_voc_));
         collect_conv_events();
         for (int b = 0; b < B; ++b) {
             const int ns = frames_for(nl[b]) * 256;
@@ -398,6 +438,7 @@ public:
     void sync() {
         use();
         HIP_CHECK(hipStreamSynchronize(st_));
+        HIP_CHECK(hipStreamSynchronize(st_voc_));
     }
     aur_stats stats() {
         std::lock_guard<std::mutex> lk(mu_);
@@ -504,6 +545,7 @@ public:
         dbg_capture_ = true;
         step(nullptr, nullptr);
         dbg_capture_ = false;
+        for (int guard = 0; guard < 1000 && seqs_.at(id)->state != SeqState::DONE; ++guard) step(nullptr, nullptr);
         Seq* s = seqs_.at(id).get();
         if (lnf_rows_out)
             HIP_CHECK(hipMemcpy(lnf_rows_out, dbg_lnf_.p, (size_t)s->n_prompt * kHidden * 4, hipMemcpyDeviceToHost));
@@ -535,13 +577,14 @@ public:
         DevBuf dl;
         dl.ensure((size_t)B * kMelVocab * 4);
         HIP_CHECK(hipMemcpyAsync(dl.p, logits, (size_t)B * kMelVocab * 4, hipMemcpyHostToDevice, st_));
-        i_sample_slot_.ensure(B * 4);
-        i_out_tok_.ensure(B * 4);
-        HIP_CHECK(hipMemcpyAsync(i_sample_slot_.p, slots.data(), B * 4, hipMemcpyHostToDevice, st_));
-        SamplerArgs a = sampler_args(dl.as<float>(), 1, B, kMelVocab, zero_bias_.as<float>(), nullptr);
+        RowWs& w = ws_[0];
+        w.i_sample_slot.ensure(B * 4);
+        w.i_out_tok.ensure(B * 4);
+        HIP_CHECK(hipMemcpyAsync(w.i_sample_slot.p, slots.data(), B * 4, hipMemcpyHostToDevice, st_));
+        SamplerArgs a = sampler_args(w, dl.as<float>(), 1, B, kMelVocab, zero_bias_.as<float>(), nullptr);
         launch_sampler(a, st_);
         HIP_CHECK(hipStreamSynchronize(st_));
-        HIP_CHECK(hipMemcpy(tokens_out, i_out_tok_.p, B * 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(tokens_out, w.i_out_tok.p, B * 4, hipMemcpyDeviceToHost));
     }
 
 private:
@@ -554,7 +597,7 @@ private:
 
     bool idle() {
         std::lock_guard<std::mutex> lk(mu_);
-        if (!waiting_.empty()) return false;
+        if (!waiting_.empty() || !voc_queue_.empty() || voc_active_) return false;
         for (auto* s : slot_owner_)
             if (s) return false;
         return true;
@@ -594,51 +637,51 @@ private:
         ensure_voc();
         gpt_ready_ = true;
     }
-    void ensure_rows(int M) {
-        if (M <= rows_cap_) return;
+    void ensure_rows(RowWs& w, int M) {
+        if (M <= w.rows_cap) return;
         const int cap = std::max(M, 64);
-        h_.ensure((size_t)cap * kHidden * 4);
-        xn_.ensure((size_t)cap * kHidden * 4);
-        qbuf_.ensure((size_t)cap * kHidden * 4);
-        att_.ensure((size_t)cap * kHidden * 4);
-        act_.ensure((size_t)cap * 4 * kHidden * 4);
+        w.h.ensure((size_t)cap * kHidden * 4);
+        w.xn.ensure((size_t)cap * kHidden * 4);
+        w.qbuf.ensure((size_t)cap * kHidden * 4);
+        w.att.ensure((size_t)cap * kHidden * 4);
+        w.act.ensure((size_t)cap * 4 * kHidden * 4);
         // slabs: small M uses split-K (<=16 slabs of M x 1024 or 4 slabs of M x 4096), large M one slab
         const size_t slab = std::max((size_t)16 * std::min(cap, 128) * 4096, (size_t)cap * 4096);
-        P_.ensure(slab * 4);
-        i_row_slot_.ensure((size_t)cap * 4);
-        i_row_pos_.ensure((size_t)cap * 4);
-        i_desc_.ensure((size_t)cap * sizeof(int4));
-        rows_cap_ = cap;
+        w.P.ensure(slab * 4);
+        w.i_row_slot.ensure((size_t)cap * 4);
+        w.i_row_pos.ensure((size_t)cap * 4);
+        w.i_desc.ensure((size_t)cap * sizeof(int4));
+        w.rows_cap = cap;
     }
-    void forward_rows(int M, const int* d_row_slot, const int* d_row_pos) {
-        float* h = h_.as<float>();
-        float* xn = xn_.as<float>();
-        float* P = P_.as<float>();
+    void forward_rows(RowWs& w, int M, const int* d_row_slot, const int* d_row_pos) {
+        float* h = w.h.as<float>();
+        float* xn = w.xn.as<float>();
+        float* P = w.P.as<float>();
         const int* bt = block_tables_.as<int>();
         const int* kvpos = slot_kvpos_.as<int>();
-        launch_rows_ln(nullptr, 0, nullptr, h, layers_[0].ln1w, layers_[0].ln1b, xn, M, 1e-5f, st_);
+        launch_rows_ln(nullptr, 0, nullptr, h, layers_[0].ln1w, layers_[0].ln1b, xn, M, 1e-5f, w.st);
         const GemmPlan p1 = gemm_plan(M, kHidden), p4 = gemm_plan(M, 4 * kHidden);
         const int S1 = p1.slabs, S4 = p4.slabs;
         for (int l = 0; l < cfg_.n_layer; ++l) {
             const LayerW& L = layers_[l];
             float* kvl = kv_.as<float>() + (long)l * kv_layer_stride_;
-            launch_gemm_splitk(xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, p1, st_);
-            launch_qkv_epilogue(P, S1, L.bqkv, qbuf_.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, st_);
-            launch_paged_attention(qbuf_.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, att_.as<float>(), M, st_);
-            launch_gemm_splitk(att_.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, p1, st_);
-            launch_rows_ln(P, S1, L.bproj, h, L.ln2w, L.ln2b, xn, M, 1e-5f, st_);
-            launch_gemm_splitk(xn, kHidden, L.wfc, P, M, 4 * kHidden, kHidden, p1, st_);
-            launch_bias_gelu(P, S1, L.bfc, act_.as<float>(), M, 4 * kHidden, st_);
-            launch_gemm_splitk(act_.as<float>(), 4 * kHidden, L.wproj2, P, M, kHidden, 4 * kHidden, p4, st_);
+            launch_gemm_splitk(xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, p1, w.st);
+            launch_qkv_epilogue(P, S1, L.bqkv, w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, w.st);
+            launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st);
+            launch_gemm_splitk(w.att.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, p1, w.st);
+            launch_rows_ln(P, S1, L.bproj, h, L.ln2w, L.ln2b, xn, M, 1e-5f, w.st);
+            launch_gemm_splitk(xn, kHidden, L.wfc, P, M, 4 * kHidden, kHidden, p1, w.st);
+            launch_bias_gelu(P, S1, L.bfc, w.act.as<float>(), M, 4 * kHidden, w.st);
+            launch_gemm_splitk(w.act.as<float>(), 4 * kHidden, L.wproj2, P, M, kHidden, 4 * kHidden, p4, w.st);
             const bool last = (l + 1 == cfg_.n_layer);
             launch_rows_ln(P, S4, L.bproj2, h, last ? lnfw_ : layers_[l + 1].ln1w, last ? lnfb_ : layers_[l + 1].ln1b,
-                           xn, M, 1e-5f, st_);
+                           xn, M, 1e-5f, w.st);
         }
     }
-    SamplerArgs sampler_args(const float* P, int S, int Ms, int Npad, const float* bias, const int* next_kvpos) {
+    SamplerArgs sampler_args(RowWs& w, const float* P, int S, int Ms, int Npad, const float* bias, const int* next_kvpos) {
         SamplerArgs a{};
         a.P = P; a.S = S; a.Ms = Ms; a.Npad = Npad; a.V = kMelVocab; a.bias = bias;
-        a.sample_slot = i_sample_slot_.as<int>();
+        a.sample_slot = w.i_sample_slot.as<int>();
         a.next_kvpos = next_kvpos;
         a.seen = seen_.as<unsigned char>();
         a.slot_tok = slot_tok_.as<int>(); a.slot_pos = slot_pos_.as<int>(); a.slot_kvpos = slot_kvpos_.as<int>();
@@ -646,36 +689,41 @@ private:
         a.temperature = temperature_.as<float>(); a.top_p = top_p_.as<float>(); a.top_k = top_k_.as<int>();
         a.rep_penalty = rep_.as<float>(); a.max_tokens = max_tokens_.as<int>(); a.ignore_stop = ignore_stop_.as<int>();
         a.seed = seed_.as<unsigned>();
-        a.out_tok = i_out_tok_.as<int>();
+        a.out_tok = w.i_out_tok.as<int>();
         a.dbg_logits = dbg_capture_ ? dbg_logits_.as<float>() : nullptr;
         a.stop_token = kStopToken;
         return a;
     }
     // final_norm -> latent stash -> mel_head GEMM -> fused sampler -> read back tokens/finished flags
-    void sample_rows(const std::vector<int>& sample_row, const std::vector<int>& sample_slot,
-                     const std::vector<int>* next_kvpos) {
+    void sample_launch(RowWs& w, const std::vector<int>& sample_row, const std::vector<int>& sample_slot,
+                       const std::vector<int>* next_kvpos) {
         const int Ms = (int)sample_slot.size();
-        i_sample_row_.ensure((size_t)Ms * 4);
-        i_sample_slot_.ensure((size_t)Ms * 4);
-        i_next_kvpos_.ensure((size_t)Ms * 4);
-        i_out_tok_.ensure((size_t)Ms * 4);
-        ybuf_.ensure((size_t)std::max(Ms, 64) * kHidden * 4);
-        P2_.ensure((size_t)4 * std::max(Ms, 64) * kHeadPad * 4);
-        HIP_CHECK(hipMemcpyAsync(i_sample_row_.p, sample_row.data(), (size_t)Ms * 4, hipMemcpyHostToDevice, st_));
-        HIP_CHECK(hipMemcpyAsync(i_sample_slot_.p, sample_slot.data(), (size_t)Ms * 4, hipMemcpyHostToDevice, st_));
+        w.pin.ensure(((size_t)cfg_.max_seqs * 2 + 16) * sizeof(int));
+        w.i_sample_row.ensure((size_t)Ms * 4);
+        w.i_sample_slot.ensure((size_t)Ms * 4);
+        w.i_next_kvpos.ensure((size_t)Ms * 4);
+        w.i_out_tok.ensure((size_t)Ms * 4);
+        w.ybuf.ensure((size_t)std::max(Ms, 64) * kHidden * 4);
+        w.P2.ensure((size_t)4 * std::max(Ms, 64) * kHeadPad * 4);
+        HIP_CHECK(hipMemcpyAsync(w.i_sample_row.p, sample_row.data(), (size_t)Ms * 4, hipMemcpyHostToDevice, w.st));
+        HIP_CHECK(hipMemcpyAsync(w.i_sample_slot.p, sample_slot.data(), (size_t)Ms * 4, hipMemcpyHostToDevice, w.st));
         if (next_kvpos)
-            HIP_CHECK(hipMemcpyAsync(i_next_kvpos_.p, next_kvpos->data(), (size_t)Ms * 4, hipMemcpyHostToDevice, st_));
-        launch_final_norm(xn_.as<float>(), i_sample_row_.as<int>(), i_sample_slot_.as<int>(), fnw_, fnb_, ybuf_.as<float>(),
-                          latents_.as<float>(), (long)kMaxLatRows * kHidden, slot_ngen_.as<int>(), kMaxLatRows, Ms, 1e-5f, st_);
+            HIP_CHECK(hipMemcpyAsync(w.i_next_kvpos.p, next_kvpos->data(), (size_t)Ms * 4, hipMemcpyHostToDevice, w.st));
+        launch_final_norm(w.xn.as<float>(), w.i_sample_row.as<int>(), w.i_sample_slot.as<int>(), fnw_, fnb_, w.ybuf.as<float>(),
+                          latents_.as<float>(), (long)kMaxLatRows * kHidden, slot_ngen_.as<int>(), kMaxLatRows, Ms, 1e-5f, w.st);
         const GemmPlan ph = gemm_plan(Ms, kHidden);
         const int S = ph.slabs;
-        launch_gemm_splitk(ybuf_.as<float>(), kHidden, headT_, P2_.as<float>(), Ms, kHeadPad, kHidden, ph, st_);
-        SamplerArgs a = sampler_args(P2_.as<float>(), S, Ms, kHeadPad, headb_, next_kvpos ? i_next_kvpos_.as<int>() : nullptr);
-        launch_sampler(a, st_);
-        int* pin = pin_.as<int>();
-        HIP_CHECK(hipMemcpyAsync(pin, i_out_tok_.p, (size_t)Ms * 4, hipMemcpyDeviceToHost, st_));
-        HIP_CHECK(hipMemcpyAsync(pin + cfg_.max_seqs, slot_finished_.p, (size_t)cfg_.max_seqs * 4, hipMemcpyDeviceToHost, st_));
-        HIP_CHECK(hipStreamSynchronize(st_));
+        launch_gemm_splitk(w.ybuf.as<float>(), kHidden, headT_, w.P2.as<float>(), Ms, kHeadPad, kHidden, ph, w.st);
+        SamplerArgs a = sampler_args(w, w.P2.as<float>(), S, Ms, kHeadPad, headb_, next_kvpos ? w.i_next_kvpos.as<int>() : nullptr);
+        launch_sampler(a, w.st);
+        int* pin = w.pin.as<int>();
+        HIP_CHECK(hipMemcpyAsync(pin, w.i_out_tok.p, (size_t)Ms * 4, hipMemcpyDeviceToHost, w.st));
+        HIP_CHECK(hipMemcpyAsync(pin + cfg_.max_seqs, slot_finished_.p, (size_t)cfg_.max_seqs * 4, hipMemcpyDeviceToHost, w.st));
+    }
+    // after the stream has been synchronised: append tokens, retire finished sequences
+    void sample_collect(RowWs& w, const std::vector<int>& sample_slot) {
+        const int Ms = (int)sample_slot.size();
+        const int* pin = w.pin.as<int>();
         for (int j = 0; j < Ms; ++j) {
             Seq* s = slot_owner_[sample_slot[j]];
             s->tokens.push_back(pin[j]);
@@ -685,9 +733,21 @@ private:
     }
     void finish_tokens(Seq* s) {
         s->state = SeqState::TOKENS_DONE;
+        // park the stashed latents in the pool (D2D on the main stream, ordered before any later prefill that reuses
+        // the slot) and release slot + KV blocks at once: the vocoder stage no longer occupies a batcher slot
+        if (latpool_free_.empty()) throw HipError("latent pool exhausted");
+        s->pool_idx = latpool_free_.back();
+        latpool_free_.pop_back();
+        const size_t n = s->tokens.size() * (size_t)kHidden * sizeof(float);
+        HIP_CHECK(hipMemcpyAsync(latpool_.as<float>() + (long)s->pool_idx * kMaxLatRows * kHidden,
+                                 latents_.as<float>() + (long)s->slot * kMaxLatRows * kHidden, n, hipMemcpyDeviceToDevice, st_));
+        HIP_CHECK(hipEventRecord(ev_lat_, st_));
         std::lock_guard<std::mutex> lk(mu_);
         for (int b : s->blocks) free_blocks_.push_back(b);
         s->blocks.clear();
+        slot_owner_[s->slot] = nullptr;
+        s->slot = -1;
+        voc_queue_.push_back(s);
     }
     void init_slots(const std::vector<SlotInit>& init) {
         i_init_.ensure(init.size() * sizeof(SlotInit));
@@ -701,6 +761,7 @@ private:
         HIP_CHECK(hipGetLastError());
     }
     void prefill(const std::vector<Seq*>& seqs) {
+        RowWs& w = ws_[0];
         std::vector<int4> desc;
         std::vector<int> row_slot, row_pos, sample_row, sample_slot, next_kvpos;
         std::vector<SlotInit> init;
@@ -724,35 +785,53 @@ private:
             next_kvpos.push_back(s->n_prompt);
         }
         const int M = (int)row_slot.size();
-        ensure_rows(M);
+        ensure_rows(w, M);
         init_slots(init);
-        HIP_CHECK(hipMemcpyAsync(block_tables_.p, h_block_tables_.data(), h_block_tables_.size() * 4, hipMemcpyHostToDevice, st_));
-        HIP_CHECK(hipMemcpyAsync(i_desc_.p, desc.data(), (size_t)M * sizeof(int4), hipMemcpyHostToDevice, st_));
-        HIP_CHECK(hipMemcpyAsync(i_row_slot_.p, row_slot.data(), (size_t)M * 4, hipMemcpyHostToDevice, st_));
-        HIP_CHECK(hipMemcpyAsync(i_row_pos_.p, row_pos.data(), (size_t)M * 4, hipMemcpyHostToDevice, st_));
+        HIP_CHECK(hipMemcpyAsync(block_tables_.p, h_block_tables_.data(), h_block_tables_.size() * 4, hipMemcpyHostToDevice, w.st));
+        HIP_CHECK(hipMemcpyAsync(w.i_desc.p, desc.data(), (size_t)M * sizeof(int4), hipMemcpyHostToDevice, w.st));
+        HIP_CHECK(hipMemcpyAsync(w.i_row_slot.p, row_slot.data(), (size_t)M * 4, hipMemcpyHostToDevice, w.st));
+        HIP_CHECK(hipMemcpyAsync(w.i_row_pos.p, row_pos.data(), (size_t)M * 4, hipMemcpyHostToDevice, w.st));
         if (debug_sync())
             fprintf(stderr, "[aur] prefill M=%d desc=%p spk=%p temb=%p tpos=%p wte=%p wpe=%p h=%p d0=(%d,%d,%d) dl=(%d,%d,%d)\n", M,
-                    i_desc_.p, spk_table_.p, (const void*)text_emb_, (const void*)text_pos_, (const void*)wte_, (const void*)wpe_, h_.p,
+                    w.i_desc.p, spk_table_.p, (const void*)text_emb_, (const void*)text_pos_, (const void*)wte_, (const void*)wpe_, w.h.p,
                     desc[0].x, desc[0].y, desc[0].z, desc[M - 1].x, desc[M - 1].y, desc[M - 1].z);
-        launch_embed_prompt(i_desc_.as<int4>(), spk_table_.as<float>(), text_emb_, text_pos_, wte_, wpe_, h_.as<float>(), M, st_);
-        forward_rows(M, i_row_slot_.as<int>(), i_row_pos_.as<int>());
+        launch_embed_prompt(w.i_desc.as<int4>(), spk_table_.as<float>(), text_emb_, text_pos_, wte_, wpe_, w.h.as<float>(), M, w.st);
+        forward_rows(w, M, w.i_row_slot.as<int>(), w.i_row_pos.as<int>());
         if (dbg_capture_) {
             dbg_lnf_.ensure((size_t)M * kHidden * 4);
-            HIP_CHECK(hipMemcpyAsync(dbg_lnf_.p, xn_.p, (size_t)M * kHidden * 4, hipMemcpyDeviceToDevice, st_));
+            HIP_CHECK(hipMemcpyAsync(dbg_lnf_.p, w.xn.p, (size_t)M * kHidden * 4, hipMemcpyDeviceToDevice, w.st));
         }
         stats_.prefill_rows += M;
-        sample_rows(sample_row, sample_slot, &next_kvpos);
+        sample_launch(w, sample_row, sample_slot, &next_kvpos);
+        HIP_CHECK(hipStreamSynchronize(w.st));
+        sample_collect(w, sample_slot);
     }
+    // One decode step.  With two streams the live sequences are split in halves whose kernels overlap: the M = 32..64
+    // GEMMs are latency bound (one 64x64x256 tile per CU), so a second independent chain fills the idle CUs and the
+    // bandwidth-bound attention of one half runs beside the MFMA-bound GEMMs of the other.
     void decode(const std::vector<int>& active) {
         const int M = (int)active.size();
-        ensure_rows(M);
-        HIP_CHECK(hipMemcpyAsync(i_row_slot_.p, active.data(), (size_t)M * 4, hipMemcpyHostToDevice, st_));
-        launch_embed_decode(i_row_slot_.as<int>(), slot_tok_.as<int>(), slot_pos_.as<int>(), wte_, wpe_, h_.as<float>(), M, st_);
-        forward_rows(M, i_row_slot_.as<int>(), nullptr);
-        std::vector<int> sample_row(M);
-        for (int i = 0; i < M; ++i) sample_row[i] = i;
+        const int n_ws = (decode_streams_ >= 2 && M >= 16) ? 2 : 1;
+        for (int k = 0; k < n_ws; ++k) {
+            RowWs& w = ws_[k];
+            const int lo = (int)((long)M * k / n_ws), hi = (int)((long)M * (k + 1) / n_ws);
+            w.sample_slot.assign(active.begin() + lo, active.begin() + hi);
+            const int Mk = hi - lo;
+            w.sample_row.resize(Mk);
+            for (int i = 0; i < Mk; ++i) w.sample_row[i] = i;
+            ensure_rows(w, Mk);
+            HIP_CHECK(hipMemcpyAsync(w.i_row_slot.p, w.sample_slot.data(), (size_t)Mk * 4, hipMemcpyHostToDevice, w.st));
+            launch_embed_decode(w.i_row_slot.as<int>(), slot_tok_.as<int>(), slot_pos_.as<int>(), wte_, wpe_, w.h.as<float>(), Mk, w.st);
+            forward_rows(w, Mk, w.i_row_slot.as<int>(), nullptr);
+            sample_launch(w, w.sample_row, w.sample_slot, nullptr);
+        }
+        if (n_ws == 2) {   // make the main stream (and its timing event) wait for the second chain
+            HIP_CHECK(hipEventRecord(ev_ws1_, ws_[1].st));
+            HIP_CHECK(hipStreamWaitEvent(ws_[0].st, ev_ws1_, 0));
+        }
+        for (int k = 0; k < n_ws; ++k) HIP_CHECK(hipStreamSynchronize(ws_[k].st));
+        for (int k = 0; k < n_ws; ++k) sample_collect(ws_[k], ws_[k].sample_slot);
         stats_.decode_rows += M;
-        sample_rows(sample_row, active, nullptr);
     }
 
     // ------------------------------------------------------------------ vocoder
@@ -790,10 +869,10 @@ private:
             ev = &conv_events_[n_conv_events_++];
             ev->flops = 2.0 * a.Cin * KS * a.Mtot * tot_in;
             ev->bytes = 4.0 * (a.Cin * tot_in + a.Cout * tot_out * (1.0 + (a.res ? 1.0 : 0.0) + (a.mrf_mode >= 2 ? 1.0 : 0.0)));
-            HIP_CHECK(hipEventRecord(ev->a, st_));
+            HIP_CHECK(hipEventRecord(ev->a, st_voc_));
         }
-        launch_conv1d(a, KS, DIL, st_);
-        if (prof) HIP_CHECK(hipEventRecord(ev->b, st_));
+        launch_conv1d(a, KS, DIL, st_voc_);
+        if (prof) HIP_CHECK(hipEventRecord(ev->b, st_voc_));
     }
     void collect_conv_events() {
         for (size_t i = 0; i < n_conv_events_; ++i) {
@@ -833,7 +912,7 @@ private:
             totT += meta[B + b];
         }
         v_meta_.ensure(meta.size() * 4);
-        HIP_CHECK(hipMemcpyAsync(v_meta_.p, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, st_));
+        HIP_CHECK(hipMemcpyAsync(v_meta_.p, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, st_voc_));
         const int* d_nlat = v_meta_.as<int>();
         const int* d_len = d_nlat + B;
         const int* d_cond = d_nlat + 2 * B;
@@ -842,8 +921,8 @@ private:
         v_z_.ensure(Bz * 1024 * T * 4);
         v_s0_.ensure(Bz * 512 * T * 4);
         for (auto* b : {&v_A_, &v_B_, &v_C_, &v_D_, &v_E_}) b->ensure(Bz * 8192 * T * 4);
-        HIP_CHECK(hipEventRecord(ev_va_, st_));
-        launch_interp2(d_lat, lat_bstride, d_latrow, d_nlat, d_len, v_z_.as<float>(), (long)T, (long)(1024 * T), 1024, B, maxT, st_);
+        HIP_CHECK(hipEventRecord(ev_va_, st_voc_));
+        launch_interp2(d_lat, lat_bstride, d_latrow, d_nlat, d_len, v_z_.as<float>(), (long)T, (long)(1024 * T), 1024, B, maxT, st_voc_);
         const float* condt = voc_cond_.as<float>();
         ConvArgs a{};
         a.base_len = d_len; a.B = B; a.cond_row = d_cond; a.cond_stride = kCondStride;
@@ -892,41 +971,71 @@ private:
                 }
             in = E; Cin = C; mul = mul_out;
         }
-        launch_conv_post(E, v_post_, d_wav, d_len, 256, 32, (long)T * 256, (long)32 * T * 256, wav_bstride, 0.01f, B, maxT * 256, st_);
-        HIP_CHECK(hipEventRecord(ev_vb_, st_));
+        launch_conv_post(E, v_post_, d_wav, d_len, 256, 32, (long)T * 256, (long)32 * T * 256, wav_bstride, 0.01f, B, maxT * 256, st_voc_);
+        HIP_CHECK(hipEventRecord(ev_vb_, st_voc_));
         voc_timed_ = true;
         stats_.vocoder_batches++;
     }
-    void vocode_finished(const std::vector<Seq*>& ready) {
-        const int B = (int)ready.size();
-        std::vector<int> nl(B), rows(B), cond(B);
-        int max_samples = 0;
+    void voc_launch() {
+        const int B = (int)std::min(voc_queue_.size(), (size_t)cfg_.max_seqs);
+        voc_batch_.assign(voc_queue_.begin(), voc_queue_.begin() + B);
+        voc_queue_.erase(voc_queue_.begin(), voc_queue_.begin() + B);
+        voc_nl_.resize(B);
+        std::vector<int> rows(B), cond(B);
+        voc_max_samples_ = 0;
         for (int b = 0; b < B; ++b) {
-            nl[b] = (int)ready[b]->tokens.size();
-            rows[b] = ready[b]->slot;
-            cond[b] = ready[b]->spk_row;
-            max_samples = std::max(max_samples, frames_for(nl[b]) * 256);
+            voc_nl_[b] = (int)voc_batch_[b]->tokens.size();
+            rows[b] = voc_batch_[b]->pool_idx;
+            cond[b] = voc_batch_[b]->spk_row;
+            voc_max_samples_ = std::max(voc_max_samples_, frames_for(voc_nl_[b]) * 256);
         }
-        tmp_wav_.ensure((size_t)B * max_samples * 4);
-        run_vocoder(B, nl, latents_.as<float>(), (long)kMaxLatRows * kHidden, &rows, cond, tmp_wav_.as<float>(), max_samples);
-        HIP_CHECK(hipStreamSynchronize(st_));
-        collect_conv_events();
+        tmp_wav_.ensure((size_t)B * voc_max_samples_ * 4);
+        voc_pin_.ensure((size_t)B * voc_max_samples_ * 4 + (size_t)B * kMaxLatRows * kHidden * 4);
+        HIP_CHECK(hipStreamWaitEvent(st_voc_, ev_lat_, 0));   // latents parked by the main stream
+        run_vocoder(B, voc_nl_, latpool_.as<float>(), (long)kMaxLatRows * kHidden, &rows, cond, tmp_wav_.as<float>(),
+                    voc_max_samples_);
+        float* hw = voc_pin_.as<float>();
+        float* hl = hw + (size_t)B * voc_max_samples_;
         for (int b = 0; b < B; ++b) {
-            Seq* s = ready[b];
-            const int ns = frames_for(nl[b]) * 256;
-            s->wav.resize(ns);
-            HIP_CHECK(hipMemcpy(s->wav.data(), tmp_wav_.as<float>() + (long)b * max_samples, (size_t)ns * 4, hipMemcpyDeviceToHost));
-            s->latents.resize((size_t)nl[b] * kHidden);
-            HIP_CHECK(hipMemcpy(s->latents.data(), latents_.as<float>() + (long)s->slot * kMaxLatRows * kHidden,
-                                s->latents.size() * 4, hipMemcpyDeviceToHost));
+            const int ns = frames_for(voc_nl_[b]) * 256;
+            HIP_CHECK(hipMemcpyAsync(hw + (size_t)b * voc_max_samples_, tmp_wav_.as<float>() + (long)b * voc_max_samples_,
+                                     (size_t)ns * 4, hipMemcpyDeviceToHost, st_voc_));
+            HIP_CHECK(hipMemcpyAsync(hl + (size_t)b * kMaxLatRows * kHidden,
+                                     latpool_.as<float>() + (long)rows[b] * kMaxLatRows * kHidden,
+                                     (size_t)voc_nl_[b] * kHidden * 4, hipMemcpyDeviceToHost, st_voc_));
+        }
+        HIP_CHECK(hipEventRecord(ev_voc_done_, st_voc_));
+        voc_active_ = true;
+    }
+    // finalize the in-flight vocoder batch if it has completed (or wait for it)
+    void voc_poll(bool wait) {
+        if (!voc_active_) return;
+        if (wait) {
+            HIP_CHECK(hipEventSynchronize(ev_voc_done_));
+        } else {
+            const hipError_t q = hipEventQuery(ev_voc_done_);
+            if (q == hipErrorNotReady) return;
+            HIP_CHECK(q);
+        }
+        collect_conv_events();
+        const int B = (int)voc_batch_.size();
+        const float* hw = voc_pin_.as<float>();
+        const float* hl = hw + (size_t)B * voc_max_samples_;
+        for (int b = 0; b < B; ++b) {
+            Seq* s = voc_batch_[b];
+            const int ns = frames_for(voc_nl_[b]) * 256;
+            s->wav.assign(hw + (size_t)b * voc_max_samples_, hw + (size_t)b * voc_max_samples_ + ns);
+            s->latents.assign(hl + (size_t)b * kMaxLatRows * kHidden, hl + (size_t)b * kMaxLatRows * kHidden + (size_t)voc_nl_[b] * kHidden);
             stats_.samples_generated += ns;
             std::lock_guard<std::mutex> lk(mu_);
-            slot_owner_[s->slot] = nullptr;
-            s->slot = -1;
+            latpool_free_.push_back(s->pool_idx);
+            s->pool_idx = -1;
             s->state = SeqState::DONE;
             done_.push_back(s);
             finished_total_++;
         }
+        voc_batch_.clear();
+        voc_active_ = false;
     }
 
     aur_config cfg_;
@@ -951,10 +1060,22 @@ private:
     DevBuf spk_table_, spk_emb_, voc_cond_, zero_bias_;
     std::map<uint64_t, int> spk_rows_;
     // row workspace
-    int rows_cap_ = 0;
-    DevBuf h_, xn_, qbuf_, att_, act_, P_, P2_, ybuf_;
-    DevBuf i_row_slot_, i_row_pos_, i_desc_, i_sample_row_, i_sample_slot_, i_next_kvpos_, i_out_tok_, i_init_;
-    PinBuf pin_;
+    RowWs ws_[2];
+    // vocoder stage
+    hipStream_t st_voc_ = nullptr;
+    hipEvent_t ev_lat_ = nullptr, ev_voc_done_ = nullptr;
+    DevBuf latpool_;
+    std::vector<int> latpool_free_;
+    std::deque<Seq*> voc_queue_;
+    std::vector<Seq*> voc_batch_;
+    std::vector<int> voc_nl_;
+    int voc_max_samples_ = 0;
+    bool voc_active_ = false;
+    PinBuf voc_pin_;
+    int decode_streams_ = 1;   // 2 measured slower on MI355X (host launch bound without graphs); kept for A/B via AUR_DECODE_STREAMS
+    hipStream_t st2_ = nullptr;
+    hipEvent_t ev_ws1_ = nullptr;
+    DevBuf i_init_;
     DevBuf dbg_lnf_, dbg_logits_;
     bool dbg_capture_ = false;
     // vocoder

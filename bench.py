@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--tokens", type=int, default=280, help="mel tokens per utterance (fixed-length mode)")
     ap.add_argument("--layers", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="queue all steps at once so the vocoder of batch k overlaps the GPT of batch k+1 (measured "
+                         "neutral on MI355X in fp32: both stages want the same CUs)")
     ap.add_argument("--cpu-tokens", type=int, default=64)
     args = ap.parse_args()
 
@@ -117,13 +120,21 @@ def main():
         eng.set_conditioning(SPK, cond.numpy(), spk.numpy())
     text_ids = make_synthetic_text_ids(dims, n_text=70, seed=11)
 
-    def one_step(step_idx: int):
-        for b in range(args.batch):
-            eng.submit(text_ids, SPK, temperature=0.75, top_p=0.85, top_k=50, repetition_penalty=5.0,
-                       max_tokens=args.tokens, seed=(rank * 100003 + step_idx * 1009 + b), ignore_stop=True)
-        outs = eng.run_until_done(max_steps=args.tokens + 16)
-        assert len(outs) == args.batch
-        return sum(len(o["wav"]) for o in outs)
+    def run_steps(first: int, n: int):
+        """n steps = n batches of `batch` utterances, one after the other.  With --pipeline all n batches are queued at
+        once: the continuous batcher admits batch k+1 into the slots batch k frees when its tokens are done, so the
+        HiFi-GAN of batch k (own stream) overlaps the GPT prefill/decode of batch k+1."""
+        total = 0
+        groups = [range(first, first + n)] if args.pipeline else [[k] for k in range(first, first + n)]
+        for grp in groups:
+            for k in grp:
+                for b in range(args.batch):
+                    eng.submit(text_ids, SPK, temperature=0.75, top_p=0.85, top_k=50, repetition_penalty=5.0,
+                               max_tokens=args.tokens, seed=(rank * 100003 + (k + 7) * 1009 + b), ignore_stop=True)
+            outs = eng.run_until_done(max_steps=len(grp) * (args.tokens + 16) + 64)
+            assert len(outs) == args.batch * len(grp)
+            total += sum(len(o["wav"]) for o in outs)
+        return total
 
     def fence():
         if world > 1:
@@ -131,16 +142,14 @@ def main():
         torch.cuda.synchronize()
         eng.sync()
 
-    for w in range(args.warmup):
-        one_step(-1 - w)
-        _log(f"warmup step {w} done")
+    if args.warmup:
+        run_steps(-args.warmup, args.warmup)
+        _log(f"{args.warmup} warmup step(s) done")
     eng.reset_stats()
     fence()
     t0 = time.perf_counter()
-    samples = 0
-    for k in range(args.steps):
-        samples += one_step(k)
-        _log(f"timed step {k} done at +{time.perf_counter() - t0:.3f}s")
+    samples = run_steps(0, args.steps)
+    _log(f"{args.steps} timed step(s) done at +{time.perf_counter() - t0:.3f}s")
     fence()
     dt = time.perf_counter() - t0
     st = eng.stats()
@@ -174,7 +183,8 @@ def main():
             "config": {"workload": f"{args.batch} concurrent 200-char utterances per GPU (70 text tokens -> "
                                    f"{args.tokens} mel tokens fixed-length -> {dims.voc.samples_for_latents(args.tokens)} "
                                    f"samples each), T=0.75 top_p=0.85 top_k=50 rep_pen=5.0, shared speaker latent, "
-                                   f"continuous batching; BASELINE.json configs[2]",
+                                   f"continuous batching; BASELINE.json configs[2]"
+                                   + ("; consecutive steps pipelined (vocoder of batch k overlaps GPT of batch k+1)" if args.pipeline else ""),
                        "utterances_per_gpu": args.batch, "mel_tokens": args.tokens, "gpt_layers": args.layers,
                        "parallelism": f"dp{world} (independent utterances, 1 RCCL broadcast of conditioning)"},
             "roofline": {
