@@ -2,10 +2,9 @@
 library: same public methods, same return shapes; vLLM, the second GPT pass and the torch HiFi-GAN are replaced by
 aur_submit / aur_step / aur_poll_finished.
 
-Out of scope this round: computing conditioning from reference audio (ConditioningEncoder,
-PerceiverResampler, ResNetSpeakerEncoder).  `speaker_files` may therefore be (a) a path to an .npz with
-`gpt_cond_latent` [1,32,1024] and `speaker_embedding` [1,512,1], or (b) a dict / tuple holding those arrays;
-audio files raise NotImplementedError with that explanation."""
+`speaker_files` may be reference audio (RIFF/WAVE paths or bytes: conditioning is computed once per speaker by
+auralis_amd/conditioning.py, SURVEY §8f #1, on the GPU through PyTorch-ROCm), a path/bytes of an .npz holding
+`gpt_cond_latent` [1,32,1024] and `speaker_embedding` [1,512,1], or a dict / tuple with those arrays."""
 from __future__ import annotations
 
 import asyncio
@@ -37,8 +36,10 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
     model_type = "xtts"
 
     def __init__(self, native_engine: Any, tokenizer: XTTSTokenizer, max_concurrency: int = 10,
-                 gpt_max_audio_tokens: int = 605):
+                 gpt_max_audio_tokens: int = 605, conditioning_weights: Optional[dict] = None):
         self.native = native_engine
+        self.conditioning_weights = conditioning_weights   # xtts-v2.safetensors tensors of the once-per-speaker modules
+        self._cond_cache = {}
         self.tokenizer = tokenizer
         self.max_concurrency = max_concurrency
         self.gpt_max_audio_tokens = gpt_max_audio_tokens
@@ -68,7 +69,10 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
             if os.path.isfile(p):
                 tok_file = p
         vocab = xtts_sd["text_embedding.weight"].shape[0]
-        return cls(native, XTTSTokenizer(tok_file, vocab_size=vocab), max_concurrency=max_concurrency)
+        cond_w = {k: v for k, v in xtts_sd.items()
+                  if k.startswith(("conditioning_", "hifigan_decoder.speaker_encoder.", "mel_stats"))}
+        return cls(native, XTTSTokenizer(tok_file, vocab_size=vocab), max_concurrency=max_concurrency,
+                   conditioning_weights=cond_w if any(k.startswith("conditioning_encoder.") for k in cond_w) else None)
 
     @property
     def conditioning_config(self) -> ConditioningConfig:
@@ -92,19 +96,39 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
     async def get_audio_conditioning(self, audio_reference, max_ref_length=30, gpt_cond_len=6, gpt_cond_chunk_len=6,
                                      librosa_trim_db=None, sound_norm_refs=False, load_sr=22050):
         """-> (gpt_cond_latent [1,32,1024], speaker_embedding [1,512,1]) as float32 numpy arrays."""
-        ref = audio_reference[0] if isinstance(audio_reference, (list, tuple)) and len(audio_reference) == 1 else audio_reference
+        refs = list(audio_reference) if isinstance(audio_reference, (list, tuple)) else [audio_reference]
+        if len(refs) == 2 and hasattr(refs[0], "shape") and hasattr(refs[1], "shape"):
+            refs = [{"gpt_cond_latent": refs[0], "speaker_embedding": refs[1]}]
+        ref = refs[0]
+
+        def _is_npz(r):
+            return (isinstance(r, str) and r.endswith(".npz")) or (isinstance(r, (bytes, bytearray)) and r[:2] == b"PK")
         if isinstance(ref, dict):
             g, s = ref["gpt_cond_latent"], ref["speaker_embedding"]
-        elif isinstance(ref, (list, tuple)) and len(ref) == 2 and hasattr(ref[0], "shape"):
-            g, s = ref
-        elif isinstance(ref, str) and ref.endswith(".npz") and os.path.isfile(ref):
-            z = np.load(ref)
+        elif _is_npz(ref):
+            import io
+            z = np.load(ref if isinstance(ref, str) else io.BytesIO(ref))
             g, s = z["gpt_cond_latent"], z["speaker_embedding"]
         else:
-            raise NotImplementedError(
-                "conditioning from reference audio (ConditioningEncoder / PerceiverResampler / ResNetSpeakerEncoder, "
-                "XTTSv2.py:409-468) is not built yet (SURVEY §8f #1): pass precomputed conditioning as an .npz path "
-                "or a dict with gpt_cond_latent [1,32,1024] and speaker_embedding [1,512,1]")
+            if self.conditioning_weights is None:
+                raise NotImplementedError(
+                    "this checkpoint carries no conditioning_encoder / perceiver / speaker_encoder weights: pass "
+                    "precomputed conditioning (.npz or dict with gpt_cond_latent [1,32,1024], speaker_embedding [1,512,1])")
+            import hashlib as _h
+
+            import torch
+
+            from .. import conditioning as Cn
+            key = _h.blake2b(b"|".join(r.encode() if isinstance(r, str) else bytes(r[:4096]) + str(len(r)).encode()
+                                       for r in refs) + f"{max_ref_length}/{gpt_cond_len}/{gpt_cond_chunk_len}".encode(),
+                             digest_size=16).digest()
+            if key not in self._cond_cache:
+                dev = "cuda" if torch.cuda.is_available() else "cpu"
+                g_t, s_t = await asyncio.to_thread(Cn.get_conditioning_latents, self.conditioning_weights, refs,
+                                                   max_ref_length, gpt_cond_len, gpt_cond_chunk_len, sound_norm_refs,
+                                                   load_sr, dev)
+                self._cond_cache[key] = (g_t.float().cpu().numpy(), s_t.float().cpu().numpy())
+            g, s = self._cond_cache[key]
         g = np.asarray(getattr(g, "numpy", lambda: g)(), dtype=np.float32).reshape(1, 32, 1024)
         s = np.asarray(getattr(s, "numpy", lambda: s)(), dtype=np.float32).reshape(1, 512, 1)
         return g, s

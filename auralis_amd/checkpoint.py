@@ -113,6 +113,77 @@ def make_synthetic_xtts(dims: XTTSDims, seed: int = 1234, gpt_sd: Optional[Dict[
                     sd[rb + f"{grp}.{q}.bias"] = _conv_default_init(g, (c,), c * rk)
         cin = c
     sd[p + "conv_post.weight"] = _conv_default_init(g, (1, cin, 7), cin * 7)
+    sd.update(make_synthetic_conditioning_weights(dims, seed=seed + 2))
+    return sd
+
+
+def conditioning_param_shapes(dims: XTTSDims) -> Dict[str, tuple]:
+    """Names/shapes of the once-per-speaker modules inside xtts-v2.safetensors:
+    conditioning_encoder (Conv1d 80->1024 + 6 attention blocks), conditioning_perceiver (32 latents, 2 x (cross-attn
+    8x64 + GEGLU FF 2730)), hifigan_decoder.speaker_encoder (ResNet-SE [3,4,6,3] x [32,64,128,256], ASP, fc 512)."""
+    H = dims.gpt.hidden
+    out: Dict[str, tuple] = {"conditioning_encoder.init.weight": (H, 80, 1), "conditioning_encoder.init.bias": (H,)}
+    for i in range(6):
+        p = f"conditioning_encoder.attn.{i}."
+        out.update({p + "norm.weight": (H,), p + "norm.bias": (H,), p + "qkv.weight": (3 * H, H, 1),
+                    p + "qkv.bias": (3 * H,), p + "proj_out.weight": (H, H, 1), p + "proj_out.bias": (H,)})
+    out["conditioning_perceiver.latents"] = (32, H)
+    inner = int(H * 4 * 2 / 3)
+    for i in range(2):
+        p = f"conditioning_perceiver.layers.{i}."
+        out.update({p + "0.to_q.weight": (512, H), p + "0.to_kv.weight": (1024, H), p + "0.to_out.weight": (H, 512),
+                    p + "1.0.weight": (2 * inner, H), p + "1.0.bias": (2 * inner,), p + "1.2.weight": (H, inner),
+                    p + "1.2.bias": (H,)})
+    out["conditioning_perceiver.norm.gamma"] = (H,)
+    s = "hifigan_decoder.speaker_encoder."
+
+    def bn(prefix, c):
+        out.update({prefix + "weight": (c,), prefix + "bias": (c,), prefix + "running_mean": (c,),
+                    prefix + "running_var": (c,), prefix + "num_batches_tracked": ()})
+    out[s + "torch_spec.0.filter"] = (1, 1, 2)     # PreEmphasis buffer; the torchaudio mel buffers are recomputed
+    out[s + "conv1.weight"] = (32, 1, 3, 3)
+    out[s + "conv1.bias"] = (32,)
+    bn(s + "bn1.", 32)
+    inpl = 32
+    for li, (planes, blocks) in enumerate(zip((32, 64, 128, 256), (3, 4, 6, 3)), start=1):
+        for bi in range(blocks):
+            p = s + f"layer{li}.{bi}."
+            out[p + "conv1.weight"] = (planes, inpl if bi == 0 else planes, 3, 3)
+            bn(p + "bn1.", planes)
+            out[p + "conv2.weight"] = (planes, planes, 3, 3)
+            bn(p + "bn2.", planes)
+            out.update({p + "se.fc.0.weight": (planes // 8, planes), p + "se.fc.0.bias": (planes // 8,),
+                        p + "se.fc.2.weight": (planes, planes // 8), p + "se.fc.2.bias": (planes,)})
+            if bi == 0 and (li > 1):
+                out[p + "downsample.0.weight"] = (planes, inpl, 1, 1)
+                bn(p + "downsample.1.", planes)
+        inpl = planes
+    out.update({s + "attention.0.weight": (128, 2048, 1), s + "attention.0.bias": (128,)})
+    bn(s + "attention.2.", 128)
+    out.update({s + "attention.3.weight": (2048, 128, 1), s + "attention.3.bias": (2048,),
+                s + "fc.weight": (512, 4096), s + "fc.bias": (512,)})
+    return out
+
+
+def make_synthetic_conditioning_weights(dims: XTTSDims, seed: int = 1236) -> Dict[str, Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, Tensor] = {}
+    for name, shape in conditioning_param_shapes(dims).items():
+        if name.endswith("num_batches_tracked"):
+            sd[name] = torch.tensor(0, dtype=torch.long)
+        elif name.endswith("torch_spec.0.filter"):
+            sd[name] = torch.tensor([-0.97, 1.0]).view(1, 1, 2)
+        elif name.endswith("running_var"):
+            sd[name] = 0.5 + torch.rand(shape, generator=g)
+        elif name.endswith(("norm.weight", "bn1.weight", "bn2.weight", "downsample.1.weight", "attention.2.weight", "norm.gamma")):
+            sd[name] = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif len(shape) <= 1:
+            sd[name] = 0.05 * torch.randn(shape, generator=g)
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            sd[name] = torch.randn(shape, generator=g) / math.sqrt(fan_in)
     return sd
 
 

@@ -83,3 +83,17 @@ def build_reference_decoder(xtts_sd):
     missing, unexpected = dec.waveform_decoder.load_state_dict(sub, strict=True), None
     dec.eval()
     return dec
+
+
+def load_reference_xtts_layer(name: str):
+    """Load another single-file module of the reference's xtts layers (latent_encoder, perceiver_encoder) unmodified."""
+    load_reference_hifigan()   # installs the stub parent packages
+    full = "auralis.models.xttsv2.components.tts.layers.xtts." + name
+    if full in sys.modules:
+        return sys.modules[full]
+    path = os.path.join(REF_ROOT, os.path.dirname(_REL), name + ".py")
+    spec = importlib.util.spec_from_file_location(full, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[full] = mod
+    spec.loader.exec_module(mod)
+    return mod

@@ -1,0 +1,103 @@
+"""CPU: the speaker-conditioning restatement (auralis_amd/conditioning.py) against the reference's own module classes
+(imported unmodified when /root/reference exists) plus front-end property tests."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from auralis_amd import conditioning as Cn
+from auralis_amd.checkpoint import conditioning_param_shapes, make_synthetic_conditioning_weights
+from oracle.ref_import import reference_available
+
+needs_ref = pytest.mark.skipif(not reference_available(), reason="/root/reference not present (GPU box)")
+
+
+@pytest.fixture(scope="module")
+def cond_sd(dims):
+    return make_synthetic_conditioning_weights(dims, seed=99)
+
+
+@needs_ref
+def test_param_names_and_shapes_match_reference_modules(dims):
+    from oracle.ref_import import load_reference_hifigan, load_reference_xtts_layer
+    le, pe, hg = load_reference_xtts_layer("latent_encoder"), load_reference_xtts_layer("perceiver_encoder"), load_reference_hifigan()
+    ref = {}
+    ref.update({"conditioning_encoder." + k: tuple(v.shape) for k, v in le.ConditioningEncoder(80, 1024, num_attn_heads=16).state_dict().items()})
+    ref.update({"conditioning_perceiver." + k: tuple(v.shape) for k, v in pe.PerceiverResampler(
+        dim=1024, depth=2, dim_context=1024, num_latents=32, dim_head=64, heads=8, ff_mult=4).state_dict().items()})
+    se = hg.HifiDecoder().speaker_encoder
+    ref.update({"hifigan_decoder.speaker_encoder." + k: tuple(v.shape) for k, v in se.state_dict().items()})
+    assert conditioning_param_shapes(dims) == ref
+
+
+@needs_ref
+def test_conditioning_encoder_and_perceiver_match_reference(cond_sd):
+    from oracle.ref_import import load_reference_xtts_layer
+    le, pe = load_reference_xtts_layer("latent_encoder"), load_reference_xtts_layer("perceiver_encoder")
+    enc = le.ConditioningEncoder(80, 1024, num_attn_heads=16).eval()
+    enc.load_state_dict({k[len("conditioning_encoder."):]: v for k, v in cond_sd.items() if k.startswith("conditioning_encoder.")})
+    per = pe.PerceiverResampler(dim=1024, depth=2, dim_context=1024, num_latents=32, dim_head=64, heads=8, ff_mult=4).eval()
+    per.load_state_dict({k[len("conditioning_perceiver."):]: v for k, v in cond_sd.items() if k.startswith("conditioning_perceiver.")})
+    mel = torch.randn(1, 80, 57, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref_h = enc(mel)
+        ref_l = per(ref_h.permute(0, 2, 1))
+        got_h = Cn.conditioning_encoder(cond_sd, mel)
+        got_l = Cn.perceiver_resampler(cond_sd, got_h.permute(0, 2, 1))
+    assert (got_h - ref_h).abs().max().item() < 1e-4
+    assert got_l.shape == (1, 32, 1024) and (got_l - ref_l).abs().max().item() < 1e-4
+
+
+@needs_ref
+def test_speaker_encoder_body_matches_reference(cond_sd):
+    from oracle.ref_import import load_reference_hifigan
+    se = load_reference_hifigan().HifiDecoder().speaker_encoder.eval()
+    se.load_state_dict({k[len("hifigan_decoder.speaker_encoder."):]: v for k, v in cond_sd.items()
+                        if k.startswith("hifigan_decoder.speaker_encoder.")})
+    se.use_torch_spec = False            # the torchaudio mel front-end is stubbed offline: feed the mel directly
+    mel = torch.rand(2, 64, 120, generator=torch.Generator().manual_seed(2)) * 3.0
+    with torch.no_grad():
+        ref = se(mel.clone(), l2_norm=True)
+        got = Cn.speaker_encoder_from_mel(cond_sd, mel.clone())
+    assert got.shape == (2, 512) and (got - ref).abs().max().item() < 1e-5
+
+
+def test_resample_keeps_a_tone_and_length():
+    sr, new = 44100, 22050
+    t = torch.arange(sr, dtype=torch.float32) / sr
+    x = (0.5 * torch.sin(2 * math.pi * 1000.0 * t))[None]
+    y = Cn.resample(x, sr, new)
+    assert y.shape[-1] == new
+    ref = 0.5 * torch.sin(2 * math.pi * 1000.0 * torch.arange(new, dtype=torch.float32) / new)
+    assert (y[0, 200:-200] - ref[200:-200]).abs().max().item() < 2e-3
+    up = Cn.resample(x[:, :4410], 22050, 24000)
+    assert up.shape[-1] == math.ceil(4410 * 24000 / 22050)
+
+
+def test_mel_filterbank_properties():
+    fb = Cn.mel_filterbank(1025, 0.0, 8000.0, 80, 22050, slaney_norm=True)
+    assert fb.shape == (1025, 80) and (fb >= 0).all()
+    peaks = fb.argmax(dim=0)
+    assert (peaks[1:] >= peaks[:-1]).all()                 # centre frequencies increase
+    assert fb[int(8000 / (22050 / 2) * 1024) + 3:, :].abs().max() == 0    # nothing above f_max
+    fb2 = Cn.mel_filterbank(257, 0.0, 8000.0, 64, 16000, slaney_norm=False)
+    assert abs(fb2.max().item() - 1.0) < 0.05              # un-normalised triangles peak at ~1
+
+
+def test_wav_roundtrip_and_end_to_end_shapes(tmp_path, cond_sd):
+    from auralis_amd import TTSOutput
+    sr = 44100
+    t = np.arange(int(2.5 * sr)) / sr
+    wav = (0.3 * np.sin(2 * np.pi * 220 * t) + 0.1 * np.sin(2 * np.pi * 1760 * t)).astype(np.float32)
+    p = tmp_path / "voice.wav"
+    TTSOutput(array=wav, sample_rate=sr).save(p)
+    a, got_sr = Cn.read_wav(str(p))
+    assert got_sr == sr and a.shape == (1, len(wav)) and np.abs(a.numpy()[0] - wav).max() < 1e-4
+    sd = dict(cond_sd)
+    sd["mel_stats"] = torch.ones(80)
+    cond, spk = Cn.get_conditioning_latents(sd, [str(p), p.read_bytes()], max_ref_length=30, gpt_cond_len=6, gpt_cond_chunk_len=2)
+    assert cond.shape == (1, 32, 1024) and spk.shape == (1, 512, 1)
+    assert torch.isfinite(cond).all() and abs(spk.norm().item() - 1.0) < 1e-4
+    with pytest.raises(ValueError):
+        Cn.read_wav(b"not a wav file at all, definitely not....................")

@@ -167,11 +167,33 @@ def test_engine_failure_reaches_caller():
         tts.close()
 
 
-def test_audio_reference_files_not_silently_accepted():
+def test_audio_reference_without_conditioning_weights_is_rejected_loudly():
     tts, _ = _tts()
     try:
         with pytest.raises(NotImplementedError):
             tts.generate_speech(TTSRequest(text="hello", speaker_files=["female.wav"], language="en"))
+    finally:
+        tts.close()
+
+
+def test_wav_reference_goes_through_conditioning_encoders(tmp_path, dims):
+    """speaker_files = real wav path / bytes -> conditioning.py -> engine.set_conditioning (cached per reference)."""
+    from auralis_amd.checkpoint import make_synthetic_conditioning_weights
+    sr = 22050
+    t = np.arange(int(1.5 * sr)) / sr
+    TTSOutput(array=(0.3 * np.sin(2 * np.pi * 330 * t)).astype(np.float32), sample_rate=sr).save(tmp_path / "v.wav")
+    w = make_synthetic_conditioning_weights(dims, seed=5)
+    w["mel_stats"] = __import__("torch").ones(80)
+    fake = FakeNativeEngine(max_seqs=3)
+    eng = XTTSv2Engine(fake, XTTSTokenizer(None), max_concurrency=3, conditioning_weights=w)
+    tts = TTS(scheduler_max_concurrency=3).with_engine(eng)
+    try:
+        for ref in (str(tmp_path / "v.wav"), (tmp_path / "v.wav").read_bytes()):
+            out = tts.generate_speech(TTSRequest(text="hello there my friend", speaker_files=[ref], language="en"))
+            assert len(out.array) > 0
+        assert len(fake.speakers) == 1                      # same audio -> same conditioning -> registered once
+        g, s = next(iter(fake.speakers.values()))
+        assert g.shape == (1, 32, 1024) and s.shape == (1, 512, 1) and abs(np.linalg.norm(s) - 1.0) < 1e-4
     finally:
         tts.close()
 
