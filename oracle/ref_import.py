@@ -25,6 +25,9 @@ def load_reference_hifigan():
     """Return the reference module object for hifigan_decoder.py."""
     if not reference_available():
         raise FileNotFoundError(f"{REF_ROOT} not present")
+    _name = "auralis.models.xttsv2.components.tts.layers.xtts.hifigan_decoder"
+    if _name in sys.modules:
+        return sys.modules[_name]
     stubbed = False
     if "torchaudio" not in sys.modules:
         stubbed = True
