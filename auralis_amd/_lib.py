@@ -23,7 +23,8 @@ class AurError(RuntimeError):
 
 class aur_config(C.Structure):
     _fields_ = [("n_layer", C.c_int32), ("max_seqs", C.c_int32), ("max_prefill_rows", C.c_int32),
-                ("max_speakers", C.c_int32), ("vocoder_min_batch", C.c_int32), ("profile", C.c_int32)]
+                ("max_speakers", C.c_int32), ("vocoder_min_batch", C.c_int32), ("profile", C.c_int32),
+                ("vocoder_fp16", C.c_int32)]
 
 
 class aur_tensor_desc(C.Structure):
@@ -59,7 +60,7 @@ EXPORTS = [
     "aur_last_error", "aur_version", "aur_engine_create", "aur_engine_destroy", "aur_load_weights",
     "aur_set_conditioning", "aur_set_conditioning_device", "aur_submit", "aur_step", "aur_poll_finished",
     "aur_release", "aur_vocode", "aur_sync", "aur_get_stats", "aur_reset_stats", "aur_dbg_gemm",
-    "aur_dbg_layernorm", "aur_dbg_conv1d", "aur_dbg_prefill", "aur_dbg_sample",
+    "aur_dbg_layernorm", "aur_dbg_conv1d", "aur_dbg_conv1d_f16", "aur_dbg_prefill", "aur_dbg_sample",
 ]
 
 _lib = None
@@ -102,6 +103,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "aur_dbg_layernorm": [eng, fp, fp, fp, fp, C.c_int32],
         "aur_dbg_conv1d": [eng, fp, fp, fp, fp, fp, ip, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                            C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32],
+        "aur_dbg_conv1d_f16": [eng, fp, C.c_void_p, fp, fp, fp, ip, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32],
         "aur_dbg_prefill": [eng, ip, C.c_int32, C.c_uint64, C.c_float, fp, fp],
         "aur_dbg_sample": [eng, fp, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_float,
                            C.POINTER(C.c_uint8), C.c_uint32, C.c_int32, ip],
@@ -135,9 +138,10 @@ class NativeEngine:
     """Thin object wrapper over the C ABI; one instance per GPU."""
 
     def __init__(self, n_layer: int = 30, max_seqs: int = 64, device: int = 0, max_prefill_rows: int = 0,
-                 max_speakers: int = 0, vocoder_min_batch: int = 0, profile: bool = False):
+                 max_speakers: int = 0, vocoder_min_batch: int = 0, profile: bool = False, vocoder_fp16: bool = False):
         self.lib = load_library()
-        cfg = aur_config(n_layer, max_seqs, max_prefill_rows, max_speakers, vocoder_min_batch, int(profile))
+        cfg = aur_config(n_layer, max_seqs, max_prefill_rows, max_speakers, vocoder_min_batch, int(profile),
+                         int(vocoder_fp16))
         h = C.c_void_p()
         self._check(self.lib.aur_engine_create(C.byref(cfg), device, C.byref(h)))
         self.h = h
@@ -278,6 +282,19 @@ class NativeEngine:
         lens = _i32(lens)
         self._check(self.lib.aur_dbg_conv1d(self.h, _fp(x), _fp(wp), _fp(bias), _fp(res), _fp(out), _ip(lens), B, cin,
                                             mtot, cout, L, ks, dil, padl, slope, ups_s, ups_p))
+        return out
+
+    def dbg_conv1d_f16(self, x, wp16, bias, res, lens, ks, dil, padl, slope, cout, mtot, ups_s=0, ups_p=0) -> np.ndarray:
+        x = _f32(x)
+        wp16 = np.ascontiguousarray(wp16, dtype=np.float16)
+        B, cin, L = x.shape
+        lout = L * max(1, ups_s)
+        bias = None if bias is None else _f32(bias)
+        res = None if res is None else _f32(res)
+        out = np.empty((B, cout, lout), dtype=np.float32)
+        lens = _i32(lens)
+        self._check(self.lib.aur_dbg_conv1d_f16(self.h, _fp(x), wp16.ctypes.data_as(C.c_void_p), _fp(bias), _fp(res),
+                                                _fp(out), _ip(lens), B, cin, mtot, cout, L, ks, dil, padl, slope, ups_s, ups_p))
         return out
 
     def dbg_prefill(self, text_ids, speaker_key: int, repetition_penalty: float = 1.0):

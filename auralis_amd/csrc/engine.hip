@@ -138,6 +138,7 @@ struct Seq {
 struct ConvLayer {
     const float* wp = nullptr;
     const float* bias = nullptr;
+    const void* wp16 = nullptr;
 };
 
 class Engine {
@@ -492,18 +493,19 @@ public:
         HIP_CHECK(hipStreamSynchronize(st_));
         HIP_CHECK(hipMemcpy(out, dout.p, (size_t)M * kHidden * 4, hipMemcpyDeviceToHost));
     }
-    void dbg_conv1d(const float* x, const float* wp, const float* bias, const float* res, float* out,
+    void dbg_conv1d(const float* x, const void* wp, const float* bias, const float* res, float* out,
                     const int* lens, int B, int Cin, int Mtot, int Cout, int L, int KS, int DIL, int padl,
-                    float slope, int ups_s, int ups_p) {
+                    float slope, int ups_s, int ups_p, bool f16) {
         use();
         const int Lout = L * std::max(1, ups_s);
         DevBuf dx, dw, db, dr, dout, dl;
         dx.ensure((size_t)B * Cin * L * 4);
-        dw.ensure((size_t)Mtot * Cin * KS * 4);
+        const size_t wbytes = (size_t)Mtot * Cin * KS * (f16 ? 2 : 4);
+        dw.ensure(wbytes);
         dout.ensure((size_t)B * Cout * Lout * 4);
         dl.ensure((size_t)B * 4);
         HIP_CHECK(hipMemcpy(dx.p, x, (size_t)B * Cin * L * 4, hipMemcpyHostToDevice));
-        HIP_CHECK(hipMemcpy(dw.p, wp, (size_t)Mtot * Cin * KS * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dw.p, wp, wbytes, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(dl.p, lens, (size_t)B * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemsetAsync(dout.p, 0, (size_t)B * Cout * Lout * 4, st_));
         if (bias) {
@@ -517,6 +519,7 @@ public:
         ConvArgs a{};
         a.x = dx.as<float>();
         a.wp = dw.as<float>();
+        a.wp16 = dw.p;
         a.bias = bias ? db.as<float>() : nullptr;
         a.res = res ? dr.as<float>() : nullptr;
         a.out = dout.as<float>();
@@ -528,7 +531,10 @@ public:
         a.padl = padl; a.slope = slope; a.ups_s = ups_s; a.ups_p = ups_p;
         a.max_len = *std::max_element(lens, lens + B);
         a.B = B;
-        launch_conv1d(a, KS, DIL, st_);
+        if (f16)
+            launch_conv1d_f16(a, KS, DIL, st_);
+        else
+            launch_conv1d(a, KS, DIL, st_);
         HIP_CHECK(hipStreamSynchronize(st_));
         HIP_CHECK(hipMemcpy(out, dout.p, (size_t)B * Cout * Lout * 4, hipMemcpyDeviceToHost));
     }
@@ -842,18 +848,25 @@ private:
     };
     void ensure_voc() {
         if (voc_ready_) return;
-        auto get = [&](const std::string& n) { return W(n); };
-        v_pre_ = ConvLayer{get("voc.conv_pre.wp"), get("voc.conv_pre.bias")};
+        const bool f16 = cfg_.vocoder_fp16 != 0;
+        auto layer = [&](const std::string& n) {
+            ConvLayer l;
+            l.wp = W("voc." + n + ".wp");
+            l.bias = W("voc." + n + ".bias");
+            if (f16) l.wp16 = W("voc16." + n + ".wp");
+            return l;
+        };
+        v_pre_ = layer("conv_pre");
         for (int i = 0; i < 4; ++i) {
-            v_ups_[i] = ConvLayer{get("voc.ups." + std::to_string(i) + ".wp"), get("voc.ups." + std::to_string(i) + ".bias")};
+            v_ups_[i] = layer("ups." + std::to_string(i));
             for (int j = 0; j < 3; ++j)
                 for (int c = 0; c < 3; ++c) {
-                    const std::string p = "voc.rb." + std::to_string(i * 3 + j) + ".";
-                    v_c1_[i][j][c] = ConvLayer{get(p + "c1." + std::to_string(c) + ".wp"), get(p + "c1." + std::to_string(c) + ".bias")};
-                    v_c2_[i][j][c] = ConvLayer{get(p + "c2." + std::to_string(c) + ".wp"), get(p + "c2." + std::to_string(c) + ".bias")};
+                    const std::string p = "rb." + std::to_string(i * 3 + j) + ".";
+                    v_c1_[i][j][c] = layer(p + "c1." + std::to_string(c));
+                    v_c2_[i][j][c] = layer(p + "c2." + std::to_string(c));
                 }
         }
-        v_post_ = get("voc.conv_post.w");
+        v_post_ = W("voc.conv_post.w");
         voc_ready_ = true;
     }
     void conv(ConvArgs& a, int KS, int DIL, double tot_in, double tot_out) {
@@ -871,7 +884,10 @@ private:
             ev->bytes = 4.0 * (a.Cin * tot_in + a.Cout * tot_out * (1.0 + (a.res ? 1.0 : 0.0) + (a.mrf_mode >= 2 ? 1.0 : 0.0)));
             HIP_CHECK(hipEventRecord(ev->a, st_voc_));
         }
-        launch_conv1d(a, KS, DIL, st_voc_);
+        if (cfg_.vocoder_fp16)
+            launch_conv1d_f16(a, KS, DIL, st_voc_);
+        else
+            launch_conv1d(a, KS, DIL, st_voc_);
         if (prof) HIP_CHECK(hipEventRecord(ev->b, st_voc_));
     }
     void collect_conv_events() {
@@ -927,7 +943,7 @@ private:
         ConvArgs a{};
         a.base_len = d_len; a.B = B; a.cond_row = d_cond; a.cond_stride = kCondStride;
         // conv_pre (+ cond_layer)
-        a.x = v_z_.as<float>(); a.wp = v_pre_.wp; a.bias = v_pre_.bias; a.cond = condt; a.res = nullptr; a.mrf = nullptr;
+        a.x = v_z_.as<float>(); a.wp = v_pre_.wp; a.wp16 = v_pre_.wp16; a.bias = v_pre_.bias; a.cond = condt; a.res = nullptr; a.mrf = nullptr;
         a.out = v_s0_.as<float>(); a.len_mul = 1; a.Cin = 1024; a.Mtot = 512; a.Cout = 512;
         a.x_stride = (long)T; a.o_stride = (long)T; a.x_bstride = (long)(1024 * T); a.o_bstride = (long)(512 * T);
         a.padl = 3; a.slope = 1.0f; a.ups_s = 0; a.ups_p = 0; a.mrf_mode = 0; a.max_len = maxT;
@@ -943,7 +959,7 @@ private:
             // transposed conv as 2-tap polyphase conv over virtual channels co*s + r
             a = ConvArgs{};
             a.base_len = d_len; a.B = B; a.cond_row = d_cond; a.cond_stride = kCondStride;
-            a.x = in; a.wp = v_ups_[i].wp; a.bias = v_ups_[i].bias; a.cond = condt + cond_off; a.out = A;
+            a.x = in; a.wp = v_ups_[i].wp; a.wp16 = v_ups_[i].wp16; a.bias = v_ups_[i].bias; a.cond = condt + cond_off; a.out = A;
             a.len_mul = mul; a.Cin = Cin; a.Mtot = C * s; a.Cout = C;
             a.x_stride = Lin; a.x_bstride = (long)Cin * Lin; a.o_stride = Lout; a.o_bstride = (long)C * Lout;
             a.padl = 1; a.slope = 0.1f; a.ups_s = s; a.ups_p = (kern[i] - s) / 2; a.mrf_mode = 0; a.max_len = maxT * mul;
@@ -954,13 +970,13 @@ private:
                     const float* r = (c == 0) ? A : Cb;
                     ConvArgs b1{};
                     b1.base_len = d_len; b1.B = B;
-                    b1.x = r; b1.wp = v_c1_[i][j][c].wp; b1.bias = v_c1_[i][j][c].bias; b1.out = Bb;
+                    b1.x = r; b1.wp = v_c1_[i][j][c].wp; b1.wp16 = v_c1_[i][j][c].wp16; b1.bias = v_c1_[i][j][c].bias; b1.out = Bb;
                     b1.len_mul = mul_out; b1.Cin = C; b1.Mtot = C; b1.Cout = C;
                     b1.x_stride = Lout; b1.o_stride = Lout; b1.x_bstride = (long)C * Lout; b1.o_bstride = (long)C * Lout;
                     b1.padl = (rk[j] - 1) / 2 * rd[c]; b1.slope = 0.1f; b1.max_len = maxT * mul_out;
                     conv(b1, rk[j], rd[c], totT * mul_out, totT * mul_out);
                     ConvArgs b2 = b1;
-                    b2.x = Bb; b2.wp = v_c2_[i][j][c].wp; b2.bias = v_c2_[i][j][c].bias; b2.res = r;
+                    b2.x = Bb; b2.wp = v_c2_[i][j][c].wp; b2.wp16 = v_c2_[i][j][c].wp16; b2.bias = v_c2_[i][j][c].bias; b2.res = r;
                     b2.padl = (rk[j] - 1) / 2;
                     if (c < 2) {
                         b2.out = Cb;
@@ -1217,7 +1233,13 @@ int aur_dbg_conv1d(aur_engine* e, const float* x, const float* wp, const float* 
                    const int32_t* lens, int32_t B, int32_t Cin, int32_t Mtot, int32_t Cout, int32_t L, int32_t KS,
                    int32_t DIL, int32_t padl, float slope, int32_t ups_s, int32_t ups_p) {
     CHECK_PTR(e);
-    return guarded([&] { e->impl.dbg_conv1d(x, wp, bias, res, out, lens, B, Cin, Mtot, Cout, L, KS, DIL, padl, slope, ups_s, ups_p); });
+    return guarded([&] { e->impl.dbg_conv1d(x, wp, bias, res, out, lens, B, Cin, Mtot, Cout, L, KS, DIL, padl, slope, ups_s, ups_p, false); });
+}
+int aur_dbg_conv1d_f16(aur_engine* e, const float* x, const void* wp16, const float* bias, const float* res, float* out,
+                       const int32_t* lens, int32_t B, int32_t Cin, int32_t Mtot, int32_t Cout, int32_t L, int32_t KS,
+                       int32_t DIL, int32_t padl, float slope, int32_t ups_s, int32_t ups_p) {
+    CHECK_PTR(e);
+    return guarded([&] { e->impl.dbg_conv1d(x, wp16, bias, res, out, lens, B, Cin, Mtot, Cout, L, KS, DIL, padl, slope, ups_s, ups_p, true); });
 }
 int aur_dbg_prefill(aur_engine* e, const int32_t* text_ids, int32_t n_text, uint64_t speaker_key, float repetition_penalty,
                     float* lnf_rows_out, float* logits_out) {

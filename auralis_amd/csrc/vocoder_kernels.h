@@ -13,6 +13,7 @@ namespace aur {
 struct ConvArgs {
     const float* x;         // [B][Cin][x_stride]
     const float* wp;        // packed [Mtot/MT][Cin][KS][MT]
+    const void* wp16;       // fp16 variant: packed [Mtot/MT][Cin/16][KS][MT][16] halves
     const float* bias;      // [Cout] or nullptr
     const float* cond;      // cond[cond_row[b]*cond_stride + co] or nullptr (1x1 speaker conditioning, precomputed)
     const int* cond_row;    // [B] row of the conditioning table per utterance
@@ -34,6 +35,8 @@ struct ConvArgs {
 };
 
 void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st);
+// same contract on fp16 MFMA inputs (fp32 accumulate, fp32 activations in HBM); uses a.wp16
+void launch_conv1d_f16(const ConvArgs& a, int KS, int DIL, hipStream_t st);
 
 // z[b][c][j] = interp(interp(latents[b]^T, x4), x24000/22050)[c][j]   (hifigan_decoder.py:787-800)
 void launch_interp2(const float* lat, long lat_bstride, const int* lat_row, const int* n_lat, const int* base_len, float* z,

@@ -15,6 +15,71 @@
 
 namespace aur {
 
+// Shared epilogue of the MFMA conv kernels: bias, speaker conditioning, residual, MRF fold, masked store.
+// D layout of the 32x32 MFMAs: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+template <int WM, int WN, int MT, int NTW>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[WM][WN], int b, int mtile, int q0, int wv,
+                                              int l31, int hi, int len_in, int n_q) {
+    const long ob = (long)b * a.o_bstride;
+    const int len_out = a.ups_s ? len_in * a.ups_s : len_in;
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int v = mtile * MT + m * 32 + row;
+            int co, toff;
+            if (a.ups_s) {
+                co = v / a.ups_s;
+                toff = (v - co * a.ups_s) - a.ups_p;
+            } else {
+                co = v;
+                toff = 0;
+            }
+            float add = a.bias ? a.bias[co] : 0.f;
+            if (a.cond) add += a.cond[(long)a.cond_row[b] * a.cond_stride + co];
+#pragma unroll
+            for (int n = 0; n < WN; ++n) {
+                const int q = q0 + wv * NTW + n * 32 + l31;
+                const int t = a.ups_s ? q * a.ups_s + toff : q;
+                if (q < n_q && t >= 0 && t < len_out) {
+                    const long off = ob + (long)co * a.o_stride + t;
+                    float val = acc[m][n][r] + add;
+                    if (a.res) val += a.res[off];
+                    if (a.mrf_mode == 0) {
+                        a.out[off] = val;
+                    } else if (a.mrf_mode == 1) {
+                        a.mrf[off] = val;
+                    } else if (a.mrf_mode == 2) {
+                        a.mrf[off] = a.mrf[off] + val;
+                    } else {
+                        a.out[off] = (a.mrf[off] + val) / 3.0f;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// XCD-aware tile order shared by both conv kernels (see conv1d_mfma_kernel).
+__device__ __forceinline__ void conv_tile_order(int& mtile, int& ttile) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int L = blockIdx.x + gx * blockIdx.y;
+    const int g8 = (gx / 8) * 8;
+    if (gy == 1) {
+        mtile = 0;
+        ttile = L;
+    } else if (L < g8 * gy) {
+        const int xcd = L & 7, slot = L >> 3;
+        mtile = slot % gy;
+        ttile = (slot / gy) * 8 + xcd;
+    } else {
+        const int r = L - g8 * gy;
+        mtile = r % gy;
+        ttile = g8 + r / gy;
+    }
+}
+
 template <int KS, int DIL, int MT, int CK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void conv1d_mfma_kernel(ConvArgs a) {
     constexpr int WM = MT / 32;            // 32-row tiles per wave
@@ -34,23 +99,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     // gridDim.y co-tiles that read the SAME input window are mapped to ids that are 8 apart => same XCD/L2, adjacent
     // in time.  Pure speed choice; any mapping is correct.
     int mtile, ttile;
-    {
-        const int gx = gridDim.x, gy = gridDim.y;
-        const int L = blockIdx.x + gx * blockIdx.y;
-        const int g8 = (gx / 8) * 8;
-        if (gy == 1) {
-            mtile = 0;
-            ttile = L;
-        } else if (L < g8 * gy) {
-            const int xcd = L & 7, slot = L >> 3;
-            mtile = slot % gy;
-            ttile = (slot / gy) * 8 + xcd;
-        } else {
-            const int r = L - g8 * gy;
-            mtile = r % gy;
-            ttile = g8 + r / gy;
-        }
-    }
+    conv_tile_order(mtile, ttile);
     const int q0 = ttile * NT;
     const int len_in = a.base_len[b] * a.len_mul;
     const int n_q = a.ups_s ? len_in + 1 : len_in;   // polyphase needs q == len_in for the tail phases
@@ -146,46 +195,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         }
     }
 
-    // ---- epilogue
-    const long ob = (long)b * a.o_bstride;
-    const int len_out = a.ups_s ? len_in * a.ups_s : len_in;
-#pragma unroll
-    for (int m = 0; m < WM; ++m) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const int v = mtile * MT + m * 32 + row;
-            int co, toff;
-            if (a.ups_s) {
-                co = v / a.ups_s;
-                toff = (v - co * a.ups_s) - a.ups_p;
-            } else {
-                co = v;
-                toff = 0;
-            }
-            float add = a.bias ? a.bias[co] : 0.f;
-            if (a.cond) add += a.cond[(long)a.cond_row[b] * a.cond_stride + co];
-#pragma unroll
-            for (int n = 0; n < WN; ++n) {
-                const int q = q0 + wv * NTW + n * 32 + l31;
-                const int t = a.ups_s ? q * a.ups_s + toff : q;
-                if (q < n_q && t >= 0 && t < len_out) {
-                    const long off = ob + (long)co * a.o_stride + t;
-                    float val = acc[m][n][r] + add;
-                    if (a.res) val += a.res[off];
-                    if (a.mrf_mode == 0) {
-                        a.out[off] = val;
-                    } else if (a.mrf_mode == 1) {
-                        a.mrf[off] = val;
-                    } else if (a.mrf_mode == 2) {
-                        a.mrf[off] = a.mrf[off] + val;
-                    } else {
-                        a.out[off] = (a.mrf[off] + val) / 3.0f;
-                    }
-                }
-            }
-        }
-    }
+    conv_epilogue<WM, WN, MT, NTW>(a, acc, b, mtile, q0, wv, l31, hi, len_in, n_q);
 }
 
 template <int KS, int DIL, int MT, int CK>
@@ -221,6 +231,153 @@ void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
         case 11 * 16 + 3: launch_conv_mt<11, 3, 4>(a, st); break;
         case 11 * 16 + 5: launch_conv_mt<11, 5, 4>(a, st); break;
         default: throw HipError("launch_conv1d: unsupported (kernel,dilation)");
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp16-input / fp32-accumulate variant (v_mfma_f32_32x32x16_f16): same tiling and epilogue, activations stay fp32 in
+// HBM and are rounded to fp16 (RN) when they are staged into LDS.  One MFMA consumes 16 input channels of one tap:
+//   A[i = lane&31][k = 8*(lane>>5)+e] = W[co][ci0 + k]   (LDS rows [tap*MT + co][16 ch], 48-B row pitch)
+//   B[k][n = lane&31]                 = x[ci0 + k][t]     (LDS rows [t][16 ch], 48-B row pitch => conflict-free b128)
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+template <int KS, int DIL, int MT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void conv1d_mfma_f16_kernel(ConvArgs a) {
+    constexpr int CK = 16;
+    constexpr int WM = MT / 32;
+    constexpr int WN = (MT == 64) ? 2 : 4;
+    constexpr int NTW = 32 * WN;
+    constexpr int NT = 4 * NTW;
+    constexpr int HALO = (KS - 1) * DIL;
+    constexpr int XROW = NT + HALO;
+    constexpr int RS = 24;                                  // halves per LDS row: 16 data + 8 pad (48 B)
+    constexpr int XI = (XROW + 255) / 256;
+    constexpr int NW = KS * MT * 2;                         // 16-byte weight pieces per chunk
+    constexpr int WI = (NW + 255) / 256;
+    static_assert(WI <= 6, "weight staging registers");
+    __shared__ __attribute__((aligned(16))) _Float16 xs[XROW * RS];
+    __shared__ __attribute__((aligned(16))) _Float16 ws[WI * 128 * RS];   // >= KS*MT rows, whole 256-piece passes
+
+    const int b = blockIdx.z;
+    int mtile, ttile;
+    conv_tile_order(mtile, ttile);
+    const int q0 = ttile * NT;
+    const int len_in = a.base_len[b] * a.len_mul;
+    const int n_q = a.ups_s ? len_in + 1 : len_in;
+    if (q0 >= n_q) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const float* xb = a.x + (long)b * a.x_bstride;
+    const float slope = a.slope;
+    const uint4* wsrc_tile = reinterpret_cast<const uint4*>(a.wp16) + (long)mtile * (a.Cin / CK) * NW;
+
+    float xv[XI][CK];
+    uint4 w0, w1, w2, w3, w4, w5;
+    w0 = w1 = w2 = w3 = w4 = w5 = uint4{0, 0, 0, 0};
+#define AUR_WLD(i, reg) \
+    if constexpr ((i) < WI) reg = src[min(tid + (i) * 256, NW - 1)];
+#define AUR_WST(i, reg)                                                                     \
+    if constexpr ((i) < WI) {                                                                \
+        const int p = tid + (i) * 256;                                                      \
+        *reinterpret_cast<uint4*>(&ws[(p >> 1) * RS + (p & 1) * 8]) = reg;                  \
+    }
+    auto load_chunk = [&](int ci0) {
+        const uint4* src = wsrc_tile + (long)(ci0 / CK) * NW;
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            const int t = q0 - a.padl + tid + it * 256;
+            const int tc = min(max(t, 0), len_in - 1);
+#pragma unroll
+            for (int c = 0; c < CK; ++c) xv[it][c] = xb[(long)(ci0 + c) * a.x_stride + tc];
+        }
+        AUR_WLD(0, w0) AUR_WLD(1, w1) AUR_WLD(2, w2) AUR_WLD(3, w3) AUR_WLD(4, w4) AUR_WLD(5, w5)
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            const int i = tid + it * 256;
+            const int t = q0 - a.padl + i;
+            const bool ok = (t >= 0 && t < len_in);
+            h16x8 lo, hh;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                lo[c] = (_Float16)(ok ? lrelu(xv[it][c], slope) : 0.f);
+                hh[c] = (_Float16)(ok ? lrelu(xv[it][c + 8], slope) : 0.f);
+            }
+            if (i < XROW) {
+                *reinterpret_cast<h16x8*>(&xs[i * RS]) = lo;
+                *reinterpret_cast<h16x8*>(&xs[i * RS + 8]) = hh;
+            }
+        }
+        AUR_WST(0, w0) AUR_WST(1, w1) AUR_WST(2, w2) AUR_WST(3, w3) AUR_WST(4, w4) AUR_WST(5, w5)
+    };
+
+    load_chunk(0);
+    for (int ci0 = 0; ci0 < a.Cin; ci0 += CK) {
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+        if (ci0 + CK < a.Cin) load_chunk(ci0 + CK);
+        __builtin_amdgcn_sched_barrier(0);
+        const _Float16* xbase = &xs[(wv * NTW + l31) * RS + 8 * hi];
+        const _Float16* wbase = &ws[l31 * RS + 8 * hi];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            h16x8 av[WM], bv[WN];
+#pragma unroll
+            for (int m = 0; m < WM; ++m) av[m] = *reinterpret_cast<const h16x8*>(wbase + (j * MT + m * 32) * RS);
+#pragma unroll
+            for (int n = 0; n < WN; ++n) bv[n] = *reinterpret_cast<const h16x8*>(xbase + (j * DIL + n * 32) * RS);
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int n = 0; n < WN; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[m], bv[n], acc[m][n], 0, 0, 0);
+        }
+    }
+#undef AUR_WLD
+#undef AUR_WST
+    conv_epilogue<WM, WN, MT, NTW>(a, acc, b, mtile, q0, wv, l31, hi, len_in, n_q);
+}
+
+template <int KS, int DIL>
+static void launch_conv_f16_t(const ConvArgs& a, hipStream_t st) {
+    AUR_REQUIRE(a.Cin % 16 == 0 && a.wp16, "conv f16: Cin % 16, packed fp16 weights");
+    const int n_q = a.ups_s ? a.max_len + 1 : a.max_len;
+    trace_launch("conv1d_mfma_f16_kernel");
+    if (a.Mtot % 64 == 0) {
+        dim3 grid((n_q + 255) / 256, a.Mtot / 64, a.B);
+        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 64>), grid, dim3(256), 0, st, a);
+    } else {
+        AUR_REQUIRE(a.Mtot % 32 == 0, "conv f16: Mtot % 32");
+        dim3 grid((n_q + 511) / 512, a.Mtot / 32, a.B);
+        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 32>), grid, dim3(256), 0, st, a);
+    }
+}
+
+void launch_conv1d_f16(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
+    switch (KS * 16 + DIL) {
+        case 2 * 16 + 1: launch_conv_f16_t<2, 1>(a, st); break;
+        case 3 * 16 + 1: launch_conv_f16_t<3, 1>(a, st); break;
+        case 3 * 16 + 3: launch_conv_f16_t<3, 3>(a, st); break;
+        case 3 * 16 + 5: launch_conv_f16_t<3, 5>(a, st); break;
+        case 7 * 16 + 1: launch_conv_f16_t<7, 1>(a, st); break;
+        case 7 * 16 + 3: launch_conv_f16_t<7, 3>(a, st); break;
+        case 7 * 16 + 5: launch_conv_f16_t<7, 5>(a, st); break;
+        case 11 * 16 + 1: launch_conv_f16_t<11, 1>(a, st); break;
+        case 11 * 16 + 3: launch_conv_f16_t<11, 3>(a, st); break;
+        case 11 * 16 + 5: launch_conv_f16_t<11, 5>(a, st); break;
+        default: throw HipError("launch_conv1d_f16: unsupported (kernel,dilation)");
     }
     HIP_CHECK(hipGetLastError());
 }

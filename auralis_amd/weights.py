@@ -37,6 +37,22 @@ def pack_conv(w: Tensor) -> Tensor:
     return w.reshape(cout // mt, mt, cin, k).permute(0, 2, 3, 1).contiguous()
 
 
+def pack_conv_f16(w: Tensor) -> Tensor:
+    """Conv1d weight [Cout, Cin, k] -> fp16 [Cout/MT, Cin/16, k, MT, 16] (A fragments of v_mfma_f32_32x32x16_f16:
+    16 input channels of one tap per MFMA)."""
+    cout, cin, k = w.shape
+    mt = 64 if cout % 64 == 0 else 32
+    assert cout % mt == 0 and cin % 16 == 0
+    return w.reshape(cout // mt, mt, cin // 16, 16, k).permute(0, 2, 4, 1, 3).contiguous().to(torch.float16)
+
+
+def f16_as_f32_words(t: Tensor) -> np.ndarray:
+    """Reinterpret an fp16 tensor's bytes as float32 words (aur_load_weights moves opaque 4-byte words)."""
+    a = np.ascontiguousarray(t.numpy())
+    assert a.dtype == np.float16 and a.size % 2 == 0
+    return a.view(np.float32).reshape(-1)
+
+
 def polyphase_convT(w: Tensor, stride: int) -> Tensor:
     """ConvTranspose1d weight [Cin, Cout, k=2s] -> virtual Conv1d weight [Cout*s, Cin, 2]."""
     cin, cout, k = w.shape
@@ -57,7 +73,7 @@ def _effective(sd: Dict[str, Tensor], base: str) -> Tensor:
     return sd[base + "weight"].float()
 
 
-def pack_vocoder(xtts_sd: Dict[str, Tensor], upsample_rates=(8, 8, 2, 2)) -> Dict[str, np.ndarray]:
+def pack_vocoder(xtts_sd: Dict[str, Tensor], upsample_rates=(8, 8, 2, 2), fp16: bool = True) -> Dict[str, np.ndarray]:
     p = VOC_PREFIX
     out: Dict[str, Tensor] = {}
     out["voc.conv_pre.wp"] = pack_conv(_effective(xtts_sd, p + "conv_pre."))
@@ -78,7 +94,18 @@ def pack_vocoder(xtts_sd: Dict[str, Tensor], upsample_rates=(8, 8, 2, 2)) -> Dic
                 out[f"voc.rb.{n}.{tag}.{q}.wp"] = pack_conv(_effective(xtts_sd, base))
                 out[f"voc.rb.{n}.{tag}.{q}.bias"] = xtts_sd[base + "bias"].float()
     out["voc.conv_post.w"] = _effective(xtts_sd, p + "conv_post.").reshape(-1, 7)
-    return {k: np.ascontiguousarray(v.numpy(), dtype=np.float32) for k, v in out.items()}
+    res = {k: np.ascontiguousarray(v.numpy(), dtype=np.float32) for k, v in out.items()}
+    if fp16:
+        # fp16-input MFMA variant of every conv ("voc16.<layer>.wp"); biases/conditioning stay fp32
+        res["voc16.conv_pre.wp"] = f16_as_f32_words(pack_conv_f16(_effective(xtts_sd, p + "conv_pre.")))
+        for i, s in enumerate(upsample_rates):
+            res[f"voc16.ups.{i}.wp"] = f16_as_f32_words(pack_conv_f16(polyphase_convT(_effective(xtts_sd, p + f"ups.{i}."), s)))
+        for n in range(n_rb):
+            for grp, tag in (("convs1", "c1"), ("convs2", "c2")):
+                for q in range(3):
+                    res[f"voc16.rb.{n}.{tag}.{q}.wp"] = f16_as_f32_words(
+                        pack_conv_f16(_effective(xtts_sd, p + f"resblocks.{n}.{grp}.{q}.")))
+    return res
 
 
 def pack_gpt(gpt_sd: Dict[str, Tensor], xtts_sd: Dict[str, Tensor]) -> Dict[str, np.ndarray]:

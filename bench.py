@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
     ap.add_argument("--tokens", type=int, default=280, help="mel tokens per utterance (fixed-length mode)")
     ap.add_argument("--layers", type=int, default=30)
+    ap.add_argument("--vocoder", choices=["fp32", "fp16"], default="fp32",
+                    help="MFMA input type of the HiFi-GAN convs (fp32 accumulate either way; GPT is fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", action="store_true",
                     help="queue all steps at once so the vocoder of batch k overlaps the GPT of batch k+1 (measured "
@@ -106,7 +108,8 @@ def main():
     _log("building synthetic checkpoint")
     gpt_sd = make_synthetic_gpt(dims.gpt, seed=1234, n_layer=args.layers)
     xtts_sd = make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd)
-    eng = NativeEngine(n_layer=args.layers, max_seqs=args.batch, device=local_rank, profile=True)
+    eng = NativeEngine(n_layer=args.layers, max_seqs=args.batch, device=local_rank, profile=True,
+                       vocoder_fp16=(args.vocoder == "fp16"))
     eng.load_weights(pack_all(gpt_sd, xtts_sd))
     _log("weights resident")
 
@@ -178,7 +181,7 @@ def main():
             "metric": "audio_samples_per_s (64-way batch; rtf = wall_s / audio_s alongside)",
             "value": samples / dt, "unit": "audio-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.vocoder == "fp32" else "f32 (GPT) + f16-in/f32-acc MFMA (vocoder convs)", "data": "synthetic",
             "rtf": dt / audio_s, "audio_sec_per_wall_sec": audio_s / dt,
             "config": {"workload": f"{args.batch} concurrent 200-char utterances per GPU (70 text tokens -> "
                                    f"{args.tokens} mel tokens fixed-length -> {dims.voc.samples_for_latents(args.tokens)} "
@@ -186,6 +189,7 @@ def main():
                                    f"continuous batching; BASELINE.json configs[2]"
                                    + ("; consecutive steps pipelined (vocoder of batch k overlaps GPT of batch k+1)" if args.pipeline else ""),
                        "utterances_per_gpu": args.batch, "mel_tokens": args.tokens, "gpt_layers": args.layers,
+                       "vocoder_mfma_inputs": args.vocoder,
                        "parallelism": f"dp{world} (independent utterances, 1 RCCL broadcast of conditioning)"},
             "roofline": {
                 "kernel": "conv1d_mfma_kernel (HiFi-GAN convs, all instantiations; dominant kernel family)",

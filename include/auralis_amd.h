@@ -40,6 +40,8 @@ typedef struct aur_config {
     int32_t max_speakers;     /* speaker-conditioning table entries (0 = default 64) */
     int32_t vocoder_min_batch;/* hold finished sequences until this many are ready (0/1 = vocode at once) */
     int32_t profile;          /* 1 = record HIP events around the vocoder conv launches (aur_stats) */
+    int32_t vocoder_fp16;     /* 1 = HiFi-GAN convs on fp16-input / fp32-accumulate MFMA (needs the voc16.* tensors);
+                                 0 = exact-f32 MFMA parity mode */
 } aur_config;
 
 /* One named fp32 tensor.  Names are the packed names produced by auralis_amd/weights.py from the
@@ -147,6 +149,10 @@ int aur_dbg_layernorm(aur_engine* e, const float* h, const float* gamma, const f
 int aur_dbg_conv1d(aur_engine* e, const float* x, const float* wp, const float* bias, const float* res,
                    float* out, const int32_t* lens, int32_t B, int32_t Cin, int32_t Mtot, int32_t Cout,
                    int32_t L, int32_t KS, int32_t DIL, int32_t padl, float slope, int32_t ups_s, int32_t ups_p);
+/* Same on the fp16-input MFMA kernel; wp16 = packed halves [Mtot/MT][Cin/16][KS][MT][16] (auralis_amd/weights.py). */
+int aur_dbg_conv1d_f16(aur_engine* e, const float* x, const void* wp16, const float* bias, const float* res,
+                       float* out, const int32_t* lens, int32_t B, int32_t Cin, int32_t Mtot, int32_t Cout,
+                       int32_t L, int32_t KS, int32_t DIL, int32_t padl, float slope, int32_t ups_s, int32_t ups_p);
 /* Prefill one prompt and return ln_f rows [n_rows][1024] and the penalised logits [1026] of the last row. */
 int aur_dbg_prefill(aur_engine* e, const int32_t* text_ids, int32_t n_text, uint64_t speaker_key,
                     float repetition_penalty, float* lnf_rows_out, float* logits_out);

@@ -75,6 +75,49 @@ def test_conv1d_mfma(eng, cout, cin, k, d):
         assert np.all(got[bi, :, ln:] == 0.0)            # nothing written past the utterance
 
 
+@pytest.mark.parametrize("cout,cin,k,d", [(64, 32, 3, 1), (64, 32, 7, 3), (128, 64, 11, 5), (32, 32, 3, 5), (32, 32, 11, 1),
+                                          (64, 16, 7, 1)])
+def test_conv1d_mfma_f16(eng, cout, cin, k, d):
+    """fp16-input / fp32-accumulate variant: exact against a reference that rounds inputs and weights to fp16."""
+    g = torch.Generator().manual_seed(cout + cin * k + d)
+    B, L = 2, 900
+    lens = [900, 411]
+    w = torch.randn(cout, cin, k, generator=g) / (cin * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    x = torch.randn(B, cin, L, generator=g)
+    res = torch.randn(B, cout, L, generator=g)
+    pad = (k - 1) // 2 * d
+    wp16 = Wt.pack_conv_f16(w)
+    got = eng.dbg_conv1d_f16(x.numpy(), wp16.numpy(), b.numpy(), res.numpy(), lens, k, d, pad, 0.1, cout, cout)
+    w16 = w.to(torch.float16).float()
+    for bi, ln in enumerate(lens):
+        xa = F.leaky_relu(x[bi:bi + 1, :, :ln], 0.1).to(torch.float16).float()
+        ref = F.conv1d(xa.double(), w16.double(), b.double(), dilation=d, padding=pad)[0].float() + res[bi, :, :ln]
+        err = (torch.from_numpy(got[bi, :, :ln]) - ref).abs().max().item()
+        assert err < 3e-5 * max(1.0, ref.abs().max().item()), (bi, err)
+        full = F.conv1d(F.leaky_relu(x[bi:bi + 1, :, :ln], 0.1), w, b, dilation=d, padding=pad)[0] + res[bi, :, :ln]
+        assert (torch.from_numpy(got[bi, :, :ln]) - full).abs().max().item() < 2e-2      # fp16 rounding only
+        assert np.all(got[bi, :, ln:] == 0.0)
+
+
+def test_conv_transpose_polyphase_f16(eng):
+    g = torch.Generator().manual_seed(21)
+    cin, cout, s, k = 64, 32, 8, 16
+    B, L = 2, 300
+    lens = [300, 77]
+    w = torch.randn(cin, cout, k, generator=g) / (cin * k / s) ** 0.5
+    b = torch.randn(cout, generator=g)
+    x = torch.randn(B, cin, L, generator=g)
+    wv = Wt.polyphase_convT(w, s)
+    got = eng.dbg_conv1d_f16(x.numpy(), Wt.pack_conv_f16(wv).numpy(), b.numpy(), None, lens, 2, 1, 1, 0.1, cout, cout * s,
+                             ups_s=s, ups_p=(k - s) // 2)
+    for bi, ln in enumerate(lens):
+        xa = F.leaky_relu(x[bi:bi + 1, :, :ln], 0.1).to(torch.float16).float()
+        ref = F.conv_transpose1d(xa, w.to(torch.float16).float(), b, stride=s, padding=(k - s) // 2)[0]
+        err = (torch.from_numpy(got[bi, :, :ln * s]) - ref).abs().max().item()
+        assert err < 5e-5 * max(1.0, ref.abs().max().item()), (bi, err)
+
+
 @pytest.mark.parametrize("cin,cout,s,k", [(64, 32, 8, 16), (32, 32, 2, 4), (512, 256, 8, 16)])
 def test_conv_transpose_polyphase(eng, cin, cout, s, k):
     g = torch.Generator().manual_seed(cin + s)

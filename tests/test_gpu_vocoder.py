@@ -71,3 +71,36 @@ def test_vocoder_full_length_properties(ctx, dims):
     lat3[0, 200:] = 0.0
     w3 = e.vocode(lat3, None, SPK_KEY)[0]
     assert np.array_equal(w3[:100000], w1[:100000])
+
+
+# ---- fp16-input MFMA mode (fp32 accumulate, fp32 activations in HBM) ---------------------------------------------
+@pytest.fixture(scope="module")
+def ctx16():
+    e, gpt_sd, xtts_sd, cond, spk = make_engine(1, max_seqs=2, vocoder_fp16=True)
+    yield e, xtts_sd, spk
+    e.close()
+
+
+@pytest.mark.parametrize("path", GOLDEN)
+def test_vocoder_fp16_within_north_star_tolerance(ctx16, path):
+    """Reference golden waveform: <= 1e-3 RMS (north_star) and <= 1 % of the signal RMS with fp16 MFMA inputs."""
+    e, _, _ = ctx16
+    g = np.load(path)
+    wav = e.vocode(g["latents"], None, SPK_KEY)[0]
+    err, sig = _check(wav, g["wav"])
+    print(f"fp16 vocoder: rms err {err:.3e} signal rms {sig:.3e} ratio {err / sig:.3e}")
+
+
+def test_vocoder_fp16_full_length(ctx16, ctx, dims):
+    e16, xtts_sd, spk = ctx16
+    e32, _, _ = ctx
+    gen = torch.Generator().manual_seed(1)
+    lat = torch.randn(2, 280, 1024, generator=gen).numpy()
+    w16 = e16.vocode(lat, [280, 133], SPK_KEY)
+    w32 = e32.vocode(lat, [280, 133], SPK_KEY)
+    assert w16[0].shape == (312064,) and w16[1].shape == w32[1].shape
+    for a, b in zip(w16, w32):
+        assert np.isfinite(a).all() and np.abs(a).max() <= 1.0
+        err, sig = rms(a - b), rms(b)
+        assert err <= 1e-3 and err <= 1e-2 * sig, (err, sig)
+    assert np.array_equal(w16[0], e16.vocode(lat[:1], None, SPK_KEY)[0])       # deterministic, batch invariant
