@@ -243,7 +243,7 @@ void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 template <int KS, int DIL, int MT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void conv1d_mfma_f16_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void conv1d_mfma_f16_kernel(ConvArgs a) {
     constexpr int CK = 16;
     constexpr int WM = MT / 32;
     constexpr int WN = (MT == 64) ? 2 : 4;
@@ -321,13 +321,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         AUR_WST(0, w0) AUR_WST(1, w1) AUR_WST(2, w2) AUR_WST(3, w3) AUR_WST(4, w4) AUR_WST(5, w5)
     };
 
-    load_chunk(0);
+#ifndef AUR_F16_PREFETCH
+#define AUR_F16_PREFETCH 0
+#endif
+    if (AUR_F16_PREFETCH) load_chunk(0);
     for (int ci0 = 0; ci0 < a.Cin; ci0 += CK) {
+        if (!AUR_F16_PREFETCH) load_chunk(ci0);          // synchronous staging: fewer live registers, more waves per SIMD
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         store_chunk();
         __syncthreads();
-        if (ci0 + CK < a.Cin) load_chunk(ci0 + CK);
+        if (AUR_F16_PREFETCH && ci0 + CK < a.Cin) load_chunk(ci0 + CK);
         __builtin_amdgcn_sched_barrier(0);
         const _Float16* xbase = &xs[(wv * NTW + l31) * RS + 8 * hi];
         const _Float16* wbase = &ws[l31 * RS + 8 * hi];
