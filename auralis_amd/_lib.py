@@ -48,7 +48,9 @@ class aur_stats(C.Structure):
     _fields_ = [("steps", C.c_int64), ("prefill_rows", C.c_int64), ("decode_rows", C.c_int64),
                 ("tokens_generated", C.c_int64), ("samples_generated", C.c_int64), ("vocoder_batches", C.c_int64),
                 ("conv_launches", C.c_int64), ("conv_ms", C.c_double), ("conv_flops", C.c_double),
-                ("conv_bytes", C.c_double), ("vocoder_ms", C.c_double), ("gpt_ms", C.c_double),
+                ("conv_bytes", C.c_double), ("gemm_launches", C.c_int64), ("gemm_ms", C.c_double), ("gemm_ms_raw", C.c_double),
+                ("event_pair_overhead_ms", C.c_double), ("gemm_flops", C.c_double),
+                ("gemm_bytes", C.c_double), ("vocoder_ms", C.c_double), ("gpt_ms", C.c_double),
                 ("kv_blocks_total", C.c_int64), ("kv_blocks_free", C.c_int64)]
 
     def as_dict(self) -> Dict[str, float]:

@@ -50,7 +50,7 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
     # ------------------------------------------------------------------ construction
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path: str, max_concurrency: int = 10, device: int = 0,
-                        **kwargs) -> "XTTSv2Engine":
+                        vocoder: str = "fp16", **kwargs) -> "XTTSv2Engine":
         """Load a checkpoint directory in the reference's on-disk format (checkpoint.py docstring).  kwargs the
         reference forwards to vLLM (tensor_parallel_size, pipeline_parallel_size, gpt_model, torch_dtype, device_map;
         XTTSv2.py:235-243) are accepted; tp/pp other than 1 are rejected (the path shards by utterance)."""
@@ -61,7 +61,10 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
             raise ValueError("the MI355X path replicates the 0.4 B-parameter model per GPU; use one engine per GPU")
         gpt_sd, xtts_sd = load_checkpoint(pretrained_model_name_or_path)
         n_layer = 1 + max(int(k.split(".")[2]) for k in gpt_sd if k.startswith("gpt.h."))
-        native = NativeEngine(n_layer=n_layer, max_seqs=max(1, max_concurrency), device=device)
+        # vocoder="fp16": HiFi-GAN convs on fp16-input / fp32-accumulate MFMA (waveform within 1e-5 RMS of the fp32
+        # path, the reference's own GPU path autocasts to fp16); vocoder="fp32": exact-f32 MFMA parity mode
+        native = NativeEngine(n_layer=n_layer, max_seqs=max(1, max_concurrency), device=device,
+                              vocoder_fp16=(vocoder == "fp16"))
         native.load_weights(pack_all(gpt_sd, xtts_sd))
         tok_file = None
         for cand in ("tokenizer.json", os.path.join("gpt", "tokenizer.json")):

@@ -184,6 +184,8 @@ public:
         ws_[0].st = st_;
         ws_[1].st = st2_;
         if (const char* e = getenv("AUR_DECODE_STREAMS")) decode_streams_ = atoi(e);
+        if (const char* e = getenv("AUR_DECODE_GRAPH")) decode_graph_ = atoi(e) != 0;
+        HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
         HIP_CHECK(hipEventCreate(&ev_a_));
         HIP_CHECK(hipEventCreate(&ev_b_));
         HIP_CHECK(hipStreamSynchronize(st_));
@@ -192,12 +194,15 @@ public:
         (void)hipSetDevice(device_);
         (void)hipStreamSynchronize(st_);
         (void)hipStreamSynchronize(st_voc_);
-        for (auto& e : conv_events_) {
-            (void)hipEventDestroy(e.a);
-            (void)hipEventDestroy(e.b);
-        }
+        for (auto* v : {&conv_events_, &gemm_events_})
+            for (auto& e : *v) {
+                (void)hipEventDestroy(e.a);
+                (void)hipEventDestroy(e.b);
+            }
         (void)hipEventDestroy(ev_a_);
         (void)hipEventDestroy(ev_b_);
+        if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+        (void)hipEventDestroy(ev_fork_);
         (void)hipEventDestroy(ev_ws1_);
         (void)hipEventDestroy(ev_lat_);
         (void)hipEventDestroy(ev_voc_done_);
@@ -364,11 +369,14 @@ public:
         for (int i = 0; i < cfg_.max_seqs; ++i)
             if (slot_owner_[i] && slot_owner_[i]->state == SeqState::RUNNING) active.push_back(i);
         if (!active.empty()) {
+            gemm_prof_now_ = cfg_.profile != 0 && !decode_graph_ && (decode_step_count_++ % 16 == 0);
             decode(active);
+            gemm_prof_now_ = false;
             worked = true;
         }
         HIP_CHECK(hipEventRecord(ev_b_, st_));
         HIP_CHECK(hipStreamSynchronize(st_));
+        collect_gemm_events();
         if (worked) {
             float ms = 0.f;
             HIP_CHECK(hipEventElapsedTime(&ms, ev_a_, ev_b_));
@@ -645,6 +653,7 @@ private:
     }
     void ensure_rows(RowWs& w, int M) {
         if (M <= w.rows_cap) return;
+        graph_active_.clear();   // buffers move: a captured decode graph is stale
         const int cap = std::max(M, 64);
         w.h.ensure((size_t)cap * kHidden * 4);
         w.xn.ensure((size_t)cap * kHidden * 4);
@@ -659,6 +668,59 @@ private:
         w.i_desc.ensure((size_t)cap * sizeof(int4));
         w.rows_cap = cap;
     }
+    // profile mode: HIP-event pairs around the GEMM launches of every 16th decode step (sampled: 121 per step)
+    void gemm(RowWs& w, const float* X, int ldx, const float* Wm, float* P, int M, int N, int K, const GemmPlan& pl) {
+        if (!gemm_prof_now_) {
+            launch_gemm_splitk(X, ldx, Wm, P, M, N, K, pl, w.st);
+            return;
+        }
+        if (n_gemm_events_ == gemm_events_.size()) {
+            ConvEvent e{};
+            HIP_CHECK(hipEventCreate(&e.a));
+            HIP_CHECK(hipEventCreate(&e.b));
+            gemm_events_.push_back(e);
+        }
+        ConvEvent& ev = gemm_events_[n_gemm_events_++];
+        ev.flops = 2.0 * M * N * K;
+        ev.bytes = 4.0 * ((double)K * N + (double)M * K + (double)pl.slabs * M * N);
+        HIP_CHECK(hipEventRecord(ev.a, w.st));
+        launch_gemm_splitk(X, ldx, Wm, P, M, N, K, pl, w.st);
+        HIP_CHECK(hipEventRecord(ev.b, w.st));
+    }
+    // Fixed cost of one HIP-event pair on an otherwise busy stream: recording events between back-to-back short
+    // kernels serialises their launch processing, which inflates a ~12 us kernel by ~3 us.  Measured once as the
+    // median elapsed time of 64 empty pairs and subtracted from every sampled GEMM interval (reported in aur_stats).
+    float event_pair_overhead_ms() {
+        if (event_overhead_ms_ >= 0.f) return event_overhead_ms_;
+        std::vector<hipEvent_t> ev(128);
+        for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+        for (int i = 0; i < 64; ++i) {
+            HIP_CHECK(hipEventRecord(ev[2 * i], st_));
+            HIP_CHECK(hipEventRecord(ev[2 * i + 1], st_));
+        }
+        HIP_CHECK(hipStreamSynchronize(st_));
+        std::vector<float> d(64);
+        for (int i = 0; i < 64; ++i) HIP_CHECK(hipEventElapsedTime(&d[i], ev[2 * i], ev[2 * i + 1]));
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        std::sort(d.begin(), d.end());
+        event_overhead_ms_ = d[32];
+        return event_overhead_ms_;
+    }
+    void collect_gemm_events() {
+        const float ovh = n_gemm_events_ ? event_pair_overhead_ms() : 0.f;
+        if (n_gemm_events_) stats_.event_pair_overhead_ms = ovh;
+        for (size_t i = 0; i < n_gemm_events_; ++i) {
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, gemm_events_[i].a, gemm_events_[i].b));
+            stats_.gemm_ms_raw += ms;
+            ms = std::max(0.f, ms - ovh);
+            stats_.gemm_ms += ms;
+            stats_.gemm_flops += gemm_events_[i].flops;
+            stats_.gemm_bytes += gemm_events_[i].bytes;
+            stats_.gemm_launches++;
+        }
+        n_gemm_events_ = 0;
+    }
     void forward_rows(RowWs& w, int M, const int* d_row_slot, const int* d_row_pos) {
         float* h = w.h.as<float>();
         float* xn = w.xn.as<float>();
@@ -671,14 +733,14 @@ private:
         for (int l = 0; l < cfg_.n_layer; ++l) {
             const LayerW& L = layers_[l];
             float* kvl = kv_.as<float>() + (long)l * kv_layer_stride_;
-            launch_gemm_splitk(xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, p1, w.st);
+            gemm(w, xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, p1);
             launch_qkv_epilogue(P, S1, L.bqkv, w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, w.st);
             launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st);
-            launch_gemm_splitk(w.att.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, p1, w.st);
+            gemm(w, w.att.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, p1);
             launch_rows_ln(P, S1, L.bproj, h, L.ln2w, L.ln2b, xn, M, 1e-5f, w.st);
-            launch_gemm_splitk(xn, kHidden, L.wfc, P, M, 4 * kHidden, kHidden, p1, w.st);
+            gemm(w, xn, kHidden, L.wfc, P, M, 4 * kHidden, kHidden, p1);
             launch_bias_gelu(P, S1, L.bfc, w.act.as<float>(), M, 4 * kHidden, w.st);
-            launch_gemm_splitk(w.act.as<float>(), 4 * kHidden, L.wproj2, P, M, kHidden, 4 * kHidden, p4, w.st);
+            gemm(w, w.act.as<float>(), 4 * kHidden, L.wproj2, P, M, kHidden, 4 * kHidden, p4);
             const bool last = (l + 1 == cfg_.n_layer);
             launch_rows_ln(P, S4, L.bproj2, h, last ? lnfw_ : layers_[l + 1].ln1w, last ? lnfb_ : layers_[l + 1].ln1b,
                            xn, M, 1e-5f, w.st);
@@ -701,30 +763,41 @@ private:
         return a;
     }
     // final_norm -> latent stash -> mel_head GEMM -> fused sampler -> read back tokens/finished flags
-    void sample_launch(RowWs& w, const std::vector<int>& sample_row, const std::vector<int>& sample_slot,
+    // final_norm -> latent stash -> mel_head GEMM -> fused sampler, in three parts so that the kernel part can be
+    // captured in a hipGraph: (1) host->device index uploads, (2) kernels only, (3) token / finished-flag read-back.
+    void sample_upload(RowWs& w, const std::vector<int>& sample_row, const std::vector<int>& sample_slot,
                        const std::vector<int>* next_kvpos) {
         const int Ms = (int)sample_slot.size();
         w.pin.ensure(((size_t)cfg_.max_seqs * 2 + 16) * sizeof(int));
-        w.i_sample_row.ensure((size_t)Ms * 4);
-        w.i_sample_slot.ensure((size_t)Ms * 4);
-        w.i_next_kvpos.ensure((size_t)Ms * 4);
-        w.i_out_tok.ensure((size_t)Ms * 4);
+        w.i_sample_row.ensure((size_t)std::max(Ms, 64) * 4);
+        w.i_sample_slot.ensure((size_t)std::max(Ms, 64) * 4);
+        w.i_next_kvpos.ensure((size_t)std::max(Ms, 64) * 4);
+        w.i_out_tok.ensure((size_t)std::max(Ms, 64) * 4);
         w.ybuf.ensure((size_t)std::max(Ms, 64) * kHidden * 4);
         w.P2.ensure((size_t)4 * std::max(Ms, 64) * kHeadPad * 4);
         HIP_CHECK(hipMemcpyAsync(w.i_sample_row.p, sample_row.data(), (size_t)Ms * 4, hipMemcpyHostToDevice, w.st));
         HIP_CHECK(hipMemcpyAsync(w.i_sample_slot.p, sample_slot.data(), (size_t)Ms * 4, hipMemcpyHostToDevice, w.st));
         if (next_kvpos)
             HIP_CHECK(hipMemcpyAsync(w.i_next_kvpos.p, next_kvpos->data(), (size_t)Ms * 4, hipMemcpyHostToDevice, w.st));
+    }
+    void sample_kernels(RowWs& w, int Ms, bool has_next_kvpos) {
         launch_final_norm(w.xn.as<float>(), w.i_sample_row.as<int>(), w.i_sample_slot.as<int>(), fnw_, fnb_, w.ybuf.as<float>(),
                           latents_.as<float>(), (long)kMaxLatRows * kHidden, slot_ngen_.as<int>(), kMaxLatRows, Ms, 1e-5f, w.st);
         const GemmPlan ph = gemm_plan(Ms, kHidden);
-        const int S = ph.slabs;
-        launch_gemm_splitk(w.ybuf.as<float>(), kHidden, headT_, w.P2.as<float>(), Ms, kHeadPad, kHidden, ph, w.st);
-        SamplerArgs a = sampler_args(w, w.P2.as<float>(), S, Ms, kHeadPad, headb_, next_kvpos ? w.i_next_kvpos.as<int>() : nullptr);
+        gemm(w, w.ybuf.as<float>(), kHidden, headT_, w.P2.as<float>(), Ms, kHeadPad, kHidden, ph);
+        SamplerArgs a = sampler_args(w, w.P2.as<float>(), ph.slabs, Ms, kHeadPad, headb_, has_next_kvpos ? w.i_next_kvpos.as<int>() : nullptr);
         launch_sampler(a, w.st);
+    }
+    void sample_readback(RowWs& w, int Ms, hipStream_t st) {
         int* pin = w.pin.as<int>();
-        HIP_CHECK(hipMemcpyAsync(pin, w.i_out_tok.p, (size_t)Ms * 4, hipMemcpyDeviceToHost, w.st));
-        HIP_CHECK(hipMemcpyAsync(pin + cfg_.max_seqs, slot_finished_.p, (size_t)cfg_.max_seqs * 4, hipMemcpyDeviceToHost, w.st));
+        HIP_CHECK(hipMemcpyAsync(pin, w.i_out_tok.p, (size_t)Ms * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(pin + cfg_.max_seqs, slot_finished_.p, (size_t)cfg_.max_seqs * 4, hipMemcpyDeviceToHost, st));
+    }
+    void sample_launch(RowWs& w, const std::vector<int>& sample_row, const std::vector<int>& sample_slot,
+                       const std::vector<int>* next_kvpos) {
+        sample_upload(w, sample_row, sample_slot, next_kvpos);
+        sample_kernels(w, (int)sample_slot.size(), next_kvpos != nullptr);
+        sample_readback(w, (int)sample_slot.size(), w.st);
     }
     // after the stream has been synchronised: append tokens, retire finished sequences
     void sample_collect(RowWs& w, const std::vector<int>& sample_slot) {
@@ -768,6 +841,7 @@ private:
     }
     void prefill(const std::vector<Seq*>& seqs) {
         RowWs& w = ws_[0];
+        graph_active_.clear();   // prefill reuses chain 0's index buffers: the decode graph's inputs must be re-uploaded
         std::vector<int4> desc;
         std::vector<int> row_slot, row_pos, sample_row, sample_slot, next_kvpos;
         std::vector<SlotInit> init;
@@ -812,30 +886,72 @@ private:
         HIP_CHECK(hipStreamSynchronize(w.st));
         sample_collect(w, sample_slot);
     }
-    // One decode step.  With two streams the live sequences are split in halves whose kernels overlap: the M = 32..64
-    // GEMMs are latency bound (one 64x64x256 tile per CU), so a second independent chain fills the idle CUs and the
-    // bandwidth-bound attention of one half runs beside the MFMA-bound GEMMs of the other.
+    // One decode step.  The kernel chain of a step (embed -> 30 layers -> final_norm -> head GEMM -> sampler, ~250
+    // launches) depends only on device-resident state, so it is captured once per live-set shape in a hipGraph and
+    // replayed while the set of live slots is unchanged; only the token / finished read-back stays outside.
+    // AUR_DECODE_STREAMS=2 splits the live sequences into two chains on two streams inside the graph (the M = 32
+    // GEMMs are latency bound, the attention is bandwidth bound: the chains fill each other's gaps).
+    void decode_kernels(RowWs& w, int Mk) {
+        launch_embed_decode(w.i_row_slot.as<int>(), slot_tok_.as<int>(), slot_pos_.as<int>(), wte_, wpe_, w.h.as<float>(), Mk, w.st);
+        forward_rows(w, Mk, w.i_row_slot.as<int>(), nullptr);
+        sample_kernels(w, Mk, false);
+    }
     void decode(const std::vector<int>& active) {
         const int M = (int)active.size();
         const int n_ws = (decode_streams_ >= 2 && M >= 16) ? 2 : 1;
-        for (int k = 0; k < n_ws; ++k) {
-            RowWs& w = ws_[k];
-            const int lo = (int)((long)M * k / n_ws), hi = (int)((long)M * (k + 1) / n_ws);
-            w.sample_slot.assign(active.begin() + lo, active.begin() + hi);
-            const int Mk = hi - lo;
-            w.sample_row.resize(Mk);
-            for (int i = 0; i < Mk; ++i) w.sample_row[i] = i;
-            ensure_rows(w, Mk);
-            HIP_CHECK(hipMemcpyAsync(w.i_row_slot.p, w.sample_slot.data(), (size_t)Mk * 4, hipMemcpyHostToDevice, w.st));
-            launch_embed_decode(w.i_row_slot.as<int>(), slot_tok_.as<int>(), slot_pos_.as<int>(), wte_, wpe_, w.h.as<float>(), Mk, w.st);
-            forward_rows(w, Mk, w.i_row_slot.as<int>(), nullptr);
-            sample_launch(w, w.sample_row, w.sample_slot, nullptr);
+        const bool same_set = (active == graph_active_ && n_ws == graph_n_ws_);
+        if (!same_set) {
+            for (int k = 0; k < n_ws; ++k) {
+                RowWs& w = ws_[k];
+                const int lo = (int)((long)M * k / n_ws), hi = (int)((long)M * (k + 1) / n_ws);
+                w.sample_slot.assign(active.begin() + lo, active.begin() + hi);
+                const int Mk = hi - lo;
+                w.sample_row.resize(Mk);
+                for (int i = 0; i < Mk; ++i) w.sample_row[i] = i;
+                ensure_rows(w, Mk);
+                HIP_CHECK(hipMemcpyAsync(w.i_row_slot.p, w.sample_slot.data(), (size_t)Mk * 4, hipMemcpyHostToDevice, st_));
+                sample_upload(w, w.sample_row, w.sample_slot, nullptr);
+            }
+            HIP_CHECK(hipStreamSynchronize(st_));
+            HIP_CHECK(hipStreamSynchronize(st2_));
+            graph_active_.clear();   // any cached graph was captured for another live set / other buffers
         }
-        if (n_ws == 2) {   // make the main stream (and its timing event) wait for the second chain
-            HIP_CHECK(hipEventRecord(ev_ws1_, ws_[1].st));
-            HIP_CHECK(hipStreamWaitEvent(ws_[0].st, ev_ws1_, 0));
+        const bool use_graph = decode_graph_ && !debug_sync();
+        if (use_graph && (!same_set || !graph_exec_)) {
+            if (graph_exec_) {
+                HIP_CHECK(hipGraphExecDestroy(graph_exec_));
+                graph_exec_ = nullptr;
+            }
+            hipGraph_t g = nullptr;
+            HIP_CHECK(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
+            if (n_ws == 2) {
+                HIP_CHECK(hipEventRecord(ev_fork_, st_));
+                HIP_CHECK(hipStreamWaitEvent(st2_, ev_fork_, 0));
+            }
+            for (int k = 0; k < n_ws; ++k) decode_kernels(ws_[k], (int)ws_[k].sample_slot.size());
+            if (n_ws == 2) {
+                HIP_CHECK(hipEventRecord(ev_ws1_, st2_));
+                HIP_CHECK(hipStreamWaitEvent(st_, ev_ws1_, 0));
+            }
+            HIP_CHECK(hipStreamEndCapture(st_, &g));
+            HIP_CHECK(hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0));
+            HIP_CHECK(hipGraphDestroy(g));
+            graph_active_ = active;
+            graph_n_ws_ = n_ws;
         }
-        for (int k = 0; k < n_ws; ++k) HIP_CHECK(hipStreamSynchronize(ws_[k].st));
+        if (use_graph) {
+            HIP_CHECK(hipGraphLaunch(graph_exec_, st_));
+        } else {
+            for (int k = 0; k < n_ws; ++k) decode_kernels(ws_[k], (int)ws_[k].sample_slot.size());
+            if (n_ws == 2) {
+                HIP_CHECK(hipEventRecord(ev_ws1_, st2_));
+                HIP_CHECK(hipStreamWaitEvent(st_, ev_ws1_, 0));
+            }
+            graph_active_ = active;
+            graph_n_ws_ = n_ws;
+        }
+        for (int k = 0; k < n_ws; ++k) sample_readback(ws_[k], (int)ws_[k].sample_slot.size(), st_);
+        HIP_CHECK(hipStreamSynchronize(st_));
         for (int k = 0; k < n_ws; ++k) sample_collect(ws_[k], ws_[k].sample_slot);
         stats_.decode_rows += M;
     }
@@ -1088,6 +1204,12 @@ private:
     int voc_max_samples_ = 0;
     bool voc_active_ = false;
     PinBuf voc_pin_;
+    bool decode_graph_ = false;         // AUR_DECODE_GRAPH=1: hipGraph replay of the decode step (measured neutral: the
+                                        // step is GPU-bound, and re-capturing on every live-set change costs)
+    hipGraphExec_t graph_exec_ = nullptr;
+    std::vector<int> graph_active_;
+    int graph_n_ws_ = 0;
+    hipEvent_t ev_fork_ = nullptr;
     int decode_streams_ = 1;   // 2 measured slower on MI355X (host launch bound without graphs); kept for A/B via AUR_DECODE_STREAMS
     hipStream_t st2_ = nullptr;
     hipEvent_t ev_ws1_ = nullptr;
@@ -1099,6 +1221,11 @@ private:
     const float* v_post_ = nullptr;
     DevBuf v_meta_, v_z_, v_s0_, v_A_, v_B_, v_C_, v_D_, v_E_, tmp_lat_, tmp_wav_;
     std::vector<ConvEvent> conv_events_;
+    std::vector<ConvEvent> gemm_events_;
+    size_t n_gemm_events_ = 0;
+    bool gemm_prof_now_ = false;
+    long decode_step_count_ = 0;
+    float event_overhead_ms_ = -1.f;
     std::vector<int> h_meta_;
     size_t n_conv_events_ = 0;
     // sequences

@@ -35,7 +35,7 @@ def _log(msg: str):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, n_tokens: int, budget_s: float = 20.0):
+def cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, n_tokens: int, budget_s: float = 30.0):
     """Time the CPU oracle (kind 'port') on a bounded sample of the same workload: ONE utterance, greedy,
     up to n_tokens mel tokens (prefill + decode + literal second pass + vocoder).  The decode loop stops early
     when `budget_s` is used up, so the leg is bounded whatever the host looks like."""
@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
     ap.add_argument("--tokens", type=int, default=280, help="mel tokens per utterance (fixed-length mode)")
     ap.add_argument("--layers", type=int, default=30)
-    ap.add_argument("--vocoder", choices=["fp32", "fp16"], default="fp32",
+    ap.add_argument("--vocoder", choices=["fp32", "fp16"], default="fp16",
                     help="MFMA input type of the HiFi-GAN convs (fp32 accumulate either way; GPT is fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", action="store_true",
@@ -168,15 +168,47 @@ def main():
     if rank == 0:
         audio_s = samples / 24000.0
         conv_s = st["conv_ms"] * 1e-3
-        n_launch = max(1, st["conv_launches"])
+        n_conv = max(1, st["conv_launches"])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.isfile(tpath):
             try:
-                traffic = json.load(open(tpath)).get("conv1d_mfma_kernel_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(f"conv_{args.vocoder}_bytes_per_launch")
             except Exception:
                 traffic = None
-        ach_gbps = st["conv_bytes"] / conv_s / 1e9 if conv_s > 0 else 0.0
+        conv_kernel = "conv1d_mfma_f16_kernel" if args.vocoder == "fp16" else "conv1d_mfma_kernel"
+        conv_gbps = st["conv_bytes"] / conv_s / 1e9 if conv_s > 0 else 0.0
+        conv_tflops = st["conv_flops"] / conv_s / 1e12 if conv_s > 0 else 0.0
+        roof_conv = {
+            "kernel": f"{conv_kernel} (HiFi-GAN convs, all instantiations)",
+            "bound": "hbm", "achieved": conv_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": conv_gbps / HBM_PEAK_GBPS,
+            "traffic": traffic, "avg_launch_ms": st["conv_ms"] / n_conv, "launches": st["conv_launches"],
+            "algorithmic_bytes_per_launch": st["conv_bytes"] / n_conv, "total_ms_in_timed_region": st["conv_ms"],
+            "mfma": {"achieved": conv_tflops, "unit": "TFLOP/s",
+                     "peak": FP32_MFMA_PEAK_TFLOPS if args.vocoder == "fp32" else 2500.0,
+                     "frac": conv_tflops / (FP32_MFMA_PEAK_TFLOPS if args.vocoder == "fp32" else 2500.0)},
+        }
+        # decode GEMMs: HIP-event pairs around every launch of each 16th decode step (sampled)
+        # `achieved` uses the RAW event intervals (kernel + dispatch latency exposed by the event records: conservative);
+        # the empty-event-pair overhead and the overhead-corrected average are reported next to it, and the rocprofv3
+        # per-kernel average (pure execution time) is in profiles/.
+        gemm_s = st["gemm_ms_raw"] * 1e-3
+        n_gemm = max(1, st["gemm_launches"])
+        gemm_gbps = st["gemm_bytes"] / gemm_s / 1e9 if gemm_s > 0 else 0.0
+        gemm_tflops = st["gemm_flops"] / gemm_s / 1e12 if gemm_s > 0 else 0.0
+        est_gemm_total_ms = (st["gemm_ms"] / n_gemm) * 121.0 * max(0, st["steps"] - args.steps)   # overhead-corrected
+        roof_gemm = {
+            "kernel": "gemm_splitk_kernel<false> (decode QKV / proj / FC / proj2 / mel-head, M = live sequences)",
+            "bound": "hbm", "achieved": gemm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gemm_gbps / HBM_PEAK_GBPS,
+            "traffic": None, "avg_launch_ms": st["gemm_ms_raw"] / n_gemm, "avg_launch_ms_minus_event_overhead": st["gemm_ms"] / n_gemm,
+            "event_pair_overhead_ms": st["event_pair_overhead_ms"], "launches_sampled": st["gemm_launches"],
+            "algorithmic_bytes_per_launch": st["gemm_bytes"] / n_gemm, "total_ms_in_timed_region_est": est_gemm_total_ms,
+            "mfma": {"achieved": gemm_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": gemm_tflops / FP32_MFMA_PEAK_TFLOPS},
+            "note": "weights stream once per step (HBM) but at M = 64 exact-f32 MFMA time is of the same order; per-launch "
+                    "latency dominates (one 64x64x256 tile per CU)",
+        }
+        dominant, other = (roof_gemm, roof_conv) if est_gemm_total_ms > st["conv_ms"] else (roof_conv, roof_gemm)
         line = {
             "metric": "audio_samples_per_s (64-way batch; rtf = wall_s / audio_s alongside)",
             "value": samples / dt, "unit": "audio-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -191,17 +223,8 @@ def main():
                        "utterances_per_gpu": args.batch, "mel_tokens": args.tokens, "gpt_layers": args.layers,
                        "vocoder_mfma_inputs": args.vocoder,
                        "parallelism": f"dp{world} (independent utterances, 1 RCCL broadcast of conditioning)"},
-            "roofline": {
-                "kernel": "conv1d_mfma_kernel (HiFi-GAN convs, all instantiations; dominant kernel family)",
-                "bound": "hbm", "achieved": ach_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": ach_gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                "avg_launch_ms": st["conv_ms"] / n_launch, "launches": st["conv_launches"],
-                "algorithmic_bytes_per_launch": st["conv_bytes"] / n_launch,
-                "note": "north_star grades the vocoder against HBM; with exact-f32 MFMA it is ALU-bound: see mfma_f32",
-                "mfma_f32": {"achieved": st["conv_flops"] / conv_s / 1e12 if conv_s > 0 else 0.0,
-                             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": (st["conv_flops"] / conv_s / 1e12 / FP32_MFMA_PEAK_TFLOPS) if conv_s > 0 else 0.0},
-            },
+            "roofline": dominant,
+            "roofline_second_kernel": other,
             "breakdown_ms_per_step": {"gpt": st["gpt_ms"] / args.steps, "vocoder": st["vocoder_ms"] / args.steps,
                                       "vocoder_convs": st["conv_ms"] / args.steps,
                                       "gpt_ms_per_decode_step": st["gpt_ms"] / max(1, st["steps"])},
