@@ -1,18 +1,15 @@
 #!/bin/bash
 # PMC passes (one counter group per run, as the microarch guide prescribes) restricted to the vocoder conv kernels.
-# usage: tools/pmc.sh <tag> ; outputs gpurun_out/pmc_<tag>/{fetch,write}/*counter_collection.csv
+# usage: tools/pmc.sh <tag> [bench args]; outputs gpurun_out/pmc_<tag>/{fetch,write,util}/*counter_collection.csv
 exec < /dev/null
-TAG=${1:-r01}
+TAG=${1:-r01}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "util SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "util SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   set -- $pass; name=$1; shift
   OUT=$R/gpurun_out/pmc_$TAG/$name
   mkdir -p $OUT
-  timeout ${PMC_TIMEOUT:-200} rocprofv3 --pmc "$@" --kernel-include-regex "conv1d_mfma" --output-format csv -d $OUT -o pmc -- \
-      python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/stdout.log 2>&1
+  timeout ${PMC_TIMEOUT:-150} rocprofv3 --pmc "$@" --kernel-include-regex "${PMC_KERNELS:-conv1d_mfma}" --output-format csv -d $OUT -o pmc -- \
+      python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline $PMC_BENCH_ARGS > $OUT/stdout.log 2>&1
   echo "pass $name rc=$?"
-  ls $OUT | head -5
-  f=$(find $OUT -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then head -3 "$f" | cut -c1-400; wc -l "$f"; fi
 done
