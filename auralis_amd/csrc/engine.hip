@@ -132,6 +132,7 @@ struct Seq {
     std::vector<float> wav;
     std::vector<float> latents;
     int pool_idx = -1;   // latent-pool entry once the tokens are done (vocoder stage)
+    bool shared_prefix = false;
     int error = 0;
 };
 
@@ -151,7 +152,7 @@ public:
         if (cfg_.max_prefill_rows <= 0) cfg_.max_prefill_rows = 8192;
         if (cfg_.max_speakers <= 0) cfg_.max_speakers = 64;
         const int S = cfg_.max_seqs;
-        n_blocks_ = (long)S * kMaxBlocks;
+        n_blocks_ = (long)S * kMaxBlocks + 2L * cfg_.max_speakers;   // + 2 shared prefix blocks per speaker
         kv_layer_stride_ = n_blocks_ * kKvBlockElems;
         kv_.ensure((size_t)cfg_.n_layer * kv_layer_stride_ * sizeof(float));
         for (int b = (int)n_blocks_ - 1; b >= 0; --b) free_blocks_.push_back(b);
@@ -162,7 +163,7 @@ public:
         ints(slot_tok_, S); ints(slot_pos_, S); ints(slot_kvpos_, S); ints(slot_ngen_, S); ints(slot_finished_, S);
         ints(temperature_, S); ints(top_p_, S); ints(top_k_, S); ints(rep_, S); ints(max_tokens_, S);
         ints(ignore_stop_, S); ints(seed_, S);
-        ints(block_tables_, (size_t)S * kMaxBlocks);
+        ints(block_tables_, (size_t)(S + 1) * kMaxBlocks);   // row S: pseudo-slot used to prefill a speaker prefix
         seen_.ensure((size_t)S * kSeenStride);
         HIP_CHECK(hipMemsetAsync(seen_.p, 0, (size_t)S * kSeenStride, st_));
         latents_.ensure((size_t)S * kMaxLatRows * kHidden * sizeof(float));
@@ -171,7 +172,9 @@ public:
         voc_cond_.ensure((size_t)cfg_.max_speakers * kCondStride * sizeof(float));
         zero_bias_.ensure(4096 * sizeof(float));
         HIP_CHECK(hipMemsetAsync(zero_bias_.p, 0, 4096 * sizeof(float), st_));
-        h_block_tables_.assign((size_t)S * kMaxBlocks, 0);
+        h_block_tables_.assign((size_t)(S + 1) * kMaxBlocks, 0);
+        spk_info_.assign(cfg_.max_speakers, SpeakerInfo{});
+        if (const char* e = getenv("AUR_SHARE_PREFIX")) share_prefix_ = atoi(e) != 0;
         slot_owner_.assign(S, nullptr);
         HIP_CHECK(hipStreamCreateWithFlags(&st2_, hipStreamDefault));
         HIP_CHECK(hipStreamCreateWithFlags(&st_voc_, hipStreamDefault));
@@ -247,8 +250,14 @@ public:
         return row;
     }
     void set_conditioning(uint64_t key, const float* gpt_cond, const float* spk, bool device_ptrs) {
+        std::lock_guard<std::mutex> gl(gpu_mu_);   // may be called while the driver thread is inside aur_step
         use();
-        const int row = speaker_row(key, true);
+        int row;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            row = speaker_row(key, true);
+            AUR_REQUIRE(spk_info_[row].live == 0, "speaker is in use by live sequences: register the new voice under a new key");
+        }
         const hipMemcpyKind kind = device_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
         HIP_CHECK(hipMemcpyAsync(spk_table_.as<float>() + (long)row * 32 * kHidden, gpt_cond,
                                  32 * kHidden * sizeof(float), kind, st_));
@@ -265,6 +274,47 @@ public:
             off += C[i];
         }
         HIP_CHECK(hipStreamSynchronize(st_));
+        prefill_speaker_prefix(row);
+    }
+    // Prefix sharing: the first 32 prompt rows (speaker latents, XTTSv2.py:345) are identical for every sequence of a
+    // speaker and, under causal attention, so are their K/V in every layer.  They are computed once per speaker into two
+    // KV blocks (32 tokens = 2 blocks of 16) that every sequence's block table points at; a prompt prefill then only
+    // processes the text rows + start token.  Results are bitwise those of the unshared path (row-independent kernels).
+    void prefill_speaker_prefix(int row) {
+        SpeakerInfo& si = spk_info_[row];
+        si.ready = false;
+        if (!share_prefix_ || w_.find("gpt.wte") == w_.end()) return;   // GPT weights not loaded yet: unshared path
+        ensure_gpt();
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (si.blocks[0] < 0) {
+                AUR_REQUIRE(free_blocks_.size() >= 2, "KV pool exhausted");
+                for (int b = 0; b < 2; ++b) {
+                    si.blocks[b] = free_blocks_.back();
+                    free_blocks_.pop_back();
+                }
+            }
+        }
+        RowWs& w = ws_[0];
+        graph_active_.clear();
+        const int S = cfg_.max_seqs;
+        std::vector<int4> desc;
+        std::vector<int> row_slot(32, S), row_pos(32);
+        for (int i = 0; i < 32; ++i) {
+            desc.push_back(make_int4(0, i, row, 0));
+            row_pos[i] = i;
+        }
+        ensure_rows(w, 32);
+        h_block_tables_[(size_t)S * kMaxBlocks + 0] = si.blocks[0];
+        h_block_tables_[(size_t)S * kMaxBlocks + 1] = si.blocks[1];
+        HIP_CHECK(hipMemcpyAsync(block_tables_.p, h_block_tables_.data(), h_block_tables_.size() * 4, hipMemcpyHostToDevice, w.st));
+        HIP_CHECK(hipMemcpyAsync(w.i_desc.p, desc.data(), 32 * sizeof(int4), hipMemcpyHostToDevice, w.st));
+        HIP_CHECK(hipMemcpyAsync(w.i_row_slot.p, row_slot.data(), 32 * 4, hipMemcpyHostToDevice, w.st));
+        HIP_CHECK(hipMemcpyAsync(w.i_row_pos.p, row_pos.data(), 32 * 4, hipMemcpyHostToDevice, w.st));
+        launch_embed_prompt(w.i_desc.as<int4>(), spk_table_.as<float>(), text_emb_, text_pos_, wte_, wpe_, w.h.as<float>(), 32, w.st);
+        forward_rows(w, 32, w.i_row_slot.as<int>(), w.i_row_pos.as<int>());
+        HIP_CHECK(hipStreamSynchronize(w.st));
+        si.ready = true;
     }
 
     // ------------------------------------------------------------------ submit / poll
@@ -319,6 +369,7 @@ public:
 
     // ------------------------------------------------------------------ one scheduler iteration
     void step(int* n_live, int* n_finished_total) {
+        std::lock_guard<std::mutex> gl(gpu_mu_);
         use();
         ensure_gpt();
         bool worked = false;
@@ -338,24 +389,30 @@ public:
             int rows = 0;
             while (!waiting_.empty()) {
                 Seq* s = waiting_.front();
-                const int need = (s->n_prompt + s->params.max_tokens + kKvBlockTokens - 1) / kKvBlockTokens;
+                const SpeakerInfo& si = spk_info_[s->spk_row];
+                s->shared_prefix = si.ready && share_prefix_now_;
+                const int skip = s->shared_prefix ? 2 : 0;   // table entries 0,1 = the speaker's shared prefix blocks
+                const int need = (s->n_prompt + s->params.max_tokens + kKvBlockTokens - 1) / kKvBlockTokens - skip;
                 int slot = -1;
                 for (int i = 0; i < cfg_.max_seqs; ++i)
                     if (!slot_owner_[i]) {
                         slot = i;
                         break;
                     }
-                if (slot < 0 || (int)free_blocks_.size() < need || rows + s->n_prompt > cfg_.max_prefill_rows) break;
+                const int n_rows = s->n_prompt - (s->shared_prefix ? 32 : 0);
+                if (slot < 0 || (int)free_blocks_.size() < need || rows + n_rows > cfg_.max_prefill_rows) break;
                 waiting_.pop_front();
                 s->slot = slot;
                 slot_owner_[slot] = s;
+                spk_info_[s->spk_row].live++;
+                for (int b = 0; b < skip; ++b) h_block_tables_[(size_t)slot * kMaxBlocks + b] = si.blocks[b];
                 for (int b = 0; b < need; ++b) {
                     s->blocks.push_back(free_blocks_.back());
                     free_blocks_.pop_back();
-                    h_block_tables_[(size_t)slot * kMaxBlocks + b] = s->blocks.back();
+                    h_block_tables_[(size_t)slot * kMaxBlocks + skip + b] = s->blocks.back();
                 }
                 s->state = SeqState::RUNNING;
-                rows += s->n_prompt;
+                rows += n_rows;
                 admitted.push_back(s);
             }
         }
@@ -557,7 +614,9 @@ public:
         const uint64_t id = submit(d);
         dbg_logits_.ensure((size_t)kMelVocab * 4);
         dbg_capture_ = true;
+        share_prefix_now_ = false;
         step(nullptr, nullptr);
+        share_prefix_now_ = true;
         dbg_capture_ = false;
         for (int guard = 0; guard < 1000 && seqs_.at(id)->state != SeqState::DONE; ++guard) step(nullptr, nullptr);
         Seq* s = seqs_.at(id).get();
@@ -824,6 +883,7 @@ private:
         std::lock_guard<std::mutex> lk(mu_);
         for (int b : s->blocks) free_blocks_.push_back(b);
         s->blocks.clear();
+        spk_info_[s->spk_row].live--;
         slot_owner_[s->slot] = nullptr;
         s->slot = -1;
         voc_queue_.push_back(s);
@@ -849,14 +909,15 @@ private:
             const aur_seq_desc& p = s->params;
             init.push_back(SlotInit{s->slot, p.temperature, p.top_p, p.top_k, p.repetition_penalty, p.max_tokens,
                                     p.ignore_stop, p.seed, 0});
-            for (int i = 0; i < 32; ++i) desc.push_back(make_int4(0, i, s->spk_row, 0));
+            const int first = s->shared_prefix ? 32 : 0;     // rows 0..31 live in the speaker's shared KV blocks
+            for (int i = first; i < 32; ++i) desc.push_back(make_int4(0, i, s->spk_row, 0));
             for (int i = 0; i < (int)s->text_ids.size(); ++i) {
                 const int id = s->text_ids[i];
                 AUR_REQUIRE(id >= 0 && id < text_vocab_ && i < text_positions_, "text id / position out of range");
                 desc.push_back(make_int4(1, id, i, 0));
             }
             desc.push_back(make_int4(2, kStartToken, 0, 0));
-            for (int i = 0; i < s->n_prompt; ++i) {
+            for (int i = first; i < s->n_prompt; ++i) {
                 row_slot.push_back(s->slot);
                 row_pos.push_back(i);
             }
@@ -1191,6 +1252,15 @@ private:
         ignore_stop_, seed_, block_tables_, seen_, latents_;
     DevBuf spk_table_, spk_emb_, voc_cond_, zero_bias_;
     std::map<uint64_t, int> spk_rows_;
+    struct SpeakerInfo {
+        int blocks[2] = {-1, -1};
+        bool ready = false;
+        int live = 0;
+    };
+    std::vector<SpeakerInfo> spk_info_;
+    bool share_prefix_ = true;        // AUR_SHARE_PREFIX=0 disables
+    bool share_prefix_now_ = true;    // dbg_prefill turns it off to return every prompt row
+    std::mutex gpu_mu_;
     // row workspace
     RowWs ws_[2];
     // vocoder stage

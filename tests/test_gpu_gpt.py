@@ -119,7 +119,7 @@ def test_continuous_batching_is_batch_invariant(small, dims):
         assert o["tokens"].tolist() == s["tokens"].tolist()
         assert np.array_equal(o["wav"], s["wav"])
     st = e.stats()
-    assert st["kv_blocks_free"] == st["kv_blocks_total"]
+    assert st["kv_blocks_total"] - st["kv_blocks_free"] in (0, 2)     # only the speaker's 2 shared prefix blocks stay allocated
 
 
 def test_full_depth_greedy_short(dims):
