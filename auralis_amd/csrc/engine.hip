@@ -793,8 +793,12 @@ private:
             const LayerW& L = layers_[l];
             float* kvl = kv_.as<float>() + (long)l * kv_layer_stride_;
             gemm(w, xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, p1);
-            launch_qkv_epilogue(P, S1, L.bqkv, w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, w.st);
-            launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st);
+            if (d_row_pos == nullptr) {   // decode: one fused launch
+                launch_qkv_attention_fused(P, S1, L.bqkv, kvl, d_row_slot, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st);
+            } else {
+                launch_qkv_epilogue(P, S1, L.bqkv, w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, w.st);
+                launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st);
+            }
             gemm(w, w.att.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, p1);
             launch_rows_ln(P, S1, L.bproj, h, L.ln2w, L.ln2b, xn, M, 1e-5f, w.st);
             gemm(w, xn, kHidden, L.wfc, P, M, 4 * kHidden, kHidden, p1);

@@ -40,6 +40,12 @@ void launch_paged_attention(const float* qbuf, const float* kv_layer, const int*
                             const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
                             hipStream_t st);
 
+// decode rows (one new token per sequence): qkv epilogue + KV page write + attention in one launch, reading the QKV
+// GEMM slabs directly (bitwise the same result as launch_qkv_epilogue + launch_paged_attention)
+void launch_qkv_attention_fused(const float* P, int S, const float* bias, float* kv_layer, const int* row_slot,
+                                const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
+                                hipStream_t st);
+
 // prompt rows: desc[m] = {kind, a, b, _}: kind 0 -> spk_cond[b][a][:], 1 -> text_emb[a]+text_pos[b], 2 -> wte[a]+wpe[b]
 void launch_embed_prompt(const int4* desc, const float* spk_cond, const float* text_emb, const float* text_pos,
                          const float* wte, const float* wpe, float* h, int M, hipStream_t st);

@@ -271,13 +271,18 @@ void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, 
 // Paged causal attention: one workgroup per (row, head).  16 lanes x float4 span the 64-wide head; a wave
 // reads 4 consecutive cached tokens (1 KiB contiguous) per instruction; 4 waves stride the context.
 // Scores are reduced with wavefront shuffles; online softmax per 16-lane group; groups merged through LDS.
+// FUSED (decode rows only): the row's q/k/v come straight from the QKV GEMM slabs (+ bias); the block writes its own
+// k,v into the page and uses them from registers, so the separate qkv_epilogue launch disappears.  Token t is still
+// handled by the same lane group in the same iteration => bitwise the same result as the unfused pair.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __restrict__ qbuf,
-                                                              const float* __restrict__ kv_layer,
+                                                              float* __restrict__ kv_layer,
                                                               const int* __restrict__ row_slot,
                                                               const int* __restrict__ row_pos,
                                                               const int* __restrict__ slot_kvpos,
                                                               const int* __restrict__ block_tables, int max_blocks,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, const float* __restrict__ P,
+                                                              int S, const float* __restrict__ bias, int M) {
     __shared__ float part_o[16][kHeadDim];
     __shared__ float part_m[16], part_l[16];
     const int m = blockIdx.x, head = blockIdx.y;
@@ -288,7 +293,29 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
     const int n_keys = pos + 1;
     const int* bt = block_tables + (long)slot * max_blocks;
 
-    const f32x4 qv = *reinterpret_cast<const f32x4*>(qbuf + (long)m * kHidden + head * kHeadDim + d4 * 4);
+    f32x4 qv, own_k = {0.f, 0.f, 0.f, 0.f}, own_v = {0.f, 0.f, 0.f, 0.f};
+    if (FUSED) {
+        constexpr int N = 3 * kHidden;
+        const int col = head * kHeadDim + d4 * 4;
+        f32x4 t[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const float* p0 = P + (long)m * N + u * kHidden + col;
+            t[u] = *reinterpret_cast<const f32x4*>(p0);
+            for (int sl = 1; sl < S; ++sl) t[u] += *reinterpret_cast<const f32x4*>(p0 + (long)sl * M * N);
+            t[u] += *reinterpret_cast<const f32x4*>(bias + u * kHidden + col);
+        }
+        qv = t[0];
+        own_k = t[1];
+        own_v = t[2];
+        if (wv == 0 && g == 0) {
+            const long off = kv_offset(bt[pos / kKvBlockTokens], 0, head, pos % kKvBlockTokens) + d4 * 4;
+            *reinterpret_cast<f32x4*>(kv_layer + off) = own_k;
+            *reinterpret_cast<f32x4*>(kv_layer + off + (long)kHeads * kKvBlockTokens * kHeadDim) = own_v;
+        }
+    } else {
+        qv = *reinterpret_cast<const f32x4*>(qbuf + (long)m * kHidden + head * kHeadDim + d4 * 4);
+    }
     float mi = -INFINITY, li = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     for (int t0 = 0; t0 < n_keys; t0 += 16) {
@@ -296,10 +323,15 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
         const bool valid = t < n_keys;
         f32x4 k4 = {0.f, 0.f, 0.f, 0.f}, v4 = {0.f, 0.f, 0.f, 0.f};
         if (valid) {
-            const int blk = bt[t / kKvBlockTokens];
-            const long off = kv_offset(blk, 0, head, t % kKvBlockTokens) + d4 * 4;
-            k4 = *reinterpret_cast<const f32x4*>(kv_layer + off);
-            v4 = *reinterpret_cast<const f32x4*>(kv_layer + off + (long)kHeads * kKvBlockTokens * kHeadDim);
+            if (FUSED && t == pos) {
+                k4 = own_k;
+                v4 = own_v;
+            } else {
+                const int blk = bt[t / kKvBlockTokens];
+                const long off = kv_offset(blk, 0, head, t % kKvBlockTokens) + d4 * 4;
+                k4 = *reinterpret_cast<const f32x4*>(kv_layer + off);
+                v4 = *reinterpret_cast<const f32x4*>(kv_layer + off + (long)kHeads * kKvBlockTokens * kHeadDim);
+            }
         }
         float sc = (qv[0] * k4[0] + qv[1] * k4[1]) + (qv[2] * k4[2] + qv[3] * k4[3]);
         sc += __shfl_xor(sc, 8, 64);
@@ -343,8 +375,18 @@ void launch_paged_attention(const float* qbuf, const float* kv_layer, const int*
                             const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
                             hipStream_t st) {
     trace_launch("paged_attention_kernel");
-    hipLaunchKernelGGL(paged_attention_kernel, dim3(M, kHeads), dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos,
-                       slot_kvpos, block_tables, max_blocks, out);
+    hipLaunchKernelGGL(paged_attention_kernel<false>, dim3(M, kHeads), dim3(256), 0, st, qbuf, const_cast<float*>(kv_layer),
+                       row_slot, row_pos, slot_kvpos, block_tables, max_blocks, out, (const float*)nullptr, 0,
+                       (const float*)nullptr, M);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_qkv_attention_fused(const float* P, int S, const float* bias, float* kv_layer, const int* row_slot,
+                                const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
+                                hipStream_t st) {
+    trace_launch("paged_attention_kernel<fused>");
+    hipLaunchKernelGGL(paged_attention_kernel<true>, dim3(M, kHeads), dim3(256), 0, st, (const float*)nullptr, kv_layer,
+                       row_slot, (const int*)nullptr, slot_kvpos, block_tables, max_blocks, out, P, S, bias, M);
     HIP_CHECK(hipGetLastError());
 }
 
