@@ -318,35 +318,42 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
     }
     float mi = -INFINITY, li = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    for (int t0 = 0; t0 < n_keys; t0 += 16) {
-        const int t = t0 + wv * 4 + g;
-        const bool valid = t < n_keys;
-        f32x4 k4 = {0.f, 0.f, 0.f, 0.f}, v4 = {0.f, 0.f, 0.f, 0.f};
-        if (valid) {
-            if (FUSED && t == pos) {
-                k4 = own_k;
-                v4 = own_v;
-            } else {
-                const int blk = bt[t / kKvBlockTokens];
-                const long off = kv_offset(blk, 0, head, t % kKvBlockTokens) + d4 * 4;
-                k4 = *reinterpret_cast<const f32x4*>(kv_layer + off);
-                v4 = *reinterpret_cast<const f32x4*>(kv_layer + off + (long)kHeads * kKvBlockTokens * kHeadDim);
-            }
-        }
-        float sc = (qv[0] * k4[0] + qv[1] * k4[1]) + (qv[2] * k4[2] + qv[3] * k4[3]);
-        sc += __shfl_xor(sc, 8, 64);
-        sc += __shfl_xor(sc, 4, 64);
-        sc += __shfl_xor(sc, 2, 64);
-        sc += __shfl_xor(sc, 1, 64);
-        sc *= 0.125f;   // 1/sqrt(64)
-        if (valid) {
-            const float mn = fmaxf(mi, sc);
-            const float alpha = expf(mi - mn);   // mi = -inf on first use -> 0
-            const float p = expf(sc - mn);
-            li = li * alpha + p;
+    // 4 tokens per wave per step, 4 steps unrolled: all 8 K/V loads of a lane are issued before the first softmax
+    // update (addresses are clamped instead of predicated so that the loads can be hoisted).
+    constexpr int UN = 4;
+    for (int t0 = 0; t0 < n_keys; t0 += 16 * UN) {
+        f32x4 k4[UN], v4[UN];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = o[c] * alpha + p * v4[c];
-            mi = mn;
+        for (int u = 0; u < UN; ++u) {
+            const int t = min(t0 + 16 * u + wv * 4 + g, n_keys - 1);
+            const int blk = bt[t / kKvBlockTokens];
+            const long off = kv_offset(blk, 0, head, t % kKvBlockTokens) + d4 * 4;
+            k4[u] = *reinterpret_cast<const f32x4*>(kv_layer + off);
+            v4[u] = *reinterpret_cast<const f32x4*>(kv_layer + off + (long)kHeads * kKvBlockTokens * kHeadDim);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int t = t0 + 16 * u + wv * 4 + g;
+            const bool valid = t < n_keys;
+            if (FUSED && t == pos) {   // own token: registers (the page write above may not be visible yet)
+                k4[u] = own_k;
+                v4[u] = own_v;
+            }
+            float sc = (qv[0] * k4[u][0] + qv[1] * k4[u][1]) + (qv[2] * k4[u][2] + qv[3] * k4[u][3]);
+            sc += __shfl_xor(sc, 8, 64);
+            sc += __shfl_xor(sc, 4, 64);
+            sc += __shfl_xor(sc, 2, 64);
+            sc += __shfl_xor(sc, 1, 64);
+            sc *= 0.125f;   // 1/sqrt(64)
+            if (valid) {
+                const float mn = fmaxf(mi, sc);
+                const float alpha = expf(mi - mn);   // mi = -inf on first use -> 0
+                const float p = expf(sc - mn);
+                li = li * alpha + p;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = o[c] * alpha + p * v4[u][c];
+                mi = mn;
+            }
         }
     }
     const int pidx = wv * 4 + g;
