@@ -14,52 +14,66 @@ namespace aur {
 // MFMA v_mfma_f32_16x16x4_f32 with a permuted K and N order so that the float4 loads ARE the fragments:
 //   step (s', c):  A[i][k'] = X[m][kb + 4k' + s'],  B[k'][j'] = W[kb + 4k' + s'][n0 + 4j' + c]
 //   D[i][j'] accumulates column n0 + 4j' + c, i.e. lane j' owns 4 consecutive columns across c = 0..3.
-template <bool FUSED>
-__global__ __launch_bounds__(512) void gemm_splitk_kernel(const float* __restrict__ X, int ldx,
+template <bool FUSED, int MTW>   // MTW = 16-row MFMA tiles per wave: the workgroup owns a (16*MTW) x 64 output tile
+__global__ __launch_bounds__(256) void gemm_splitk_kernel(const float* __restrict__ X, int ldx,
                                                           const float* __restrict__ W, float* __restrict__ P,
                                                           int M, int N, int n_slices) {
-    // 8 waves: wave = (K-quarter ks, M-half mh).  Each wave streams its 64 weight rows x 64 columns once
-    // (16 float4 loads issued back to back, so one HBM latency covers the whole slice) and multiplies them
-    // with its 32 activation rows.  Reduction order per output element is ((k0 + k1) + k2) + k3.
+    // 4 waves = the 4 K-quarters of one 256-deep slice.  Each wave streams its 64 weight rows x 64 columns once
+    // (16 float4 loads issued back to back, so one HBM latency covers the whole slice) and multiplies them with the
+    // tile's activation rows.  Reduction order per output element is ((k0 + k1) + k2) + k3, then slices in order.
     constexpr int KW = 64;
-    __shared__ __attribute__((aligned(16))) float red[2][3][32][68];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ks = wv & 3, mh = wv >> 2;
+    constexpr int MR = 16 * MTW;
+    __shared__ __attribute__((aligned(16))) float red[3][MR][68];
+    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * 64, m0 = blockIdx.z * 64 + mh * 32;
-    const int s_begin = FUSED ? 0 : blockIdx.y, s_end = FUSED ? n_slices : blockIdx.y + 1;
-
-    const float* xp[2];
-    bool xv[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int r = m0 + 16 * mt + i;
-        xv[mt] = r < M;
-        xp[mt] = X + (long)(xv[mt] ? r : 0) * ldx + 4 * q;
+    // Tile order: dispatch order is x fastest and consecutive workgroups go to consecutive XCDs, so the M-tiles that
+    // stream the SAME weight tile are given ids 8 apart => same XCD L2, adjacent in time (weights leave HBM once).
+    int ntile, slice, mtile;
+    {
+        const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+        const int nw = gx * gy;
+        const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        int wt;
+        if ((nw & 7) == 0) {
+            const int xcd = L & 7, slot = L >> 3;
+            mtile = slot % gz;
+            wt = (slot / gz) * 8 + xcd;
+        } else {
+            mtile = L / nw;
+            wt = L - mtile * nw;
+        }
+        ntile = wt % gx;
+        slice = wt / gx;
     }
-    f32x4 total[2][4];
+    const int n0 = ntile * 64, m0 = mtile * MR;
+    const int s_begin = FUSED ? 0 : slice, s_end = FUSED ? n_slices : slice + 1;
+
+    const float* xp[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int r = m0 + 16 * mt + i;
+        xp[mt] = X + (long)(r < M ? r : 0) * ldx + 4 * q;   // rows >= M alias row 0: never stored
+    }
+    f32x4 total[MTW][4];
 
     for (int s = s_begin; s < s_end; ++s) {
         const int kbeg = (s * 4 + ks) * KW;
         const float* wp = W + (long)(kbeg + 4 * q) * N + n0 + 4 * i;
-        f32x4 bf[4][4], af[4][2];
+        f32x4 bf[4][4], af[4][MTW];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
             for (int sp = 0; sp < 4; ++sp)
-                bf[kb][sp] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + (long)(16 * kb + sp) * N));
+                bf[kb][sp] = *reinterpret_cast<const f32x4*>(wp + (long)(16 * kb + sp) * N);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                // rows >= M alias row 0: their products land in output rows that are never stored
-                af[kb][mt] = *reinterpret_cast<const f32x4*>(xp[mt] + kbeg + 16 * kb);
-            }
+            for (int mt = 0; mt < MTW; ++mt) af[kb][mt] = *reinterpret_cast<const f32x4*>(xp[mt] + kbeg + 16 * kb);
         }
         // keep every load above this line: hipcc otherwise sinks each load next to its first use and the wave
         // pays one HBM round trip per load instead of one per slice
         __builtin_amdgcn_sched_barrier(0);
-        f32x4 acc[2][4];
+        f32x4 acc[MTW][4];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[mt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -69,29 +83,29 @@ __global__ __launch_bounds__(512) void gemm_splitk_kernel(const float* __restric
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
+                    for (int mt = 0; mt < MTW; ++mt)
                         acc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kb][mt][sp], bf[kb][sp][c], acc[mt][c], 0, 0, 0);
         if (ks > 0) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * mt + 4 * q + r;
                     f32x4 v = {acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
-                    *reinterpret_cast<f32x4*>(&red[mh][ks - 1][row][4 * i]) = v;
+                    *reinterpret_cast<f32x4*>(&red[ks - 1][row][4 * i]) = v;
                 }
         }
         __syncthreads();
         if (ks == 0) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * mt + 4 * q + r;
                     f32x4 v = {acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
-                    v += *reinterpret_cast<const f32x4*>(&red[mh][0][row][4 * i]);
-                    v += *reinterpret_cast<const f32x4*>(&red[mh][1][row][4 * i]);
-                    v += *reinterpret_cast<const f32x4*>(&red[mh][2][row][4 * i]);
+                    v += *reinterpret_cast<const f32x4*>(&red[0][row][4 * i]);
+                    v += *reinterpret_cast<const f32x4*>(&red[1][row][4 * i]);
+                    v += *reinterpret_cast<const f32x4*>(&red[2][row][4 * i]);
                     if (FUSED) {
                         total[mt][r] = (s == 0) ? v : total[mt][r] + v;
                     } else if (m0 + row < M) {
@@ -103,7 +117,7 @@ __global__ __launch_bounds__(512) void gemm_splitk_kernel(const float* __restric
     }
     if (FUSED && ks == 0) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * mt + 4 * q + r;
@@ -127,12 +141,19 @@ void launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M
                         hipStream_t st) {
     AUR_REQUIRE(N % 64 == 0 && pl.kw == 64 && K == pl.slices * 4 * pl.kw && ldx % 4 == 0, "gemm: shape");
     trace_launch("gemm_splitk_kernel");
+    static const int mtw = [] {
+        const char* e = getenv("AUR_GEMM_MTW");
+        return (e && atoi(e) == 1) ? 1 : 2;
+    }();
     if (pl.fused) {
-        dim3 grid(N / 64, 1, (M + 63) / 64);
-        hipLaunchKernelGGL(gemm_splitk_kernel<true>, grid, dim3(512), 0, st, X, ldx, W, P, M, N, pl.slices);
+        dim3 grid(N / 64, 1, (M + 31) / 32);
+        hipLaunchKernelGGL((gemm_splitk_kernel<true, 2>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices);
+    } else if (mtw == 1) {
+        dim3 grid(N / 64, pl.slices, (M + 15) / 16);
+        hipLaunchKernelGGL((gemm_splitk_kernel<false, 1>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices);
     } else {
-        dim3 grid(N / 64, pl.slices, (M + 63) / 64);
-        hipLaunchKernelGGL(gemm_splitk_kernel<false>, grid, dim3(512), 0, st, X, ldx, W, P, M, N, pl.slices);
+        dim3 grid(N / 64, pl.slices, (M + 31) / 32);
+        hipLaunchKernelGGL((gemm_splitk_kernel<false, 2>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices);
     }
     HIP_CHECK(hipGetLastError());
 }
