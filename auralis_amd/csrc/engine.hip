@@ -325,6 +325,13 @@ public:
         AUR_REQUIRE(n_prompt + d.max_tokens <= kMaxBlocks * kKvBlockTokens, "prompt + max_tokens exceeds max_model_len");
         AUR_REQUIRE(n_prompt <= cfg_.max_prefill_rows, "prompt longer than max_prefill_rows");
         AUR_REQUIRE(d.repetition_penalty > 0.f, "repetition_penalty > 0");
+        {   // reject bad text ids / positions here, not in the middle of a batched prefill
+            auto te = w_.find("text_emb"), tp = w_.find("text_pos");
+            AUR_REQUIRE(te != w_.end() && tp != w_.end(), "weights not loaded");
+            const int vocab = (int)(te->second.numel / kHidden), npos = (int)(tp->second.numel / kHidden);
+            AUR_REQUIRE(d.n_text <= npos, "text longer than the text position table");
+            for (int i = 0; i < d.n_text; ++i) AUR_REQUIRE(d.text_ids[i] >= 0 && d.text_ids[i] < vocab, "text id out of range");
+        }
         std::lock_guard<std::mutex> lk(mu_);
         const int row = speaker_row(d.speaker_key, false);
         AUR_REQUIRE(row >= 0, "unknown speaker_key (call aur_set_conditioning first)");
