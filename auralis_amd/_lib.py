@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_C", "libauralis_amd.so")
+LIB_PATH = os.environ.get("AURALIS_AMD_LIB") or os.path.join(_HERE, "_C", "libauralis_amd.so")   # override: A/B builds
 
 
 class AurError(RuntimeError):

@@ -246,7 +246,11 @@ template <int KS, int DIL, int MT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void conv1d_mfma_f16_kernel(ConvArgs a) {
     constexpr int CK = 16;
     constexpr int WM = MT / 32;
-    constexpr int WN = (MT == 64) ? 2 : 4;
+#ifndef AUR_F16_WN64
+#define AUR_F16_WN64 2
+#define AUR_F16_WN32 4
+#endif
+    constexpr int WN = (MT == 64) ? AUR_F16_WN64 : AUR_F16_WN32;
     constexpr int NTW = 32 * WN;
     constexpr int NT = 4 * NTW;
     constexpr int HALO = (KS - 1) * DIL;
@@ -360,11 +364,13 @@ static void launch_conv_f16_t(const ConvArgs& a, hipStream_t st) {
     const int n_q = a.ups_s ? a.max_len + 1 : a.max_len;
     trace_launch("conv1d_mfma_f16_kernel");
     if (a.Mtot % 64 == 0) {
-        dim3 grid((n_q + 255) / 256, a.Mtot / 64, a.B);
+        constexpr int NT64 = 128 * AUR_F16_WN64;
+        dim3 grid((n_q + NT64 - 1) / NT64, a.Mtot / 64, a.B);
         hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 64>), grid, dim3(256), 0, st, a);
     } else {
         AUR_REQUIRE(a.Mtot % 32 == 0, "conv f16: Mtot % 32");
-        dim3 grid((n_q + 511) / 512, a.Mtot / 32, a.B);
+        constexpr int NT32 = 128 * AUR_F16_WN32;
+        dim3 grid((n_q + NT32 - 1) / NT32, a.Mtot / 32, a.B);
         hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 32>), grid, dim3(256), 0, st, a);
     }
 }
