@@ -1,0 +1,248 @@
+"""Text normalisation in front of the BPE tokenizer: quotes -> lowercase -> numbers -> abbreviations -> symbols ->
+whitespace, the order of the reference's `multilingual_cleaners` (src/auralis/models/xttsv2/config/tokenizer.py:
+708-719; number handling 603-700, abbreviation / symbol tables 241-600).
+
+The reference delegates number spelling to `num2words` (absent offline).  en / fr / de — the languages of BASELINE
+config 5 — are spelled out here following num2words' conventions ("one thousand, two hundred and thirty-four",
+"quatre-vingt-un", "einundzwanzig"); other languages keep their digits.  This module is CPU text plumbing in front of
+the hot path and is "parity unpinned": no num2words output can be generated in this environment.
+"""
+from __future__ import annotations
+
+import re
+from typing import Callable, Dict, List, Tuple
+
+_WS = re.compile(r"\s+")
+
+# ------------------------------------------------------------------------------------------------ tables
+_ABBREV = {
+    "en": [("mrs", "misess"), ("mr", "mister"), ("dr", "doctor"), ("st", "saint"), ("co", "company"), ("jr", "junior"),
+           ("maj", "major"), ("gen", "general"), ("drs", "doctors"), ("rev", "reverend"), ("lt", "lieutenant"),
+           ("hon", "honorable"), ("sgt", "sergeant"), ("capt", "captain"), ("esq", "esquire"), ("ltd", "limited"),
+           ("col", "colonel"), ("ft", "fort")],
+    "fr": [("mme", "madame"), ("mr", "monsieur"), ("dr", "docteur"), ("st", "saint"), ("co", "compagnie"), ("jr", "junior"),
+           ("ltd", "limitée")],
+    "de": [("fr", "frau"), ("dr", "doktor"), ("st", "sankt"), ("co", "firma"), ("jr", "junior")],
+    "es": [("sra", "señora"), ("sr", "señor"), ("dr", "doctor"), ("dra", "doctora"), ("st", "santo"), ("co", "compañía"),
+           ("jr", "junior"), ("ltd", "limitada")],
+    "it": [("sig", "signore"), ("dr", "dottore"), ("st", "santo"), ("co", "compagnia"), ("jr", "junior"), ("ltd", "limitata")],
+    "pt": [("sra", "senhora"), ("sr", "senhor"), ("dr", "doutor"), ("dra", "doutora"), ("st", "santo"), ("co", "companhia"),
+           ("jr", "júnior"), ("ltd", "limitada")],
+}
+_ABBREV_RE = {lang: [(re.compile(r"\b%s\." % a, re.IGNORECASE), b) for a, b in lst] for lang, lst in _ABBREV.items()}
+
+_SYMBOLS = {
+    "en": [("&", " and "), ("@", " at "), ("%", " percent "), ("#", " hash "), ("$", " dollar "), ("£", " pound "), ("°", " degree ")],
+    "fr": [("&", " et "), ("@", " arobase "), ("%", " pour cent "), ("#", " dièse "), ("$", " dollar "), ("£", " livre "), ("°", " degrés ")],
+    "de": [("&", " und "), ("@", " at "), ("%", " prozent "), ("#", " raute "), ("$", " dollar "), ("£", " pfund "), ("°", " grad ")],
+    "es": [("&", " y "), ("@", " arroba "), ("%", " por ciento "), ("#", " numeral "), ("$", " dolar "), ("£", " libra "), ("°", " grados ")],
+    "it": [("&", " e "), ("@", " chiocciola "), ("%", " per cento "), ("#", " cancelletto "), ("$", " dollaro "), ("£", " sterlina "), ("°", " gradi ")],
+    "pt": [("&", " e "), ("@", " arroba "), ("%", " por cento "), ("#", " cardinal "), ("$", " dólar "), ("£", " libra "), ("°", " graus ")],
+}
+
+_ORDINAL_RE = {
+    "en": re.compile(r"([0-9]+)(st|nd|rd|th)"),
+    "fr": re.compile(r"([0-9]+)(º|ª|er|re|e|ème)"),
+    "de": re.compile(r"([0-9]+)(st|nd|rd|th|º|ª|\.(?=\s|$))"),
+}
+_NUMBER_RE = re.compile(r"[0-9]+")
+_CURRENCY_RE = {
+    "GBP": re.compile(r"((£[0-9\.\,]*[0-9]+)|([0-9\.\,]*[0-9]+£))"),
+    "USD": re.compile(r"((\$[0-9\.\,]*[0-9]+)|([0-9\.\,]*[0-9]+\$))"),
+    "EUR": re.compile(r"(([0-9\.\,]*[0-9]+€)|((€[0-9\.\,]*[0-9]+)))"),
+}
+_COMMA_NUMBER_RE = re.compile(r"\b\d{1,3}(,\d{3})*(\.\d+)?\b")
+_DOT_NUMBER_RE = re.compile(r"\b\d{1,3}(\.\d{3})*(\,\d+)?\b")
+_DECIMAL_RE = re.compile(r"([0-9]+[.,][0-9]+)")
+
+
+# ------------------------------------------------------------------------------------------------ number spelling
+def _en_card(n: int) -> str:
+    ones = ["zero", "one", "two", "three", "four", "five", "six", "seven", "eight", "nine", "ten", "eleven", "twelve",
+            "thirteen", "fourteen", "fifteen", "sixteen", "seventeen", "eighteen", "nineteen"]
+    tens = ["", "", "twenty", "thirty", "forty", "fifty", "sixty", "seventy", "eighty", "ninety"]
+    if n < 20:
+        return ones[n]
+    if n < 100:
+        t, o = divmod(n, 10)
+        return tens[t] + ("-" + ones[o] if o else "")
+    if n < 1000:
+        h, r = divmod(n, 100)
+        return ones[h] + " hundred" + (" and " + _en_card(r) if r else "")
+    parts: List[str] = []
+    for value, name in ((10 ** 12, "trillion"), (10 ** 9, "billion"), (10 ** 6, "million"), (1000, "thousand")):
+        if n >= value:
+            q, n = divmod(n, value)
+            parts.append(_en_card(q) + " " + name)
+    if n:
+        parts.append(("and " if n < 100 else "") + _en_card(n))
+    out = parts[0]
+    for p in parts[1:]:
+        out += (" " if p.startswith("and ") else ", ") + p
+    return out
+
+
+def _en_ord(n: int) -> str:
+    irregular = {"one": "first", "two": "second", "three": "third", "five": "fifth", "eight": "eighth", "nine": "ninth",
+                 "twelve": "twelfth"}
+    words = _en_card(n)
+    head, sep, last = words.rpartition("-") if "-" in words.split(" ")[-1] else words.rpartition(" ")
+    if last in irregular:
+        last = irregular[last]
+    elif last.endswith("y"):
+        last = last[:-1] + "ieth"
+    else:
+        last = last + "th"
+    return head + sep + last
+
+
+def _fr_card(n: int) -> str:
+    ones = ["zéro", "un", "deux", "trois", "quatre", "cinq", "six", "sept", "huit", "neuf", "dix", "onze", "douze", "treize",
+            "quatorze", "quinze", "seize", "dix-sept", "dix-huit", "dix-neuf"]
+    tens = {20: "vingt", 30: "trente", 40: "quarante", 50: "cinquante", 60: "soixante"}
+    if n < 20:
+        return ones[n]
+    if n < 70:
+        t, o = divmod(n, 10)
+        if o == 0:
+            return tens[t * 10]
+        return tens[t * 10] + (" et un" if o == 1 else "-" + ones[o])
+    if n < 80:
+        return "soixante" + (" et onze" if n == 71 else "-" + ones[n - 60])
+    if n < 100:
+        return "quatre-vingts" if n == 80 else "quatre-vingt-" + ones[n - 80]
+    if n < 1000:
+        h, r = divmod(n, 100)
+        head = "cent" if h == 1 else ones[h] + " cent" + ("s" if r == 0 else "")
+        return head + (" " + _fr_card(r) if r else "")
+    if n < 10 ** 6:
+        q, r = divmod(n, 1000)
+        head = "mille" if q == 1 else _fr_card(q).replace("quatre-vingts", "quatre-vingt").replace(" cents", " cent") + " mille"
+        return head + (" " + _fr_card(r) if r else "")
+    for value, name in ((10 ** 9, "milliard"), (10 ** 6, "million")):
+        if n >= value:
+            q, r = divmod(n, value)
+            return _fr_card(q) + " " + name + ("s" if q > 1 else "") + (" " + _fr_card(r) if r else "")
+    return str(n)
+
+
+def _fr_ord(n: int) -> str:
+    if n == 1:
+        return "premier"
+    w = _fr_card(n)
+    if w.endswith("e"):
+        w = w[:-1]
+    elif w.endswith("f"):
+        w = w[:-1] + "v"
+    elif w.endswith("q"):
+        w = w + "u"
+    elif w.endswith("s") and (w.endswith("cents") or w.endswith("vingts")):
+        w = w[:-1]
+    return w + "ième"
+
+
+def _de_card(n: int, standalone: bool = True) -> str:
+    ones = ["null", "ein", "zwei", "drei", "vier", "fünf", "sechs", "sieben", "acht", "neun", "zehn", "elf", "zwölf", "dreizehn",
+            "vierzehn", "fünfzehn", "sechzehn", "siebzehn", "achtzehn", "neunzehn"]
+    tens = ["", "", "zwanzig", "dreißig", "vierzig", "fünfzig", "sechzig", "siebzig", "achtzig", "neunzig"]
+    if n == 1:
+        return "eins" if standalone else "ein"
+    if n < 20:
+        return ones[n]
+    if n < 100:
+        t, o = divmod(n, 10)
+        return (ones[o] + "und" if o else "") + tens[t]
+    if n < 1000:
+        h, r = divmod(n, 100)
+        return ones[h] + "hundert" + (_de_card(r, standalone) if r else "")
+    if n < 10 ** 6:
+        q, r = divmod(n, 1000)
+        return _de_card(q, False) + "tausend" + (_de_card(r, standalone) if r else "")
+    for value, sing, plur in ((10 ** 9, "milliarde", "milliarden"), (10 ** 6, "million", "millionen")):
+        if n >= value:
+            q, r = divmod(n, value)
+            head = "eine " + sing if q == 1 else _de_card(q, False) + " " + plur
+            return head + (" " + _de_card(r, standalone) if r else "")
+    return str(n)
+
+
+def _de_ord(n: int) -> str:
+    special = {1: "erste", 3: "dritte", 7: "siebte", 8: "achte"}
+    if n in special:
+        return special[n]
+    if n < 20:
+        return _de_card(n) + "te"
+    if n < 100 or n % 100 == 0 or n % 100 >= 20:
+        tail = n % 100
+        if 0 < tail < 20 and n >= 100:
+            return _de_card(n - tail, False) + _de_ord(tail)
+        return _de_card(n, False) + "ste"
+    return _de_card(n - n % 100, False) + _de_ord(n % 100)
+
+
+_CARD: Dict[str, Callable[[int], str]] = {"en": _en_card, "fr": _fr_card, "de": _de_card}
+_ORD: Dict[str, Callable[[int], str]] = {"en": _en_ord, "fr": _fr_ord, "de": _de_ord}
+_POINT = {"en": "point", "fr": "virgule", "de": "komma"}
+_CURRENCY_WORDS = {   # (major singular, major plural, minor singular, minor plural, joiner)
+    "en": {"USD": ("dollar", "dollars", "cent", "cents"), "GBP": ("pound", "pounds", "penny", "pence"),
+           "EUR": ("euro", "euro", "cent", "cents"), "join": ", "},
+    "fr": {"USD": ("dollar", "dollars", "cent", "cents"), "GBP": ("livre", "livres", "penny", "pence"),
+           "EUR": ("euro", "euros", "centime", "centimes"), "join": " et "},
+    "de": {"USD": ("dollar", "dollar", "cent", "cent"), "GBP": ("pfund", "pfund", "penny", "pence"),
+           "EUR": ("euro", "euro", "cent", "cent"), "join": " und "},
+}
+
+
+def _spell_decimal(text: str, lang: str) -> str:
+    whole, frac = text.replace(",", ".").split(".")
+    digits = " ".join(_CARD[lang](int(d)) for d in frac)
+    return f"{_CARD[lang](int(whole))} {_POINT[lang]} {digits}"
+
+
+def _spell_currency(m: re.Match, lang: str, cur: str) -> str:
+    amount = float(re.sub(r"[^\d.]", "", m.group(0).replace(",", ".")))
+    major, cents = int(amount), int(round((amount - int(amount)) * 100))
+    w = _CURRENCY_WORDS[lang]
+    ms, mp, cs, cp = w[cur]
+    out = f"{_CARD[lang](major)} {ms if major == 1 else mp}"
+    if cents:   # the reference drops the ", zero cents" tail of integer amounts (tokenizer.py:668-673)
+        out += f"{w['join']}{_CARD[lang](cents)} {cs if cents == 1 else cp}"
+    return out
+
+
+def expand_numbers(text: str, lang: str) -> str:
+    base = lang.split("-")[0]
+    if base not in _CARD:
+        return text
+    if base == "en":
+        text = _COMMA_NUMBER_RE.sub(lambda m: m.group(0).replace(",", ""), text)
+    else:
+        text = _DOT_NUMBER_RE.sub(lambda m: m.group(0).replace(".", ""), text)
+    for cur in ("GBP", "USD", "EUR"):
+        text = _CURRENCY_RE[cur].sub(lambda m, c=cur: _spell_currency(m, base, c), text)
+    text = _DECIMAL_RE.sub(lambda m: _spell_decimal(m.group(1), base), text)
+    text = _ORDINAL_RE[base].sub(lambda m: _ORD[base](int(m.group(1))), text)
+    return _NUMBER_RE.sub(lambda m: _CARD[base](int(m.group(0))), text)
+
+
+def expand_abbreviations(text: str, lang: str) -> str:
+    for rx, rep in _ABBREV_RE.get(lang.split("-")[0], []):
+        text = rx.sub(rep, text)
+    return text
+
+
+def expand_symbols(text: str, lang: str) -> str:
+    for sym, rep in _SYMBOLS.get(lang.split("-")[0], []):
+        text = text.replace(sym, rep).replace("  ", " ")
+    return text.strip()
+
+
+def multilingual_cleaners(text: str, lang: str) -> str:
+    text = text.replace('"', "")
+    if lang == "tr":
+        text = text.replace("İ", "i").replace("Ö", "ö").replace("Ü", "ü")
+    text = text.lower()
+    text = expand_numbers(text, lang)
+    text = expand_abbreviations(text, lang)
+    text = expand_symbols(text, lang)
+    return _WS.sub(" ", text)

@@ -1,8 +1,9 @@
 """Minimal text front-end feeding the hot path: sentence chunking and BPE ids.
 
 Reference: XTTSTokenizerFast / split_sentence / char_limits (src/auralis/models/xttsv2/config/tokenizer.py:119-236,
-742-1002).  Scope note: the multilingual cleaners / spaCy sentencizer are not restated yet; this
-module keeps the contract the engine depends on — chunks no longer than the per-language character limit,
+742-1002).  Scope note: text normalisation lives in api/cleaners.py (en/fr/de numbers spelled out; other languages
+keep digits); the spaCy sentencizer is replaced by a punctuation sentencizer; this module keeps the contract the engine
+depends on — chunks no longer than the per-language character limit,
 ids = BPE("[lang]" + text with " " -> "[SPACE]") wrapped in [START]/[STOP] — and uses the real tokenizer.json when
 the checkpoint directory has one, else a deterministic stand-in vocabulary for synthetic checkpoints."""
 from __future__ import annotations
@@ -75,14 +76,16 @@ class XTTSTokenizer:
         return CHAR_LIMITS.get(lang.split("-")[0], 250)
 
     def encode_chunk(self, text: str, lang: str) -> List[int]:
+        from .cleaners import multilingual_cleaners
         base = lang.split("-")[0]
         code = "zh-cn" if base == "zh" else base
-        s = f"[{code}]{text.strip().lower()}".replace(" ", "[SPACE]")
+        clean = multilingual_cleaners(text, lang)           # tokenizer.py:708-719 order
+        s = f"[{code}]{clean}".replace(" ", "[SPACE]")
         if self._tok is not None:
             ids = self._tok.encode(s, add_special_tokens=False).ids
         else:
             # stand-in: ~3 characters per token, stable across runs/platforms
-            raw = f"[{code}]{text.strip().lower()}"
+            raw = f"[{code}]{clean}"
             ids = [2 + zlib.crc32(raw[i:i + 3].encode("utf-8")) % (self.vocab_size - 300) for i in range(0, len(raw), 3)]
             ids = [i if i != 261 else 262 for i in ids]
         return [self.bos_token_id] + ids + [self.eos_token_id]
