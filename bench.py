@@ -88,7 +88,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # any torchrun launch, even N = 1
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -116,7 +117,7 @@ def main():
     # speaker conditioning: computed on rank 0, RCCL-broadcast over xGMI, registered from the device buffer
     cond, spk = make_synthetic_conditioning(dims)
     SPK = 1
-    if world > 1:
+    if use_dist:
         broadcast_conditioning(eng, SPK, cond if rank == 0 else None, spk if rank == 0 else None, src=0,
                                device=torch.device("cuda", local_rank))
     else:
@@ -140,7 +141,7 @@ def main():
         return total
 
     def fence():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
         eng.sync()
@@ -157,7 +158,7 @@ def main():
     dt = time.perf_counter() - t0
     st = eng.stats()
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -235,7 +236,7 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 
