@@ -322,7 +322,7 @@ public:
         AUR_REQUIRE(d.text_ids && d.n_text >= 1, "text_ids");
         AUR_REQUIRE(d.max_tokens >= 1 && d.max_tokens <= kMaxLatRows - 3, "max_tokens in [1,605]");
         const int n_prompt = 32 + d.n_text + 1;
-        AUR_REQUIRE(n_prompt + d.max_tokens <= kMaxBlocks * kKvBlockTokens, "prompt + max_tokens exceeds max_model_len");
+        AUR_REQUIRE(n_prompt + d.max_tokens + 4 <= kMaxBlocks * kKvBlockTokens, "prompt + max_tokens exceeds max_model_len");
         AUR_REQUIRE(n_prompt <= cfg_.max_prefill_rows, "prompt longer than max_prefill_rows");
         AUR_REQUIRE(d.repetition_penalty > 0.f, "repetition_penalty > 0");
         {   // reject bad text ids / positions here, not in the middle of a batched prefill
@@ -399,7 +399,8 @@ public:
                 const SpeakerInfo& si = spk_info_[s->spk_row];
                 s->shared_prefix = si.ready && share_prefix_now_;
                 const int skip = s->shared_prefix ? 2 : 0;   // table entries 0,1 = the speaker's shared prefix blocks
-                const int need = (s->n_prompt + s->params.max_tokens + kKvBlockTokens - 1) / kKvBlockTokens - skip;
+                const int extra = cfg_.second_pass ? 4 : 0;   // second pass appends 4 stop tokens after the generated ones
+                const int need = (s->n_prompt + s->params.max_tokens + extra + kKvBlockTokens - 1) / kKvBlockTokens - skip;
                 int slot = -1;
                 for (int i = 0; i < cfg_.max_seqs; ++i)
                     if (!slot_owner_[i]) {
@@ -877,19 +878,72 @@ private:
             Seq* s = slot_owner_[sample_slot[j]];
             s->tokens.push_back(pin[j]);
             stats_.tokens_generated++;
-            if (pin[cfg_.max_seqs + sample_slot[j]]) finish_tokens(s);
+            if (pin[cfg_.max_seqs + sample_slot[j]]) just_finished_.push_back(s);
         }
+    }
+    // sequences whose tokens completed in this step: (optional literal second pass) -> latent pool -> vocoder queue
+    void retire_finished() {
+        if (just_finished_.empty()) return;
+        if (cfg_.second_pass) second_pass(just_finished_);
+        for (Seq* s : just_finished_) finish_tokens(s);
+        just_finished_.clear();
+    }
+    // A/B mode (aur_config.second_pass): the reference's get_model_logits (XTTSv2.py:617-687) restated on the GPU: one
+    // prefill over [cond ; 1024 ; tokens ; 1025 x 4] with mel positions 0..N+4, collect ln_f rows of positions
+    // n_cond .. n_cond+N-1 (i.e. drop the last 5), apply final_norm twice.  The sequence still owns its slot and KV
+    // blocks, which are simply overwritten.  The default path (latent stash) never runs this.
+    void second_pass(const std::vector<Seq*>& seqs) {
+        RowWs& w = ws_[0];
+        graph_active_.clear();
+        std::vector<int4> desc;
+        std::vector<int> row_slot, row_pos, lat_row0;
+        for (Seq* s : seqs) {
+            const int first = s->shared_prefix ? 32 : 0;
+            const int n_cond = 32 + (int)s->text_ids.size();
+            for (int i = first; i < 32; ++i) desc.push_back(make_int4(0, i, s->spk_row, 0));
+            for (int i = 0; i < (int)s->text_ids.size(); ++i) desc.push_back(make_int4(1, s->text_ids[i], i, 0));
+            lat_row0.push_back((int)desc.size());
+            const int N = (int)s->tokens.size();
+            for (int j = 0; j < N + 5; ++j) {
+                const int id = (j == 0) ? kStartToken : (j <= N ? s->tokens[j - 1] : kStopToken);
+                desc.push_back(make_int4(2, id, std::min(j, kMaxLatRows - 1), 0));   // trailing rows are dropped; keep wpe in range
+            }
+            for (int i = first; i < n_cond + N + 5; ++i) {
+                row_slot.push_back(s->slot);
+                row_pos.push_back(i);
+            }
+        }
+        const int M = (int)row_slot.size();
+        ensure_rows(w, M);
+        HIP_CHECK(hipMemcpyAsync(w.i_desc.p, desc.data(), (size_t)M * sizeof(int4), hipMemcpyHostToDevice, w.st));
+        HIP_CHECK(hipMemcpyAsync(w.i_row_slot.p, row_slot.data(), (size_t)M * 4, hipMemcpyHostToDevice, w.st));
+        HIP_CHECK(hipMemcpyAsync(w.i_row_pos.p, row_pos.data(), (size_t)M * 4, hipMemcpyHostToDevice, w.st));
+        launch_embed_prompt(w.i_desc.as<int4>(), spk_table_.as<float>(), text_emb_, text_pos_, wte_, wpe_, w.h.as<float>(), M, w.st);
+        forward_rows(w, M, w.i_row_slot.as<int>(), w.i_row_pos.as<int>());
+        for (size_t k = 0; k < seqs.size(); ++k) {
+            Seq* s = seqs[k];
+            if (latpool_free_.empty()) throw HipError("latent pool exhausted");
+            s->pool_idx = latpool_free_.back();
+            latpool_free_.pop_back();
+            launch_double_norm_rows(w.xn.as<float>() + (long)lat_row0[k] * kHidden,
+                                    latpool_.as<float>() + (long)s->pool_idx * kMaxLatRows * kHidden, (int)s->tokens.size(),
+                                    fnw_, fnb_, 1e-5f, w.st);
+        }
+        HIP_CHECK(hipStreamSynchronize(w.st));
+        stats_.prefill_rows += M;
     }
     void finish_tokens(Seq* s) {
         s->state = SeqState::TOKENS_DONE;
         // park the stashed latents in the pool (D2D on the main stream, ordered before any later prefill that reuses
         // the slot) and release slot + KV blocks at once: the vocoder stage no longer occupies a batcher slot
-        if (latpool_free_.empty()) throw HipError("latent pool exhausted");
-        s->pool_idx = latpool_free_.back();
-        latpool_free_.pop_back();
-        const size_t n = s->tokens.size() * (size_t)kHidden * sizeof(float);
-        HIP_CHECK(hipMemcpyAsync(latpool_.as<float>() + (long)s->pool_idx * kMaxLatRows * kHidden,
-                                 latents_.as<float>() + (long)s->slot * kMaxLatRows * kHidden, n, hipMemcpyDeviceToDevice, st_));
+        if (s->pool_idx < 0) {   // (the second-pass mode has already written the pool entry)
+            if (latpool_free_.empty()) throw HipError("latent pool exhausted");
+            s->pool_idx = latpool_free_.back();
+            latpool_free_.pop_back();
+            const size_t n = s->tokens.size() * (size_t)kHidden * sizeof(float);
+            HIP_CHECK(hipMemcpyAsync(latpool_.as<float>() + (long)s->pool_idx * kMaxLatRows * kHidden,
+                                     latents_.as<float>() + (long)s->slot * kMaxLatRows * kHidden, n, hipMemcpyDeviceToDevice, st_));
+        }
         HIP_CHECK(hipEventRecord(ev_lat_, st_));
         std::lock_guard<std::mutex> lk(mu_);
         for (int b : s->blocks) free_blocks_.push_back(b);
@@ -957,6 +1011,7 @@ private:
         sample_launch(w, sample_row, sample_slot, &next_kvpos);
         HIP_CHECK(hipStreamSynchronize(w.st));
         sample_collect(w, sample_slot);
+        retire_finished();
     }
     // One decode step.  The kernel chain of a step (embed -> 30 layers -> final_norm -> head GEMM -> sampler, ~250
     // launches) depends only on device-resident state, so it is captured once per live-set shape in a hipGraph and
@@ -1025,6 +1080,7 @@ private:
         for (int k = 0; k < n_ws; ++k) sample_readback(ws_[k], (int)ws_[k].sample_slot.size(), st_);
         HIP_CHECK(hipStreamSynchronize(st_));
         for (int k = 0; k < n_ws; ++k) sample_collect(ws_[k], ws_[k].sample_slot);
+        retire_finished();
         stats_.decode_rows += M;
     }
 
@@ -1315,6 +1371,7 @@ private:
     std::unordered_map<uint64_t, std::unique_ptr<Seq>> seqs_;
     std::deque<Seq*> waiting_, done_;
     std::vector<Seq*> slot_owner_;
+    std::vector<Seq*> just_finished_;
     int64_t finished_total_ = 0;
     aur_stats stats_{};
 };

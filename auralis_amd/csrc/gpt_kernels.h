@@ -59,6 +59,9 @@ void launch_final_norm(const float* xn, const int* sample_row, const int* sample
                        const float* beta, float* ybuf, float* latents, long lat_slot_stride,
                        const int* slot_ngen, int max_lat_rows, int Ms, float eps, hipStream_t st);
 
+void launch_double_norm_rows(const float* src, float* dst, int n, const float* gamma, const float* beta, float eps,
+                             hipStream_t st);
+
 struct SamplerArgs {
     const float* P;          // [S][Ms][Npad] logits slabs
     int S, Ms, Npad, V;

@@ -519,6 +519,30 @@ __global__ __launch_bounds__(256) void final_norm_kernel(const float* __restrict
     }
 }
 
+// dst[j] = final_norm(final_norm(src[j]))  for n contiguous rows (literal second pass, XTTSv2.py:685-687 on top of
+// vllm_mm_gpt.py:671)
+__global__ __launch_bounds__(256) void double_norm_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= n) return;
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (long)j * kHidden + 4 * (lane + 64 * u));
+    ln_wave(v, gamma, beta, lane, eps);
+    ln_wave(v, gamma, beta, lane, eps);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(dst + (long)j * kHidden + 4 * (lane + 64 * u)) = v[u];
+}
+
+void launch_double_norm_rows(const float* src, float* dst, int n, const float* gamma, const float* beta, float eps,
+                             hipStream_t st) {
+    trace_launch("double_norm_rows_kernel");
+    hipLaunchKernelGGL(double_norm_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, st, src, dst, n, gamma, beta, eps);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_final_norm(const float* xn, const int* sample_row, const int* sample_slot, const float* gamma,
                        const float* beta, float* ybuf, float* latents, long lat_slot_stride,
                        const int* slot_ngen, int max_lat_rows, int Ms, float eps, hipStream_t st) {

@@ -42,6 +42,8 @@ typedef struct aur_config {
     int32_t profile;          /* 1 = record HIP events around the vocoder conv launches (aur_stats) */
     int32_t vocoder_fp16;     /* 1 = HiFi-GAN convs on fp16-input / fp32-accumulate MFMA (needs the voc16.* tensors);
                                  0 = exact-f32 MFMA parity mode */
+    int32_t second_pass;      /* 1 = A/B mode: recompute the latents with the reference's literal second GPT pass
+                                 (XTTSv2.py:617-687) instead of the decode-time stash */
 } aur_config;
 
 /* One named fp32 tensor.  Names are the packed names produced by auralis_amd/weights.py from the

@@ -134,3 +134,28 @@ def test_full_depth_greedy_short(dims):
         assert np.abs(got["latents"] - lat_ref).max() < 5e-3
     finally:
         e.close()
+
+
+def test_literal_second_pass_mode_matches_stash_and_oracle(dims):
+    """aur_config.second_pass = 1 recomputes the latents the reference's way (XTTSv2.py:617-687) on the GPU: same
+    tokens, latents equal to the decode-time stash within fp32 reordering noise, and to the oracle's second pass."""
+    from oracle import xtts_oracle as O
+    e1, gpt_sd, xtts_sd, cond, spk = make_engine(3, max_seqs=3)
+    e2, *_ = make_engine(3, max_seqs=3, second_pass=True)
+    try:
+        gpt = O.GPTOracle(gpt_sd, xtts_sd)
+        outs = []
+        for e in (e1, e2):
+            for n_text, mt, seed in ((16, 30, 1), (9, 12, 2), (25, 21, 3)):
+                e.submit(make_synthetic_text_ids(dims, n_text=n_text, seed=seed), SPK_KEY, temperature=0.0, max_tokens=mt, ignore_stop=True)
+            outs.append(sorted(e.run_until_done(), key=lambda o: o["seq_id"]))
+        for a, b in zip(*outs):
+            assert a["tokens"].tolist() == b["tokens"].tolist()
+            assert np.abs(a["latents"] - b["latents"]).max() < 2e-3
+            assert rms(a["wav"] - b["wav"]) < 1e-4
+        ids = make_synthetic_text_ids(dims, n_text=16, seed=1)
+        lat_ref = gpt.second_pass_latents(gpt.build_cond(cond, ids), outs[1][0]["tokens"].tolist())[0].numpy()
+        assert np.abs(outs[1][0]["latents"] - lat_ref).max() < 1e-3
+    finally:
+        e1.close()
+        e2.close()
