@@ -1,0 +1,61 @@
+"""Long-form / mixed-language streaming (BASELINE config 5 at test scale): CPU with the fake engine, GPU with the real one."""
+import numpy as np
+import pytest
+
+from auralis_amd import TTS, TTSOutput
+from auralis_amd.api.text import CHAR_LIMITS, XTTSTokenizer, split_sentence
+from auralis_amd.api.xtts_engine import XTTSv2Engine
+from auralis_amd.longform import build_requests, split_paragraphs, stream_longform
+from tests.fakes import FakeNativeEngine
+
+EN = ("It was a bright cold day in April, and the clocks were striking thirteen. Nobody in the street seemed to notice, "
+      "and the wind kept pushing the dust along the old road as if nothing had happened at all. " * 2)
+FR = ("Il était une fois, dans une petite ville que nous ne connaissons pas, un homme qui avait beaucoup d'idées et très peu "
+      "de temps pour les écrire. Il marchait chaque matin le long de la rivière avec son chien. " * 2)
+DE = ("Es war einmal ein Mann, der nicht mit dem Zug fahren wollte und auch nicht zu Fuß gehen konnte, weil der Weg durch "
+      "den Wald zu lang war. Also blieb er zu Hause und schrieb Briefe an seine Freunde. " * 2)
+BOOK = "\n\n".join([EN, FR, DE, EN[:120], FR[:150], DE[:90]])
+VOICE = {"gpt_cond_latent": np.zeros((1, 32, 1024), np.float32), "speaker_embedding": np.ones((1, 512, 1), np.float32)}
+
+
+def _expected_chunks(reqs):
+    return [len(split_sentence(r.text, r.language, CHAR_LIMITS[r.language])) for r in reqs]
+
+
+def test_longform_requests_and_order_cpu():
+    paras = split_paragraphs(BOOK)
+    reqs = build_requests(paras, [VOICE], seed=7)
+    assert [r.language for r in reqs] == ["en", "fr", "de", "en", "fr", "de"]
+    fake = FakeNativeEngine(max_seqs=3)
+    tts = TTS(scheduler_max_concurrency=3).with_engine(XTTSv2Engine(fake, XTTSTokenizer(None)))
+    try:
+        got = list(stream_longform(tts, reqs, window=3))
+        idx = [i for i, _ in got]
+        assert idx == sorted(idx)                                       # paragraph order preserved
+        counts = [idx.count(i) for i in range(len(reqs))]
+        assert counts == _expected_chunks(reqs) and sum(counts) == len(fake.submitted)
+        assert all(isinstance(c, TTSOutput) and len(c.array) > 0 for _, c in got)
+    finally:
+        tts.close()
+
+
+@pytest.mark.gpu
+def test_longform_mixed_languages_gpu(tmp_path, dims):
+    from auralis_amd.checkpoint import make_synthetic_conditioning, make_synthetic_gpt, make_synthetic_xtts, save_checkpoint
+    gpt_sd = make_synthetic_gpt(dims.gpt, seed=1234, n_layer=2)
+    gpt_sd["mel_head.bias"][1025] = 3.0          # natural stops after a handful of tokens
+    save_checkpoint(str(tmp_path), gpt_sd, make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd), dims)
+    cond, spk = make_synthetic_conditioning(dims)
+    voice = {"gpt_cond_latent": cond.numpy(), "speaker_embedding": spk.numpy()}
+    reqs = build_requests(split_paragraphs(BOOK), [voice], seed=3, temperature=0.0)
+    tts = TTS(scheduler_max_concurrency=8).from_pretrained(str(tmp_path))
+    try:
+        got = list(stream_longform(tts, reqs, window=4))
+        idx = [i for i, _ in got]
+        assert idx == sorted(idx) and [idx.count(i) for i in range(len(reqs))] == _expected_chunks(reqs)
+        audio = TTSOutput.combine_outputs([c for _, c in got])
+        assert len(audio.array) > 0 and np.isfinite(audio.array).all()
+        again = TTSOutput.combine_outputs([c for _, c in stream_longform(tts, reqs, window=2)])
+        assert np.array_equal(audio.array, again.array)                 # greedy: independent of the window / batching
+    finally:
+        tts.close()
