@@ -186,6 +186,8 @@ public:
         HIP_CHECK(hipEventCreate(&ev_ws1_));
         ws_[0].st = st_;
         ws_[1].st = st2_;
+        xt_f16_ = cfg_.vocoder_fp16 != 0;   // fp16 storage of the ResBlock c1 -> c2 intermediate (bit-identical, see ConvArgs)
+        if (const char* e = getenv("AUR_XT_F16")) xt_f16_ = xt_f16_ && atoi(e) != 0;
         if (const char* e = getenv("AUR_DECODE_STREAMS")) decode_streams_ = atoi(e);
         if (const char* e = getenv("AUR_DECODE_GRAPH")) decode_graph_ = atoi(e) != 0;
         HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
@@ -1125,7 +1127,9 @@ private:
             }
             ev = &conv_events_[n_conv_events_++];
             ev->flops = 2.0 * a.Cin * KS * a.Mtot * tot_in;
-            ev->bytes = 4.0 * (a.Cin * tot_in + a.Cout * tot_out * (1.0 + (a.res ? 1.0 : 0.0) + (a.mrf_mode >= 2 ? 1.0 : 0.0)));
+            // bytes in the dtype each tensor is actually stored in (the c1 -> c2 intermediate may be fp16)
+            ev->bytes = (a.x_f16 ? 2.0 : 4.0) * a.Cin * tot_in +
+                        a.Cout * tot_out * ((a.out_act_f16 ? 2.0 : 4.0) + 4.0 * ((a.res ? 1.0 : 0.0) + (a.mrf_mode >= 2 ? 1.0 : 0.0)));
             HIP_CHECK(hipEventRecord(ev->a, st_voc_));
         }
         if (cfg_.vocoder_fp16)
@@ -1218,8 +1222,10 @@ private:
                     b1.len_mul = mul_out; b1.Cin = C; b1.Mtot = C; b1.Cout = C;
                     b1.x_stride = Lout; b1.o_stride = Lout; b1.x_bstride = (long)C * Lout; b1.o_bstride = (long)C * Lout;
                     b1.padl = (rk[j] - 1) / 2 * rd[c]; b1.slope = 0.1f; b1.max_len = maxT * mul_out;
+                    if (xt_f16_) { b1.out_act_f16 = 1; b1.out_slope = 0.1f; }
                     conv(b1, rk[j], rd[c], totT * mul_out, totT * mul_out);
                     ConvArgs b2 = b1;
+                    b2.out_act_f16 = 0; b2.x_f16 = xt_f16_ ? 1 : 0;
                     b2.x = Bb; b2.wp = v_c2_[i][j][c].wp; b2.wp16 = v_c2_[i][j][c].wp16; b2.bias = v_c2_[i][j][c].bias; b2.res = r;
                     b2.padl = (rk[j] - 1) / 2;
                     if (c < 2) {
@@ -1341,6 +1347,7 @@ private:
     int voc_max_samples_ = 0;
     bool voc_active_ = false;
     PinBuf voc_pin_;
+    bool xt_f16_ = false;               // set in the constructor: fp16 vocoder => fp16 c1 -> c2 intermediate (AUR_XT_F16=0 disables)
     bool decode_graph_ = false;         // AUR_DECODE_GRAPH=1: hipGraph replay of the decode step (measured neutral: the
                                         // step is GPU-bound, and re-capturing on every live-set change costs)
     hipGraphExec_t graph_exec_ = nullptr;

@@ -32,6 +32,12 @@ struct ConvArgs {
     int mrf_mode;           // 0 none; 1 mrf = v; 2 mrf += v; 3 out = (mrf + v) / 3
     int max_len;            // max over batch of valid input length (grid sizing)
     int B;
+    // fp16 kernel only: the c1 -> c2 intermediate of a ResBlock can live in HBM as fp16.  out_act_f16: the epilogue
+    // stores (_Float16)lrelu(value, out_slope) -- exactly what the consumer's staging would have produced from the fp32
+    // value -- and the consumer sets x_f16 (input rows are halves, already activated; its `slope` is ignored).
+    // Strides stay in elements.  Bit-identical results, half the bytes for that tensor.
+    int x_f16, out_act_f16;
+    float out_slope;
 };
 
 void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st);

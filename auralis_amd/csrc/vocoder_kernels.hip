@@ -17,47 +17,116 @@ namespace aur {
 
 // Shared epilogue of the MFMA conv kernels: bias, speaker conditioning, residual, MRF fold, masked store.
 // D layout of the 32x32 MFMAs: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-template <int WM, int WN, int MT, int NTW>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[WM][WN], int b, int mtile, int q0, int wv,
-                                              int l31, int hi, int len_in, int n_q) {
+// Epilogue.  Every global read the epilogue needs (bias / conditioning per output row, residual and MRF accumulator
+// per element) is issued as a batch of unconditional loads at clamped addresses, then a scheduling fence, then the
+// arithmetic and the predicated stores: a predicated load inside the r/n loops made hipcc emit
+// load -> s_waitcnt vmcnt(0) -> store 64 times per wave, i.e. 64 serialized memory round trips per tile.
+// add[r] = bias[co] + cond[b][co] for the 16 accumulator rows of 32-row tile m (all loads issued together)
+template <int MT, bool UPS>
+__device__ __forceinline__ void conv_row_adds(const ConvArgs& a, float (&add)[16], int b, int mtile, int m, int hi) {
+    int co[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int v = mtile * MT + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        co[r] = UPS ? v / a.ups_s : v;
+        add[r] = 0.f;
+    }
+    if (a.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) add[r] = a.bias[co[r]];
+    }
+    if (a.cond) {
+        const float* cb = a.cond + (long)a.cond_row[b] * a.cond_stride;
+        float cv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cv[r] = cb[co[r]];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) add[r] += cv[r];
+    }
+}
+
+// plain conv (ups_s == 0): t == q, len_out == n_q
+template <int WM, int WN, int MT, int NTW, int MODE>
+__device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, f32x16 (&acc)[WM][WN], int b, int mtile, int q0, int wv,
+                                                    int l31, int hi, int n_q) {
     const long ob = (long)b * a.o_bstride;
-    const int len_out = a.ups_s ? len_in * a.ups_s : len_in;
+    const bool has_res = a.res != nullptr;
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
+        float add[16];
+        conv_row_adds<MT, false>(a, add, b, mtile, m, hi);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const int v = mtile * MT + m * 32 + row;
-            int co, toff;
-            if (a.ups_s) {
-                co = v / a.ups_s;
-                toff = (v - co * a.ups_s) - a.ups_p;
-            } else {
-                co = v;
-                toff = 0;
+        for (int n = 0; n < WN; ++n) {
+            const int q = q0 + wv * NTW + n * 32 + l31;
+            const bool ok = q < n_q;
+            const long base = ob + (long)(mtile * MT + m * 32 + 4 * hi) * a.o_stride + min(q, n_q - 1);
+            float rv[16], mv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = a.res[base + (long)((r & 3) + 8 * (r >> 2)) * a.o_stride];
             }
-            float add = a.bias ? a.bias[co] : 0.f;
-            if (a.cond) add += a.cond[(long)a.cond_row[b] * a.cond_stride + co];
+            if (MODE >= 2) {
 #pragma unroll
-            for (int n = 0; n < WN; ++n) {
-                const int q = q0 + wv * NTW + n * 32 + l31;
-                const int t = a.ups_s ? q * a.ups_s + toff : q;
-                if (q < n_q && t >= 0 && t < len_out) {
-                    const long off = ob + (long)co * a.o_stride + t;
-                    float val = acc[m][n][r] + add;
-                    if (a.res) val += a.res[off];
-                    if (a.mrf_mode == 0) {
-                        a.out[off] = val;
-                    } else if (a.mrf_mode == 1) {
-                        a.mrf[off] = val;
-                    } else if (a.mrf_mode == 2) {
-                        a.mrf[off] = a.mrf[off] + val;
-                    } else {
-                        a.out[off] = (a.mrf[off] + val) / 3.0f;
-                    }
+                for (int r = 0; r < 16; ++r) mv[r] = a.mrf[base + (long)((r & 3) + 8 * (r >> 2)) * a.o_stride];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // all loads of this 32x32 tile are in flight before the first use
+            if (ok) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long off = base + (long)((r & 3) + 8 * (r >> 2)) * a.o_stride;
+                    const float val = acc[m][n][r] + add[r] + rv[r];
+                    if (MODE == 0) {
+                        if (a.out_act_f16) reinterpret_cast<_Float16*>(a.out)[off] = (_Float16)lrelu(val, a.out_slope);
+                        else a.out[off] = val;
+                    } else if (MODE == 1) a.mrf[off] = val;
+                    else if (MODE == 2) a.mrf[off] = mv[r] + val;
+                    else a.out[off] = (mv[r] + val) / 3.0f;
                 }
             }
         }
+    }
+}
+
+// polyphase transposed conv: virtual row v = co*s + phase lands at t = q*s + phase - p (no residual / MRF on these layers)
+template <int WM, int WN, int MT, int NTW>
+__device__ __forceinline__ void conv_epilogue_ups(const ConvArgs& a, f32x16 (&acc)[WM][WN], int b, int mtile, int q0, int wv,
+                                                  int l31, int hi, int len_in, int n_q) {
+    const long ob = (long)b * a.o_bstride;
+    const int len_out = len_in * a.ups_s;
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+        float add[16];
+        conv_row_adds<MT, true>(a, add, b, mtile, m, hi);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int v = mtile * MT + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int co = v / a.ups_s;
+            const int toff = (v - co * a.ups_s) - a.ups_p;
+#pragma unroll
+            for (int n = 0; n < WN; ++n) {
+                const int q = q0 + wv * NTW + n * 32 + l31;
+                const int t = q * a.ups_s + toff;
+                if (q < n_q && t >= 0 && t < len_out) a.out[ob + (long)co * a.o_stride + t] = acc[m][n][r] + add[r];
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int MT, int NTW>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[WM][WN], int b, int mtile, int q0, int wv,
+                                              int l31, int hi, int len_in, int n_q) {
+    if (a.ups_s) {
+        conv_epilogue_ups<WM, WN, MT, NTW>(a, acc, b, mtile, q0, wv, l31, hi, len_in, n_q);
+    } else if (a.mrf_mode == 0) {
+        conv_epilogue_plain<WM, WN, MT, NTW, 0>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
+    } else if (a.mrf_mode == 1) {
+        conv_epilogue_plain<WM, WN, MT, NTW, 1>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
+    } else if (a.mrf_mode == 2) {
+        conv_epilogue_plain<WM, WN, MT, NTW, 2>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
+    } else {
+        conv_epilogue_plain<WM, WN, MT, NTW, 3>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
     }
 }
 
@@ -202,6 +271,7 @@ template <int KS, int DIL, int MT, int CK>
 static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
     constexpr int NT = (MT == 64) ? 256 : 512;
     AUR_REQUIRE(a.Cin % CK == 0, "conv: Cin % CK");
+    AUR_REQUIRE(!a.x_f16 && !a.out_act_f16, "conv: fp16 tensors need the fp16 kernel");
     AUR_REQUIRE(a.Mtot % MT == 0, "conv: Mtot % MT");
     const int n_q = a.ups_s ? a.max_len + 1 : a.max_len;
     dim3 grid((n_q + NT - 1) / NT, a.Mtot / MT, a.B);
@@ -242,7 +312,8 @@ void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
 //   B[k][n = lane&31]                 = x[ci0 + k][t]     (LDS rows [t][16 ch], 48-B row pitch => conflict-free b128)
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
-template <int KS, int DIL, int MT>
+// XH: the input tensor is fp16 in HBM and already activated (ConvArgs::x_f16), staged without conversion.
+template <int KS, int DIL, int MT, bool XH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void conv1d_mfma_f16_kernel(ConvArgs a) {
     constexpr int CK = 16;
     constexpr int WM = MT / 32;
@@ -281,10 +352,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     const float* xb = a.x + (long)b * a.x_bstride;
+    const _Float16* xhb = reinterpret_cast<const _Float16*>(a.x) + (long)b * a.x_bstride;
     const float slope = a.slope;
     const uint4* wsrc_tile = reinterpret_cast<const uint4*>(a.wp16) + (long)mtile * (a.Cin / CK) * NW;
 
-    float xv[XI][CK];
+    float xv[XH ? 1 : XI][XH ? 1 : CK];
+    _Float16 xhv[XH ? XI : 1][XH ? CK : 1];
     uint4 w0, w1, w2, w3, w4, w5;
     w0 = w1 = w2 = w3 = w4 = w5 = uint4{0, 0, 0, 0};
 #define AUR_WLD(i, reg) \
@@ -301,7 +374,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             const int t = q0 - a.padl + tid + it * 256;
             const int tc = min(max(t, 0), len_in - 1);
 #pragma unroll
-            for (int c = 0; c < CK; ++c) xv[it][c] = xb[(long)(ci0 + c) * a.x_stride + tc];
+            for (int c = 0; c < CK; ++c) {
+                if constexpr (XH) xhv[it][c] = xhb[(long)(ci0 + c) * a.x_stride + tc];
+                else xv[it][c] = xb[(long)(ci0 + c) * a.x_stride + tc];
+            }
         }
         AUR_WLD(0, w0) AUR_WLD(1, w1) AUR_WLD(2, w2) AUR_WLD(3, w3) AUR_WLD(4, w4) AUR_WLD(5, w5)
     };
@@ -314,8 +390,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             h16x8 lo, hh;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                lo[c] = (_Float16)(ok ? lrelu(xv[it][c], slope) : 0.f);
-                hh[c] = (_Float16)(ok ? lrelu(xv[it][c + 8], slope) : 0.f);
+                if constexpr (XH) {
+                    lo[c] = ok ? xhv[it][c] : (_Float16)0.f;
+                    hh[c] = ok ? xhv[it][c + 8] : (_Float16)0.f;
+                } else {
+                    lo[c] = (_Float16)(ok ? lrelu(xv[it][c], slope) : 0.f);
+                    hh[c] = (_Float16)(ok ? lrelu(xv[it][c + 8], slope) : 0.f);
+                }
             }
             if (i < XROW) {
                 *reinterpret_cast<h16x8*>(&xs[i * RS]) = lo;
@@ -358,35 +439,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     conv_epilogue<WM, WN, MT, NTW>(a, acc, b, mtile, q0, wv, l31, hi, len_in, n_q);
 }
 
-template <int KS, int DIL>
+template <int KS, int DIL, bool XH>
 static void launch_conv_f16_t(const ConvArgs& a, hipStream_t st) {
     AUR_REQUIRE(a.Cin % 16 == 0 && a.wp16, "conv f16: Cin % 16, packed fp16 weights");
+    AUR_REQUIRE(!a.out_act_f16 || (a.mrf_mode == 0 && a.ups_s == 0), "conv f16: fp16 output only for plain convs");
     const int n_q = a.ups_s ? a.max_len + 1 : a.max_len;
     trace_launch("conv1d_mfma_f16_kernel");
     if (a.Mtot % 64 == 0) {
         constexpr int NT64 = 128 * AUR_F16_WN64;
         dim3 grid((n_q + NT64 - 1) / NT64, a.Mtot / 64, a.B);
-        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 64>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 64, XH>), grid, dim3(256), 0, st, a);
     } else {
         AUR_REQUIRE(a.Mtot % 32 == 0, "conv f16: Mtot % 32");
         constexpr int NT32 = 128 * AUR_F16_WN32;
         dim3 grid((n_q + NT32 - 1) / NT32, a.Mtot / 32, a.B);
-        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 32>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 32, XH>), grid, dim3(256), 0, st, a);
     }
 }
 
 void launch_conv1d_f16(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
+    if (a.x_f16) {   // fp16 inputs exist only for the second conv of a ResBlock pair (dilation 1)
+        switch (KS * 16 + DIL) {
+            case 3 * 16 + 1: launch_conv_f16_t<3, 1, true>(a, st); break;
+            case 7 * 16 + 1: launch_conv_f16_t<7, 1, true>(a, st); break;
+            case 11 * 16 + 1: launch_conv_f16_t<11, 1, true>(a, st); break;
+            default: throw HipError("launch_conv1d_f16: fp16 input only for k in {3,7,11}, dilation 1");
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     switch (KS * 16 + DIL) {
-        case 2 * 16 + 1: launch_conv_f16_t<2, 1>(a, st); break;
-        case 3 * 16 + 1: launch_conv_f16_t<3, 1>(a, st); break;
-        case 3 * 16 + 3: launch_conv_f16_t<3, 3>(a, st); break;
-        case 3 * 16 + 5: launch_conv_f16_t<3, 5>(a, st); break;
-        case 7 * 16 + 1: launch_conv_f16_t<7, 1>(a, st); break;
-        case 7 * 16 + 3: launch_conv_f16_t<7, 3>(a, st); break;
-        case 7 * 16 + 5: launch_conv_f16_t<7, 5>(a, st); break;
-        case 11 * 16 + 1: launch_conv_f16_t<11, 1>(a, st); break;
-        case 11 * 16 + 3: launch_conv_f16_t<11, 3>(a, st); break;
-        case 11 * 16 + 5: launch_conv_f16_t<11, 5>(a, st); break;
+        case 2 * 16 + 1: launch_conv_f16_t<2, 1, false>(a, st); break;
+        case 3 * 16 + 1: launch_conv_f16_t<3, 1, false>(a, st); break;
+        case 3 * 16 + 3: launch_conv_f16_t<3, 3, false>(a, st); break;
+        case 3 * 16 + 5: launch_conv_f16_t<3, 5, false>(a, st); break;
+        case 7 * 16 + 1: launch_conv_f16_t<7, 1, false>(a, st); break;
+        case 7 * 16 + 3: launch_conv_f16_t<7, 3, false>(a, st); break;
+        case 7 * 16 + 5: launch_conv_f16_t<7, 5, false>(a, st); break;
+        case 11 * 16 + 1: launch_conv_f16_t<11, 1, false>(a, st); break;
+        case 11 * 16 + 3: launch_conv_f16_t<11, 3, false>(a, st); break;
+        case 11 * 16 + 5: launch_conv_f16_t<11, 5, false>(a, st); break;
         default: throw HipError("launch_conv1d_f16: unsupported (kernel,dilation)");
     }
     HIP_CHECK(hipGetLastError());
@@ -458,12 +550,28 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
     const int tid = threadIdx.x;
     for (int i = tid; i < Cin * KS; i += 256) wsm[i] = w[i];
     const float* xb = x + (long)b * x_bstride;
-    for (int c = 0; c < Cin; ++c) {
-        const float* xr = xb + (long)c * x_stride;
-        for (int i = tid; i < NT + KS - 1; i += 256) {
-            const int t = t0 - 3 + i;
-            float v = (t >= 0 && t < len) ? xr[t] : 0.f;
-            xs[c][i] = lrelu(v, slope);
+    // stage 16 channels per pass: 16 unconditional loads at clamped addresses in flight per thread (a predicated load
+    // per channel serialised 32 memory round trips), masked when written to LDS; lanes 0..5 also fetch the right halo
+    constexpr int CU = 16;
+    const int tm = t0 - 3 + tid, th = t0 - 3 + NT + tid;
+    const int tmc = min(max(tm, 0), len - 1), thc = min(max(th, 0), len - 1);
+    const bool okm = tm >= 0 && tm < len, okh = th >= 0 && th < len;
+    for (int c0 = 0; c0 < Cin; c0 += CU) {
+        float v[CU], h[CU];
+#pragma unroll
+        for (int u = 0; u < CU; ++u) v[u] = xb[(long)min(c0 + u, Cin - 1) * x_stride + tmc];
+        if (tid < KS - 1) {
+#pragma unroll
+            for (int u = 0; u < CU; ++u) h[u] = xb[(long)min(c0 + u, Cin - 1) * x_stride + thc];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < CU; ++u)
+            if (c0 + u < Cin) xs[c0 + u][tid] = okm ? lrelu(v[u], slope) : 0.f;
+        if (tid < KS - 1) {
+#pragma unroll
+            for (int u = 0; u < CU; ++u)
+                if (c0 + u < Cin) xs[c0 + u][NT + tid] = okh ? lrelu(h[u], slope) : 0.f;
         }
     }
     __syncthreads();

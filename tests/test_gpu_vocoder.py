@@ -104,3 +104,20 @@ def test_vocoder_fp16_full_length(ctx16, ctx, dims):
         err, sig = rms(a - b), rms(b)
         assert err <= 1e-3 and err <= 1e-2 * sig, (err, sig)
     assert np.array_equal(w16[0], e16.vocode(lat[:1], None, SPK_KEY)[0])       # deterministic, batch invariant
+
+
+def test_vocoder_fp16_intermediate_storage_is_bit_identical(ctx16, monkeypatch):
+    """The ResBlock c1 -> c2 intermediate is stored as fp16(lrelu(x)) in HBM (what the consumer's staging computes
+    anyway); AUR_XT_F16=0 keeps it fp32.  Both engines must produce the same bits."""
+    e16, _, _ = ctx16
+    monkeypatch.setenv("AUR_XT_F16", "0")
+    e_ref, *_ = make_engine(1, max_seqs=2, vocoder_fp16=True)
+    try:
+        gen = torch.Generator().manual_seed(4)
+        lat = torch.randn(2, 57, 1024, generator=gen).numpy()
+        a = e16.vocode(lat, [57, 20], SPK_KEY)
+        b = e_ref.vocode(lat, [57, 20], SPK_KEY)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    finally:
+        e_ref.close()
