@@ -146,7 +146,13 @@ class Engine {
 public:
     Engine(const aur_config& c, int device) : cfg_(c), device_(device) {
         HIP_CHECK(hipSetDevice(device_));
-        HIP_CHECK(hipStreamCreateWithFlags(&st_, hipStreamDefault));   // blocking w.r.t. the null stream on purpose
+        // GPT stream at the highest priority, vocoder stream at the lowest: when a vocoder batch overlaps the decode steps
+        // of other sequences, the latency-bound decode kernels get the CUs first and the vocoder fills what is left
+        int prio_lo = 0, prio_hi = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        if (const char* e = getenv("AUR_STREAM_PRIORITY"))
+            if (atoi(e) == 0) prio_lo = prio_hi = 0;
+        HIP_CHECK(hipStreamCreateWithPriority(&st_, hipStreamDefault, prio_hi));   // blocking w.r.t. the null stream on purpose
         AUR_REQUIRE(c.n_layer >= 1 && c.n_layer <= 64, "n_layer in [1,64]");
         AUR_REQUIRE(c.max_seqs >= 1 && c.max_seqs <= 4096, "max_seqs in [1,4096]");
         if (cfg_.max_prefill_rows <= 0) cfg_.max_prefill_rows = 8192;
@@ -176,8 +182,8 @@ public:
         spk_info_.assign(cfg_.max_speakers, SpeakerInfo{});
         if (const char* e = getenv("AUR_SHARE_PREFIX")) share_prefix_ = atoi(e) != 0;
         slot_owner_.assign(S, nullptr);
-        HIP_CHECK(hipStreamCreateWithFlags(&st2_, hipStreamDefault));
-        HIP_CHECK(hipStreamCreateWithFlags(&st_voc_, hipStreamDefault));
+        HIP_CHECK(hipStreamCreateWithPriority(&st2_, hipStreamDefault, prio_hi));
+        HIP_CHECK(hipStreamCreateWithPriority(&st_voc_, hipStreamDefault, prio_lo));
         HIP_CHECK(hipEventCreateWithFlags(&ev_lat_, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ev_voc_done_, hipEventDisableTiming));
         HIP_CHECK(hipEventRecord(ev_lat_, st_));
@@ -189,6 +195,12 @@ public:
         xt_f16_ = cfg_.vocoder_fp16 != 0;   // fp16 storage of the ResBlock c1 -> c2 intermediate (bit-identical, see ConvArgs)
         if (const char* e = getenv("AUR_XT_F16")) xt_f16_ = xt_f16_ && atoi(e) != 0;
         if (const char* e = getenv("AUR_DECODE_STREAMS")) decode_streams_ = atoi(e);
+        if (const char* e = getenv("AUR_DECODE_PIPELINE")) pipeline_ = atoi(e) != 0;
+        for (int i = 0; i < 2; ++i) {
+            HIP_CHECK(hipEventCreateWithFlags(&ev_rb_[i], hipEventDisableTiming));
+            HIP_CHECK(hipEventCreate(&ev_ds_[i]));
+            HIP_CHECK(hipEventCreate(&ev_de_[i]));
+        }
         if (const char* e = getenv("AUR_DECODE_GRAPH")) decode_graph_ = atoi(e) != 0;
         HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
         HIP_CHECK(hipEventCreate(&ev_a_));
@@ -206,6 +218,11 @@ public:
             }
         (void)hipEventDestroy(ev_a_);
         (void)hipEventDestroy(ev_b_);
+        for (int i = 0; i < 2; ++i) {
+            (void)hipEventDestroy(ev_rb_[i]);
+            (void)hipEventDestroy(ev_ds_[i]);
+            (void)hipEventDestroy(ev_de_[i]);
+        }
         if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
         (void)hipEventDestroy(ev_fork_);
         (void)hipEventDestroy(ev_ws1_);
@@ -426,30 +443,32 @@ public:
                 admitted.push_back(s);
             }
         }
-        HIP_CHECK(hipEventRecord(ev_a_, st_));
         if (!admitted.empty()) {
-            prefill(admitted);
+            HIP_CHECK(hipEventRecord(ev_a_, st_));
+            prefill(admitted);   // synchronises the stream before it returns
+            HIP_CHECK(hipEventRecord(ev_b_, st_));
+            HIP_CHECK(hipEventSynchronize(ev_b_));
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, ev_a_, ev_b_));
+            stats_.gpt_ms += ms;
             worked = true;
         }
-        // 2. decode step for every running sequence
+        // 2. decode step for every running sequence (GPU time is accounted per collected step inside decode)
         std::vector<int> active;
         for (int i = 0; i < cfg_.max_seqs; ++i)
             if (slot_owner_[i] && slot_owner_[i]->state == SeqState::RUNNING) active.push_back(i);
         if (!active.empty()) {
-            gemm_prof_now_ = cfg_.profile != 0 && !decode_graph_ && (decode_step_count_++ % 16 == 0);
+            HIP_CHECK(hipEventRecord(ev_a_, st_));
             decode(active);
-            gemm_prof_now_ = false;
             worked = true;
         }
-        HIP_CHECK(hipEventRecord(ev_b_, st_));
-        HIP_CHECK(hipStreamSynchronize(st_));
-        collect_gemm_events();
-        if (worked) {
-            float ms = 0.f;
-            HIP_CHECK(hipEventElapsedTime(&ms, ev_a_, ev_b_));
-            stats_.gpt_ms += ms;
-            stats_.steps++;
+        {
+            bool any_running = false;
+            for (int i = 0; i < cfg_.max_seqs; ++i)
+                if (slot_owner_[i] && slot_owner_[i]->state == SeqState::RUNNING) any_running = true;
+            if (!any_running) drain_inflight();
         }
+        if (worked) stats_.steps++;
         // 3. vocoder stage (asynchronous): finished sequences left their slots already (latents parked in the pool);
         //    one vocoder batch is in flight on its own stream while the next GPT steps run on the main stream.
         voc_poll(false);
@@ -680,7 +699,7 @@ private:
 
     bool idle() {
         std::lock_guard<std::mutex> lk(mu_);
-        if (!waiting_.empty() || !voc_queue_.empty() || voc_active_) return false;
+        if (!waiting_.empty() || !voc_queue_.empty() || voc_active_ || infl_.on) return false;
         for (auto* s : slot_owner_)
             if (s) return false;
         return true;
@@ -861,8 +880,8 @@ private:
         SamplerArgs a = sampler_args(w, w.P2.as<float>(), ph.slabs, Ms, kHeadPad, headb_, has_next_kvpos ? w.i_next_kvpos.as<int>() : nullptr);
         launch_sampler(a, w.st);
     }
-    void sample_readback(RowWs& w, int Ms, hipStream_t st) {
-        int* pin = w.pin.as<int>();
+    void sample_readback(RowWs& w, int Ms, hipStream_t st, int* pin = nullptr) {
+        if (!pin) pin = w.pin.as<int>();
         HIP_CHECK(hipMemcpyAsync(pin, w.i_out_tok.p, (size_t)Ms * 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipMemcpyAsync(pin + cfg_.max_seqs, slot_finished_.p, (size_t)cfg_.max_seqs * 4, hipMemcpyDeviceToHost, st));
     }
@@ -1025,9 +1044,118 @@ private:
         forward_rows(w, Mk, w.i_row_slot.as<int>(), nullptr);
         sample_kernels(w, Mk, false);
     }
-    void decode(const std::vector<int>& active) {
+    // ---- pipelined decode (default): the step's kernel chain depends only on device-resident state, so step s+1 is
+    // enqueued BEFORE the host waits for the token / finished-flag read-back of step s (otherwise the GPU idles for the
+    // host round trip, ~80 us of a 2.8 ms step).  A sequence that turns out to have finished in step s rides along in
+    // step s+1 as a ghost: the sampler leaves a finished slot untouched and reports token -1, its K/V write lands in
+    // a block the sequence had reserved, and the GEMMs are bitwise batch-invariant, so the other rows are unaffected.
+    struct InFlight {
+        bool on = false;
+        std::vector<int> slots;   // live slots at launch, in row order
+        int buf = 0;              // read-back buffer / event index
+        bool profiled = false;
+    };
+    InFlight launch_decode_step(const std::vector<int>& active) {
+        RowWs& w = ws_[0];
         const int M = (int)active.size();
-        const int n_ws = (decode_streams_ >= 2 && M >= 16) ? 2 : 1;
+        const bool same_set = (active == graph_active_ && graph_n_ws_ == 1);
+        if (!same_set) {
+            w.sample_slot = active;
+            w.sample_row.resize(M);
+            for (int i = 0; i < M; ++i) w.sample_row[i] = i;
+            ensure_rows(w, M);
+            HIP_CHECK(hipMemcpyAsync(w.i_row_slot.p, w.sample_slot.data(), (size_t)M * 4, hipMemcpyHostToDevice, st_));
+            sample_upload(w, w.sample_row, w.sample_slot, nullptr);
+            HIP_CHECK(hipStreamSynchronize(st_));   // pageable sources: the vectors may change before the copies run
+            graph_active_.clear();
+        }
+        const bool use_graph = decode_graph_ && !debug_sync();
+        if (use_graph && (!same_set || !graph_exec_)) {
+            if (graph_exec_) {
+                HIP_CHECK(hipGraphExecDestroy(graph_exec_));
+                graph_exec_ = nullptr;
+            }
+            hipGraph_t g = nullptr;
+            HIP_CHECK(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
+            decode_kernels(w, M);
+            HIP_CHECK(hipStreamEndCapture(st_, &g));
+            HIP_CHECK(hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0));
+            HIP_CHECK(hipGraphDestroy(g));
+        }
+        InFlight f;
+        f.on = true;
+        f.slots = active;
+        f.buf = rb_next_;
+        rb_next_ ^= 1;
+        f.profiled = cfg_.profile != 0 && !decode_graph_ && (decode_step_count_++ % 16 == 0);
+        pin_rb_[f.buf].ensure(((size_t)cfg_.max_seqs * 2 + 16) * sizeof(int));
+        HIP_CHECK(hipEventRecord(ev_ds_[f.buf], st_));
+        if (use_graph) {
+            HIP_CHECK(hipGraphLaunch(graph_exec_, st_));
+        } else {
+            gemm_prof_now_ = f.profiled;
+            decode_kernels(w, M);
+            gemm_prof_now_ = false;
+        }
+        HIP_CHECK(hipEventRecord(ev_de_[f.buf], st_));
+        sample_readback(w, M, st_, pin_rb_[f.buf].as<int>());
+        HIP_CHECK(hipEventRecord(ev_rb_[f.buf], st_));
+        graph_active_ = active;
+        graph_n_ws_ = 1;
+        return f;
+    }
+    void collect_decode_step(InFlight& f) {
+        HIP_CHECK(hipEventSynchronize(ev_rb_[f.buf]));
+        const int* pin = pin_rb_[f.buf].as<int>();
+        int rows = 0;
+        for (size_t j = 0; j < f.slots.size(); ++j) {
+            const int tok = pin[j];
+            if (tok < 0) continue;   // ghost row of a sequence that had already finished
+            Seq* s = slot_owner_[f.slots[j]];
+            AUR_REQUIRE(s && s->state == SeqState::RUNNING, "decode read-back for a slot without a running sequence");
+            s->tokens.push_back(tok);
+            stats_.tokens_generated++;
+            ++rows;
+            if (pin[cfg_.max_seqs + f.slots[j]]) just_finished_.push_back(s);
+        }
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, ev_ds_[f.buf], ev_de_[f.buf]));
+        stats_.gpt_ms += ms;
+        stats_.decode_rows += rows;
+        if (f.profiled) collect_gemm_events();
+        f.on = false;
+    }
+    // launch the next step ahead of the read-back only if some sequence is certain to need it
+    bool worth_speculating(const std::vector<int>& active, const InFlight& pending) const {
+        if (!pipeline_ || cfg_.second_pass || debug_sync()) return false;
+        for (int slot : active) {
+            const Seq* s = slot_owner_[slot];
+            const bool in_pending = std::find(pending.slots.begin(), pending.slots.end(), slot) != pending.slots.end();
+            const int n_after = (int)s->tokens.size() + (in_pending ? 1 : 0);
+            if (n_after < s->params.max_tokens) return true;
+        }
+        return false;
+    }
+    void decode_pipelined(const std::vector<int>& active) {
+        if (!infl_.on) infl_ = launch_decode_step(active);
+        InFlight next;
+        if (worth_speculating(active, infl_)) next = launch_decode_step(active);
+        collect_decode_step(infl_);
+        retire_finished();
+        infl_ = next;
+    }
+    void drain_inflight() {   // only ghosts can be left once no sequence is running
+        if (infl_.on) collect_decode_step(infl_);
+        retire_finished();
+    }
+    void decode(const std::vector<int>& active) {
+        if (decode_streams_ < 2) {
+            decode_pipelined(active);
+            return;
+        }
+        // two-chain A/B mode (AUR_DECODE_STREAMS=2): one synchronous step per call
+        const int M = (int)active.size();
+        const int n_ws = (M >= 16) ? 2 : 1;
         const bool same_set = (active == graph_active_ && n_ws == graph_n_ws_);
         if (!same_set) {
             for (int k = 0; k < n_ws; ++k) {
@@ -1071,7 +1199,9 @@ private:
         if (use_graph) {
             HIP_CHECK(hipGraphLaunch(graph_exec_, st_));
         } else {
+            gemm_prof_now_ = cfg_.profile != 0 && (decode_step_count_++ % 16 == 0);
             for (int k = 0; k < n_ws; ++k) decode_kernels(ws_[k], (int)ws_[k].sample_slot.size());
+            gemm_prof_now_ = false;
             if (n_ws == 2) {
                 HIP_CHECK(hipEventRecord(ev_ws1_, st2_));
                 HIP_CHECK(hipStreamWaitEvent(st_, ev_ws1_, 0));
@@ -1080,7 +1210,12 @@ private:
             graph_n_ws_ = n_ws;
         }
         for (int k = 0; k < n_ws; ++k) sample_readback(ws_[k], (int)ws_[k].sample_slot.size(), st_);
+        HIP_CHECK(hipEventRecord(ev_b_, st_));
         HIP_CHECK(hipStreamSynchronize(st_));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, ev_a_, ev_b_));
+        stats_.gpt_ms += ms;
+        collect_gemm_events();
         for (int k = 0; k < n_ws; ++k) sample_collect(ws_[k], ws_[k].sample_slot);
         retire_finished();
         stats_.decode_rows += M;
@@ -1347,6 +1482,11 @@ private:
     int voc_max_samples_ = 0;
     bool voc_active_ = false;
     PinBuf voc_pin_;
+    InFlight infl_;                     // decode step launched but not yet collected
+    PinBuf pin_rb_[2];
+    hipEvent_t ev_rb_[2] = {nullptr, nullptr}, ev_ds_[2] = {nullptr, nullptr}, ev_de_[2] = {nullptr, nullptr};
+    int rb_next_ = 0;
+    bool pipeline_ = true;              // AUR_DECODE_PIPELINE=0: wait for every read-back before launching the next step
     bool xt_f16_ = false;               // set in the constructor: fp16 vocoder => fp16 c1 -> c2 intermediate (AUR_XT_F16=0 disables)
     bool decode_graph_ = false;         // AUR_DECODE_GRAPH=1: hipGraph replay of the decode step (measured neutral: the
                                         // step is GPU-bound, and re-capturing on every live-set change costs)

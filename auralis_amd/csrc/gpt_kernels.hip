@@ -158,6 +158,27 @@ void launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M
     HIP_CHECK(hipGetLastError());
 }
 
+// Sum of the S split-K partial slabs of one float4 column group plus the bias, in the fixed order
+// ((p[0] + p[1]) + ... + p[S-1]) + bias.  Loads go out four at a time at clamped slab indices (a counted loop of
+// dependent `t += load` made hipcc wait for every slab separately: S + 1 serialized round trips per consumer kernel);
+// the surplus lanes of the last group add 0.
+__device__ __forceinline__ f32x4 slab_sum(const float* __restrict__ p0, long sstride, int S, const float* __restrict__ bias_n) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_n);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 t = zero;
+    for (int s = 0; s < S; s += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p0 + (long)s * sstride);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p0 + (long)min(s + 1, S - 1) * sstride);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(p0 + (long)min(s + 2, S - 1) * sstride);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(p0 + (long)min(s + 3, S - 1) * sstride);
+        t += a;
+        t += (s + 1 < S) ? b : zero;
+        t += (s + 2 < S) ? c : zero;
+        t += (s + 3 < S) ? d : zero;
+    }
+    return t + bv;
+}
+
 // ------------------------------------------------------------------------------------------------
 // residual + LayerNorm rows (one wave per 1024-wide row; statistics via wavefront shuffles)
 __global__ __launch_bounds__(256) void rows_ln_kernel(const float* __restrict__ P, int S,
@@ -171,22 +192,12 @@ __global__ __launch_bounds__(256) void rows_ln_kernel(const float* __restrict__ 
     const int row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = 4 * tid;
+    // gamma/beta are fetched first: behind the two barriers below they would cost one more memory round trip
+    const f32x4 gam = *reinterpret_cast<const f32x4*>(gamma + n);
+    const f32x4 bet = *reinterpret_cast<const f32x4*>(beta + n);
     f32x4 v = *reinterpret_cast<const f32x4*>(h + (long)row * kHidden + n);
     if (S > 0) {
-        const float* p0 = P + (long)row * kHidden + n;
-        const long sstride = (long)M * kHidden;
-        f32x4 t = *reinterpret_cast<const f32x4*>(p0);
-        int s = 1;
-        for (; s + 3 < S; s += 4) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(p0 + s * sstride);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(p0 + (s + 1) * sstride);
-            const f32x4 c = *reinterpret_cast<const f32x4*>(p0 + (s + 2) * sstride);
-            const f32x4 d = *reinterpret_cast<const f32x4*>(p0 + (s + 3) * sstride);
-            t += a; t += b; t += c; t += d;
-        }
-        for (; s < S; ++s) t += *reinterpret_cast<const f32x4*>(p0 + s * sstride);
-        t += *reinterpret_cast<const f32x4*>(bias + n);
-        v += t;
+        v += slab_sum(P + (long)row * kHidden + n, (long)M * kHidden, S, bias + n);
         *reinterpret_cast<f32x4*>(h + (long)row * kHidden + n) = v;
     }
     float sum = wave_sum((v[0] + v[1]) + (v[2] + v[3]));
@@ -204,11 +215,9 @@ __global__ __launch_bounds__(256) void rows_ln_kernel(const float* __restrict__ 
     __syncthreads();
     const float var = ((part[1][0] + part[1][1]) + (part[1][2] + part[1][3])) * (1.0f / kHidden);
     const float rstd = 1.0f / sqrtf(var + eps);
-    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + n);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + n);
     f32x4 o;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) o[c] = (v[c] - mean) * rstd * g[c] + b[c];
+    for (int c = 0; c < 4; ++c) o[c] = (v[c] - mean) * rstd * gam[c] + bet[c];
     *reinterpret_cast<f32x4*>(out + (long)row * kHidden + n) = o;
 }
 
@@ -227,9 +236,7 @@ __global__ __launch_bounds__(256) void bias_gelu_kernel(const float* __restrict_
     const long total = (long)M * N / 4;
     if (idx >= total) return;
     const int n = (int)((idx * 4) % N);
-    f32x4 t = *reinterpret_cast<const f32x4*>(P + idx * 4);
-    for (int s = 1; s < S; ++s) t += *reinterpret_cast<const f32x4*>(P + (long)s * M * N + idx * 4);
-    t += *reinterpret_cast<const f32x4*>(bias + n);
+    const f32x4 t = slab_sum(P + idx * 4, (long)M * N, S, bias + n);
     f32x4 o;
 #pragma unroll
     for (int c = 0; c < 4; ++c) o[c] = gelu_new(t[c]);
@@ -266,9 +273,7 @@ __global__ __launch_bounds__(256) void qkv_epilogue_kernel(const float* __restri
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int n = 4 * (threadIdx.x + 256 * u);
-        f32x4 t = *reinterpret_cast<const f32x4*>(P + (long)m * N + n);
-        for (int s = 1; s < S; ++s) t += *reinterpret_cast<const f32x4*>(P + ((long)s * M + m) * N + n);
-        t += *reinterpret_cast<const f32x4*>(bias + n);
+        const f32x4 t = slab_sum(P + (long)m * N + n, (long)M * N, S, bias + n);
         if (u == 0) {
             *reinterpret_cast<f32x4*>(qbuf + (long)m * kHidden + n) = t;
         } else {
@@ -314,21 +319,30 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
     const int n_keys = pos + 1;
     const int* bt = block_tables + (long)slot * max_blocks;
 
+    // 4 tokens per wave per step, 4 steps unrolled: all 8 K/V loads of a lane are issued before the first softmax
+    // update (addresses are clamped instead of predicated so that the loads can be hoisted).  The first batch goes out
+    // before q is assembled from the GEMM slabs: it does not depend on q.
+    constexpr int UN = 4;
+    f32x4 k4[UN], v4[UN];
+    auto load_kv = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int t = min(t0 + 16 * u + wv * 4 + g, n_keys - 1);
+            const int blk = bt[t / kKvBlockTokens];
+            const long off = kv_offset(blk, 0, head, t % kKvBlockTokens) + d4 * 4;
+            k4[u] = *reinterpret_cast<const f32x4*>(kv_layer + off);
+            v4[u] = *reinterpret_cast<const f32x4*>(kv_layer + off + (long)kHeads * kKvBlockTokens * kHeadDim);
+        }
+    };
+    load_kv(0);
     f32x4 qv, own_k = {0.f, 0.f, 0.f, 0.f}, own_v = {0.f, 0.f, 0.f, 0.f};
     if (FUSED) {
         constexpr int N = 3 * kHidden;
         const int col = head * kHeadDim + d4 * 4;
-        f32x4 t[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const float* p0 = P + (long)m * N + u * kHidden + col;
-            t[u] = *reinterpret_cast<const f32x4*>(p0);
-            for (int sl = 1; sl < S; ++sl) t[u] += *reinterpret_cast<const f32x4*>(p0 + (long)sl * M * N);
-            t[u] += *reinterpret_cast<const f32x4*>(bias + u * kHidden + col);
-        }
-        qv = t[0];
-        own_k = t[1];
-        own_v = t[2];
+        const float* p0 = P + (long)m * N + col;
+        qv = slab_sum(p0, (long)M * N, S, bias + col);
+        own_k = slab_sum(p0 + kHidden, (long)M * N, S, bias + kHidden + col);
+        own_v = slab_sum(p0 + 2 * kHidden, (long)M * N, S, bias + 2 * kHidden + col);
         if (wv == 0 && g == 0) {
             const long off = kv_offset(bt[pos / kKvBlockTokens], 0, head, pos % kKvBlockTokens) + d4 * 4;
             *reinterpret_cast<f32x4*>(kv_layer + off) = own_k;
@@ -339,19 +353,8 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
     }
     float mi = -INFINITY, li = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    // 4 tokens per wave per step, 4 steps unrolled: all 8 K/V loads of a lane are issued before the first softmax
-    // update (addresses are clamped instead of predicated so that the loads can be hoisted).
-    constexpr int UN = 4;
     for (int t0 = 0; t0 < n_keys; t0 += 16 * UN) {
-        f32x4 k4[UN], v4[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int t = min(t0 + 16 * u + wv * 4 + g, n_keys - 1);
-            const int blk = bt[t / kKvBlockTokens];
-            const long off = kv_offset(blk, 0, head, t % kKvBlockTokens) + d4 * 4;
-            k4[u] = *reinterpret_cast<const f32x4*>(kv_layer + off);
-            v4[u] = *reinterpret_cast<const f32x4*>(kv_layer + off + (long)kHeads * kKvBlockTokens * kHeadDim);
-        }
+        if (t0 > 0) load_kv(t0);
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int t = t0 + 16 * u + wv * 4 + g;
@@ -611,6 +614,10 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
     const int tid = threadIdx.x;
     const int slot = a.sample_slot[j];
     const int V = a.V;
+    if (a.slot_finished[slot]) {   // ghost row (engine.hip, pipelined decode): leave every piece of slot state untouched
+        if (tid == 0) a.out_tok[j] = -1;
+        return;
+    }
     const float pen = a.rep_penalty[slot];
     const unsigned char* seen = a.seen + (long)slot * kSeenStride;
 

@@ -96,3 +96,40 @@ def test_seed_controls_sampling(ctx, dims):
         e.submit(ids, SPK_KEY, temperature=0.9, top_k=50, top_p=0.9, max_tokens=16, seed=seed, ignore_stop=True)
         runs.append(e.run_until_done()[0]["tokens"].tolist())
     assert runs[0] == runs[1] and runs[0] != runs[2]
+
+
+def test_pipelined_decode_equals_synchronous(dims, monkeypatch):
+    """The engine launches decode step s+1 before it has read back step s (a sequence that finished in s rides along
+    as a ghost row).  Ragged finishes (natural stop tokens + different max_tokens), more sequences than batcher slots
+    (admissions while a speculative step is in flight), sampling: tokens and audio must equal the synchronous engine."""
+    from auralis_amd._lib import NativeEngine
+    from auralis_amd.checkpoint import make_synthetic_gpt, make_synthetic_xtts
+    from auralis_amd.weights import pack_all
+    gpt_sd = make_synthetic_gpt(dims.gpt, seed=1234, n_layer=2)
+    gpt_sd["mel_head.bias"][1025] = 3.0                    # natural stops after a few (sampled) tokens
+    packed = pack_all(gpt_sd, make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd))
+    cond, spk = make_synthetic_conditioning(dims)
+
+    def run(pipeline):
+        monkeypatch.setenv("AUR_DECODE_PIPELINE", "1" if pipeline else "0")
+        e = NativeEngine(n_layer=2, max_seqs=3)
+        try:
+            e.load_weights(packed)
+            e.set_conditioning(SPK_KEY, cond.numpy(), spk.numpy())
+            sids = []
+            for k in range(8):
+                ids = make_synthetic_text_ids(dims, n_text=9 + 3 * k, seed=20 + k)
+                sids.append(e.submit(ids, SPK_KEY, temperature=0.9 if k % 3 else 0.0, top_k=50, top_p=0.85,
+                                     max_tokens=[1, 2, 7, 30, 12, 3, 30, 18][k], seed=100 + k, ignore_stop=(k == 3)))
+            outs = {o["seq_id"]: o for o in e.run_until_done()}
+            return [outs[s] for s in sids]
+        finally:
+            e.close()
+
+    a, b = run(True), run(False)
+    lens = [len(o["tokens"]) for o in a]
+    print("token counts", lens)
+    assert lens[0] == 1 and lens[1] <= 2 and lens[3] == 30 and any(n < m for n, m in zip(lens, [1, 2, 7, 30, 12, 3, 30, 18]))
+    for x, y in zip(a, b):
+        assert x["tokens"].tolist() == y["tokens"].tolist()
+        assert np.array_equal(x["wav"], y["wav"]) and np.array_equal(x["latents"], y["latents"])
