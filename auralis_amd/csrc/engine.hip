@@ -196,6 +196,7 @@ public:
         if (const char* e = getenv("AUR_XT_F16")) xt_f16_ = xt_f16_ && atoi(e) != 0;
         if (const char* e = getenv("AUR_DECODE_STREAMS")) decode_streams_ = atoi(e);
         if (const char* e = getenv("AUR_DECODE_PIPELINE")) pipeline_ = atoi(e) != 0;
+        if (const char* e = getenv("AUR_SAMPLER_FULL_SORT")) sampler_full_sort_ = atoi(e) != 0;
         for (int i = 0; i < 2; ++i) {
             HIP_CHECK(hipEventCreateWithFlags(&ev_rb_[i], hipEventDisableTiming));
             HIP_CHECK(hipEventCreate(&ev_ds_[i]));
@@ -852,6 +853,7 @@ private:
         a.out_tok = w.i_out_tok.as<int>();
         a.dbg_logits = dbg_capture_ ? dbg_logits_.as<float>() : nullptr;
         a.stop_token = kStopToken;
+        a.force_full_sort = sampler_full_sort_ ? 1 : 0;
         return a;
     }
     // final_norm -> latent stash -> mel_head GEMM -> fused sampler -> read back tokens/finished flags
@@ -1486,6 +1488,7 @@ private:
     PinBuf pin_rb_[2];
     hipEvent_t ev_rb_[2] = {nullptr, nullptr}, ev_ds_[2] = {nullptr, nullptr}, ev_de_[2] = {nullptr, nullptr};
     int rb_next_ = 0;
+    bool sampler_full_sort_ = false;    // AUR_SAMPLER_FULL_SORT=1: disable the sampler's top-k fast path (A/B)
     bool pipeline_ = true;              // AUR_DECODE_PIPELINE=0: wait for every read-back before launching the next step
     bool xt_f16_ = false;               // set in the constructor: fp16 vocoder => fp16 c1 -> c2 intermediate (AUR_XT_F16=0 disables)
     bool decode_graph_ = false;         // AUR_DECODE_GRAPH=1: hipGraph replay of the decode step (measured neutral: the

@@ -85,6 +85,7 @@ struct SamplerArgs {
     int* out_tok;            // [Ms]
     float* dbg_logits;       // optional [Ms][V] penalised logits
     int stop_token;
+    int force_full_sort;     // 1: always take the 2048-key bitonic path (A/B of the top-k fast path)
 };
 void launch_sampler(const SamplerArgs& a, hipStream_t st);
 constexpr int kSeenStride = 1040;

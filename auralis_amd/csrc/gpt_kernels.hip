@@ -645,38 +645,107 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
     } else {
         for (int v = tid; v < V; v += 256) z[v] = z[v] / T;
         __syncthreads();
-        for (int e = tid; e < 2048; e += 256)
-            keys[e] = (e < V) ? (((unsigned long long)f2ord(z[e]) << 32) | (unsigned)e) : 0ull;
-        __syncthreads();
-        for (int k = 2; k <= 2048; k <<= 1)
-            for (int jj = k >> 1; jj > 0; jj >>= 1) {
-                for (int e = tid; e < 2048; e += 256) {
-                    const int x = e ^ jj;
-                    if (x > e) {
-                        const bool up = (e & k) == 0;
-                        const unsigned long long ka = keys[e], kb = keys[x];
-                        if ((ka < kb) == up) {
-                            keys[e] = kb;
-                            keys[x] = ka;
+        const int topk = a.top_k[slot];
+        // ---- top-k fast path (0 < k <= 64, the XTTS default is 50): the k-th largest value is found by a 32-step
+        // bisection on the order-preserving integer image of the logits (one ballot/popcount per element, one barrier
+        // per step), the >= threshold survivors (k plus ties) are compacted and sorted by ONE wave, no workgroup
+        // barriers.  Same threshold, same survivor set and same (value, id) order as the full sort below, so both paths
+        // give identical tokens; it replaces 66 barrier-separated passes over 2048 keys.
+        bool sorted = false;
+        if (topk > 0 && topk <= 64 && topk < V && !a.force_full_sort) {
+            unsigned ov[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int v = tid + 256 * u;
+                ov[u] = (v < V) ? f2ord(z[v] + 0.0f) : 0u;   // (-0 -> +0: equal floats, equal images); 0 sorts below every float
+            }
+            unsigned lo = 0u;
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned x = lo | (1u << bit);
+                int c = 0;
+#pragma unroll
+                for (int u = 0; u < 5; ++u) c += __popcll(__ballot(ov[u] >= x));
+                if ((tid & 63) == 0) si[(bit & 1) * 4 + (tid >> 6)] = c;
+                __syncthreads();
+                const int* cc = &si[(bit & 1) * 4];
+                if ((cc[0] + cc[1]) + (cc[2] + cc[3]) >= topk) lo = x;
+            }
+            // lo = image of the k-th largest logit; survivors: everything >= lo
+            if (tid == 0) sh_i[1] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int v = tid + 256 * u;
+                if (v < V && ov[u] >= lo) {
+                    const int pos = atomicAdd(&sh_i[1], 1);
+                    if (pos < 128) keys[pos] = ((unsigned long long)ov[u] << 32) | (unsigned)v;
+                }
+            }
+            __syncthreads();
+            const int n_surv = sh_i[1];
+            if (n_surv <= 128) {
+                if (tid < 64) {   // one wave: LDS accesses of a single wave execute in order, no barrier needed
+                    for (int e = tid; e < 128; e += 64)
+                        if (e >= n_surv) keys[e] = 0ull;
+                    for (int k = 2; k <= 128; k <<= 1)
+                        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const int e = tid + 64 * h;
+                                const int x = e ^ jj;
+                                if (x > e) {
+                                    const bool up = (e & k) == 0;
+                                    const unsigned long long ka = keys[e], kb = keys[x];
+                                    if ((ka < kb) == up) {
+                                        keys[e] = kb;
+                                        keys[x] = ka;
+                                    }
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();
                         }
+                    if (tid == 0) {
+                        sh_f[0] = ord2f(lo);
+                        sh_i[0] = n_surv;
                     }
                 }
-                __syncthreads();
+                sorted = true;
             }
-        // top-k threshold (ties at the k-th value are kept)
-        const int topk = a.top_k[slot];
-        if (tid == 0) {
-            int n1 = V;
-            float thr = -INFINITY;
-            if (topk > 0 && topk < V) {
-                thr = ord2f((unsigned)(keys[topk - 1] >> 32));
-                n1 = topk;
-                while (n1 < V && ord2f((unsigned)(keys[n1] >> 32)) == thr) ++n1;
-            }
-            sh_f[0] = thr;
-            sh_i[0] = n1;
+            __syncthreads();
         }
-        __syncthreads();
+        if (!sorted) {
+            for (int e = tid; e < 2048; e += 256)
+                keys[e] = (e < V) ? (((unsigned long long)f2ord(z[e]) << 32) | (unsigned)e) : 0ull;
+            __syncthreads();
+            for (int k = 2; k <= 2048; k <<= 1)
+                for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                    for (int e = tid; e < 2048; e += 256) {
+                        const int x = e ^ jj;
+                        if (x > e) {
+                            const bool up = (e & k) == 0;
+                            const unsigned long long ka = keys[e], kb = keys[x];
+                            if ((ka < kb) == up) {
+                                keys[e] = kb;
+                                keys[x] = ka;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            // top-k threshold (ties at the k-th value are kept)
+            if (tid == 0) {
+                int n1 = V;
+                float thr = -INFINITY;
+                if (topk > 0 && topk < V) {
+                    thr = ord2f((unsigned)(keys[topk - 1] >> 32));
+                    n1 = topk;
+                    while (n1 < V && ord2f((unsigned)(keys[n1] >> 32)) == thr) ++n1;
+                }
+                sh_f[0] = thr;
+                sh_i[0] = n1;
+            }
+            __syncthreads();
+        }
         const float thr = sh_f[0];
         const int n1 = sh_i[0];
         for (int v = tid; v < V; v += 256)

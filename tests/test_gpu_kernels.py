@@ -180,3 +180,29 @@ def test_sampler_distribution_chi2(eng):
     n = counts.sum()
     chi2 = float(((counts - n * p) ** 2 / (n * p)).sum())
     assert chi2 < 16.3, (chi2, counts)     # 3 dof, p = 0.001
+
+
+def test_sampler_topk_fast_path_equals_full_sort(eng, monkeypatch):
+    """0 < top_k <= 64 takes the bisection + one-wave sort path; AUR_SAMPLER_FULL_SORT=1 forces the 2048-key bitonic sort.
+    Same tokens on smooth logits, on heavily tied logits (ties at the k-th value are kept, > 128 survivors fall back to
+    the full sort) and with -inf / duplicated maxima.  (The oracle comparisons above cover k = 50 and k = 5 on smooth logits;
+    inside a tie group the top-p cut depends on the sort's tie order, which torch.sort does not pin down.)"""
+    monkeypatch.setenv("AUR_SAMPLER_FULL_SORT", "1")
+    ref_eng, *_ = make_engine(1, max_seqs=8)
+    try:
+        g = torch.Generator().manual_seed(77)
+        B = 8
+        smooth = torch.randn(B, 1026, generator=g) * 3.0
+        tied = torch.round(torch.randn(B, 1026, generator=g) * 2.0) * 0.5          # ~10 distinct values: massive ties
+        coarse = torch.round(torch.randn(B, 1026, generator=g) * 40.0) / 8.0      # a few ties around the k-th value
+        holes = smooth.clone()
+        holes[:, ::3] = -float("inf")
+        holes[:, 5] = holes[:, 7] = 9.0                                           # duplicated maximum
+        for name, lg in (("smooth", smooth), ("tied", tied), ("coarse", coarse), ("holes", holes)):
+            for T, k, p in ((0.75, 50, 0.85), (1.0, 64, 1.0), (0.4, 1, 0.9), (1.5, 7, 0.3), (0.9, 33, 0.6)):
+                for step in (0, 11):
+                    a = eng.dbg_sample(lg.numpy(), T, p, k, seed=4242, step=step)
+                    b = ref_eng.dbg_sample(lg.numpy(), T, p, k, seed=4242, step=step)
+                    assert list(a) == list(b), (name, T, k, p, step, a, b)
+    finally:
+        ref_eng.close()
