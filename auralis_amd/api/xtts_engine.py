@@ -64,7 +64,7 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
         # vocoder="fp16": HiFi-GAN convs on fp16-input / fp32-accumulate MFMA (waveform within 1e-5 RMS of the fp32
         # path, the reference's own GPU path autocasts to fp16); vocoder="fp32": exact-f32 MFMA parity mode
         native = NativeEngine(n_layer=n_layer, max_seqs=max(1, max_concurrency), device=device,
-                              vocoder_fp16=(vocoder == "fp16"))
+                              vocoder_fp16=(vocoder == "fp16"), return_latents=False)
         native.load_weights(pack_all(gpt_sd, xtts_sd))
         tok_file = None
         for cand in ("tokenizer.json", os.path.join("gpt", "tokenizer.json")):

@@ -67,6 +67,13 @@ struct PinBuf {
     }
 };
 
+// Pinned result block of one vocoder batch: the D2H copies land here and aur_result.wav / .latents point straight into
+// it (no second host copy); the block returns to the pool when the last sequence of the batch is released.
+struct PinBlock {
+    PinBuf buf;
+    int refs = 0;
+};
+
 struct Tensor {
     std::unique_ptr<DevBuf> buf;
     int64_t numel = 0;
@@ -129,8 +136,11 @@ struct Seq {
     int n_prompt = 0;
     std::vector<int> blocks;
     std::vector<int32_t> tokens;
-    std::vector<float> wav;
-    std::vector<float> latents;
+    const float* wav = nullptr;       // into `result_block`
+    int n_samples = 0;
+    const float* latents = nullptr;   // into `result_block` (aur_config.return_latents)
+    int n_latent_rows = 0;
+    PinBlock* result_block = nullptr;
     int pool_idx = -1;   // latent-pool entry once the tokens are done (vocoder stage)
     bool shared_prefix = false;
     int error = 0;
@@ -197,6 +207,8 @@ public:
         if (const char* e = getenv("AUR_DECODE_STREAMS")) decode_streams_ = atoi(e);
         if (const char* e = getenv("AUR_DECODE_PIPELINE")) pipeline_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_SAMPLER_FULL_SORT")) sampler_full_sort_ = atoi(e) != 0;
+        if (const char* e = getenv("AUR_FUSE_GELU")) fuse_gelu_ = atoi(e) != 0;
+
         for (int i = 0; i < 2; ++i) {
             HIP_CHECK(hipEventCreateWithFlags(&ev_rb_[i], hipEventDisableTiming));
             HIP_CHECK(hipEventCreate(&ev_ds_[i]));
@@ -378,10 +390,10 @@ public:
             r.seq_id = s->id;
             r.n_tokens = (int)s->tokens.size();
             r.tokens = s->tokens.data();
-            r.n_samples = (int)s->wav.size();
-            r.wav = s->wav.data();
-            r.n_latent_rows = s->latents.empty() ? 0 : (int)(s->latents.size() / kHidden);
-            r.latents = s->latents.empty() ? nullptr : s->latents.data();
+            r.n_samples = s->n_samples;
+            r.wav = s->wav;
+            r.n_latent_rows = s->n_latent_rows;
+            r.latents = s->latents;
             r.error = s->error;
         }
         return n;
@@ -391,6 +403,7 @@ public:
         auto it = seqs_.find(id);
         AUR_REQUIRE(it != seqs_.end(), "unknown seq_id");
         AUR_REQUIRE(it->second->state == SeqState::DONE, "sequence not finished");
+        if (it->second->result_block) it->second->result_block->refs--;
         seqs_.erase(it);
     }
 
@@ -758,11 +771,9 @@ private:
         w.rows_cap = cap;
     }
     // profile mode: HIP-event pairs around the GEMM launches of every 16th decode step (sampled: 121 per step)
-    void gemm(RowWs& w, const float* X, int ldx, const float* Wm, float* P, int M, int N, int K, const GemmPlan& pl) {
-        if (!gemm_prof_now_) {
-            launch_gemm_splitk(X, ldx, Wm, P, M, N, K, pl, w.st);
-            return;
-        }
+    bool gemm(RowWs& w, const float* X, int ldx, const float* Wm, float* P, int M, int N, int K, const GemmPlan& pl,
+              const GemmGelu* gelu = nullptr) {
+        if (!gemm_prof_now_) return launch_gemm_splitk(X, ldx, Wm, P, M, N, K, pl, w.st, gelu);
         if (n_gemm_events_ == gemm_events_.size()) {
             ConvEvent e{};
             HIP_CHECK(hipEventCreate(&e.a));
@@ -773,8 +784,9 @@ private:
         ev.flops = 2.0 * M * N * K;
         ev.bytes = 4.0 * ((double)K * N + (double)M * K + (double)pl.slabs * M * N);
         HIP_CHECK(hipEventRecord(ev.a, w.st));
-        launch_gemm_splitk(X, ldx, Wm, P, M, N, K, pl, w.st);
+        const bool applied = launch_gemm_splitk(X, ldx, Wm, P, M, N, K, pl, w.st, gelu);
         HIP_CHECK(hipEventRecord(ev.b, w.st));
+        return applied;
     }
     // Fixed cost of one HIP-event pair on an otherwise busy stream: recording events between back-to-back short
     // kernels serialises their launch processing, which inflates a ~12 us kernel by ~3 us.  Measured once as the
@@ -831,8 +843,9 @@ private:
             }
             gemm(w, w.att.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, p1);
             launch_rows_ln(P, S1, L.bproj, h, L.ln2w, L.ln2b, xn, M, 1e-5f, w.st);
-            gemm(w, xn, kHidden, L.wfc, P, M, 4 * kHidden, kHidden, p1);
-            launch_bias_gelu(P, S1, L.bfc, w.act.as<float>(), M, 4 * kHidden, w.st);
+            const GemmGelu ge{L.bfc, w.act.as<float>()};
+            if (!gemm(w, xn, kHidden, L.wfc, P, M, 4 * kHidden, kHidden, p1, fuse_gelu_ ? &ge : nullptr))
+                launch_bias_gelu(P, S1, L.bfc, w.act.as<float>(), M, 4 * kHidden, w.st);
             gemm(w, w.act.as<float>(), 4 * kHidden, L.wproj2, P, M, kHidden, 4 * kHidden, p4);
             const bool last = (l + 1 == cfg_.n_layer);
             launch_rows_ln(P, S4, L.bproj2, h, last ? lnfw_ : layers_[l + 1].ln1w, last ? lnfb_ : layers_[l + 1].ln1b,
@@ -1393,19 +1406,31 @@ private:
             voc_max_samples_ = std::max(voc_max_samples_, frames_for(voc_nl_[b]) * 256);
         }
         tmp_wav_.ensure((size_t)B * voc_max_samples_ * 4);
-        voc_pin_.ensure((size_t)B * voc_max_samples_ * 4 + (size_t)B * kMaxLatRows * kHidden * 4);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            voc_block_ = nullptr;
+            for (auto& blk : result_blocks_)
+                if (blk->refs == 0) voc_block_ = blk.get();
+            if (!voc_block_) {
+                result_blocks_.emplace_back(new PinBlock());
+                voc_block_ = result_blocks_.back().get();
+            }
+            voc_block_->refs = 1;   // held by the in-flight batch
+        }
+        voc_block_->buf.ensure((size_t)B * voc_max_samples_ * 4 + (cfg_.return_latents ? (size_t)B * kMaxLatRows * kHidden * 4 : 0));
         HIP_CHECK(hipStreamWaitEvent(st_voc_, ev_lat_, 0));   // latents parked by the main stream
         run_vocoder(B, voc_nl_, latpool_.as<float>(), (long)kMaxLatRows * kHidden, &rows, cond, tmp_wav_.as<float>(),
                     voc_max_samples_);
-        float* hw = voc_pin_.as<float>();
+        float* hw = voc_block_->buf.as<float>();
         float* hl = hw + (size_t)B * voc_max_samples_;
         for (int b = 0; b < B; ++b) {
             const int ns = frames_for(voc_nl_[b]) * 256;
             HIP_CHECK(hipMemcpyAsync(hw + (size_t)b * voc_max_samples_, tmp_wav_.as<float>() + (long)b * voc_max_samples_,
                                      (size_t)ns * 4, hipMemcpyDeviceToHost, st_voc_));
-            HIP_CHECK(hipMemcpyAsync(hl + (size_t)b * kMaxLatRows * kHidden,
-                                     latpool_.as<float>() + (long)rows[b] * kMaxLatRows * kHidden,
-                                     (size_t)voc_nl_[b] * kHidden * 4, hipMemcpyDeviceToHost, st_voc_));
+            if (cfg_.return_latents)
+                HIP_CHECK(hipMemcpyAsync(hl + (size_t)b * kMaxLatRows * kHidden,
+                                         latpool_.as<float>() + (long)rows[b] * kMaxLatRows * kHidden,
+                                         (size_t)voc_nl_[b] * kHidden * 4, hipMemcpyDeviceToHost, st_voc_));
         }
         HIP_CHECK(hipEventRecord(ev_voc_done_, st_voc_));
         voc_active_ = true;
@@ -1422,20 +1447,30 @@ private:
         }
         collect_conv_events();
         const int B = (int)voc_batch_.size();
-        const float* hw = voc_pin_.as<float>();
+        const float* hw = voc_block_->buf.as<float>();
         const float* hl = hw + (size_t)B * voc_max_samples_;
         for (int b = 0; b < B; ++b) {
             Seq* s = voc_batch_[b];
             const int ns = frames_for(voc_nl_[b]) * 256;
-            s->wav.assign(hw + (size_t)b * voc_max_samples_, hw + (size_t)b * voc_max_samples_ + ns);
-            s->latents.assign(hl + (size_t)b * kMaxLatRows * kHidden, hl + (size_t)b * kMaxLatRows * kHidden + (size_t)voc_nl_[b] * kHidden);
+            s->wav = hw + (size_t)b * voc_max_samples_;
+            s->n_samples = ns;
+            if (cfg_.return_latents) {
+                s->latents = hl + (size_t)b * kMaxLatRows * kHidden;
+                s->n_latent_rows = voc_nl_[b];
+            }
             stats_.samples_generated += ns;
             std::lock_guard<std::mutex> lk(mu_);
+            s->result_block = voc_block_;
+            voc_block_->refs++;
             latpool_free_.push_back(s->pool_idx);
             s->pool_idx = -1;
             s->state = SeqState::DONE;
             done_.push_back(s);
             finished_total_++;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            voc_block_->refs--;   // the batch's own hold
         }
         voc_batch_.clear();
         voc_active_ = false;
@@ -1483,11 +1518,13 @@ private:
     std::vector<int> voc_nl_;
     int voc_max_samples_ = 0;
     bool voc_active_ = false;
-    PinBuf voc_pin_;
+    std::vector<std::unique_ptr<PinBlock>> result_blocks_;   // pool; a block is free when refs == 0 (guarded by mu_)
+    PinBlock* voc_block_ = nullptr;                          // block of the in-flight vocoder batch
     InFlight infl_;                     // decode step launched but not yet collected
     PinBuf pin_rb_[2];
     hipEvent_t ev_rb_[2] = {nullptr, nullptr}, ev_ds_[2] = {nullptr, nullptr}, ev_de_[2] = {nullptr, nullptr};
     int rb_next_ = 0;
+    bool fuse_gelu_ = true;             // AUR_FUSE_GELU=0: separate bias_gelu launch after the prefill FC GEMM too (A/B)
     bool sampler_full_sort_ = false;    // AUR_SAMPLER_FULL_SORT=1: disable the sampler's top-k fast path (A/B)
     bool pipeline_ = true;              // AUR_DECODE_PIPELINE=0: wait for every read-back before launching the next step
     bool xt_f16_ = false;               // set in the constructor: fp16 vocoder => fp16 c1 -> c2 intermediate (AUR_XT_F16=0 disables)

@@ -20,8 +20,18 @@ struct GemmPlan {
     int slabs;   // slabs the epilogue has to sum
 };
 GemmPlan gemm_plan(int M, int K);
-void launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M, int N, int K, const GemmPlan& pl,
-                        hipStream_t st);
+// Optional bias + gelu_new epilogue of the FC GEMM, fused-slice plan only (M > 128, i.e. prefill): the totals are in
+// registers, so act[m][n] = gelu_new(total + bias[n]) is written instead of the slab (same arithmetic order as
+// launch_bias_gelu on the slabs).  The split plan keeps the separate launch: a last-arriver tail inside the GEMM was
+// measured (r01): with agent-scope fences (buffer_wbl2/buffer_inv per workgroup) the step got 20 % slower, with
+// workgroup-scope fences it gained 0.5 % but is only correct while all K-slices of a tile share one XCD's L2.
+struct GemmGelu {
+    const float* bias;
+    float* act;
+};
+// returns true when the gelu tail was applied (false: caller runs launch_bias_gelu on the slabs)
+bool launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M, int N, int K, const GemmPlan& pl,
+                        hipStream_t st, const GemmGelu* gelu = nullptr);
 
 // h[m] += sum_s P[s][m] + bias (if S > 0); out[m] = LayerNorm(h[m]; gamma, beta, eps).  Rows of 1024.
 void launch_rows_ln(const float* P, int S, const float* bias, float* h, const float* gamma, const float* beta,

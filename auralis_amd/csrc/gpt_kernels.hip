@@ -14,10 +14,33 @@ namespace aur {
 // MFMA v_mfma_f32_16x16x4_f32 with a permuted K and N order so that the float4 loads ARE the fragments:
 //   step (s', c):  A[i][k'] = X[m][kb + 4k' + s'],  B[k'][j'] = W[kb + 4k' + s'][n0 + 4j' + c]
 //   D[i][j'] accumulates column n0 + 4j' + c, i.e. lane j' owns 4 consecutive columns across c = 0..3.
-template <bool FUSED, int MTW>   // MTW = 16-row MFMA tiles per wave: the workgroup owns a (16*MTW) x 64 output tile
+// Sum of the S split-K partial slabs of one float4 column group plus the bias, in the fixed order
+// ((p[0] + p[1]) + ... + p[S-1]) + bias.  Loads go out four at a time at clamped slab indices (a counted loop of
+// dependent `t += load` made hipcc wait for every slab separately: S + 1 serialized round trips per consumer kernel);
+// the surplus lanes of the last group add 0.
+__device__ __forceinline__ f32x4 slab_sum(const float* __restrict__ p0, long sstride, int S, const float* __restrict__ bias_n) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_n);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 t = zero;
+    for (int s = 0; s < S; s += 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p0 + (long)s * sstride);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p0 + (long)min(s + 1, S - 1) * sstride);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(p0 + (long)min(s + 2, S - 1) * sstride);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(p0 + (long)min(s + 3, S - 1) * sstride);
+        t += a;
+        t += (s + 1 < S) ? b : zero;
+        t += (s + 2 < S) ? c : zero;
+        t += (s + 3 < S) ? d : zero;
+    }
+    return t + bv;
+}
+
+// MTW = 16-row MFMA tiles per wave: the workgroup owns a (16*MTW) x 64 output tile.  GELU (fused-slice plan only): the
+// register totals get bias + gelu_new and go to `act` instead of P.
+template <bool FUSED, int MTW, bool GELU>
 __global__ __launch_bounds__(256) void gemm_splitk_kernel(const float* __restrict__ X, int ldx,
                                                           const float* __restrict__ W, float* __restrict__ P,
-                                                          int M, int N, int n_slices) {
+                                                          int M, int N, int n_slices, GemmGelu ep) {
     // 4 waves = the 4 K-quarters of one 256-deep slice.  Each wave streams its 64 weight rows x 64 columns once
     // (16 float4 loads issued back to back, so one HBM latency covers the whole slice) and multiplies them with the
     // tile's activation rows.  Reduction order per output element is ((k0 + k1) + k2) + k3, then slices in order.
@@ -116,12 +139,24 @@ __global__ __launch_bounds__(256) void gemm_splitk_kernel(const float* __restric
         if (FUSED) __syncthreads();   // LDS tiles consumed before the next slice overwrites them
     }
     if (FUSED && ks == 0) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (GELU) bv = *reinterpret_cast<const f32x4*>(ep.bias + n0 + 4 * i);
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * mt + 4 * q + r;
-                if (m0 + row < M) *reinterpret_cast<f32x4*>(P + (long)(m0 + row) * N + n0 + 4 * i) = total[mt][r];
+                if (m0 + row < M) {
+                    if (GELU) {
+                        const f32x4 t = total[mt][r] + bv;
+                        f32x4 o;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] = gelu_new(t[c]);
+                        *reinterpret_cast<f32x4*>(ep.act + (long)(m0 + row) * N + n0 + 4 * i) = o;
+                    } else {
+                        *reinterpret_cast<f32x4*>(P + (long)(m0 + row) * N + n0 + 4 * i) = total[mt][r];
+                    }
+                }
             }
     }
 }
@@ -137,46 +172,33 @@ GemmPlan gemm_plan(int M, int K) {
     return p;
 }
 
-void launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M, int N, int K, const GemmPlan& pl,
-                        hipStream_t st) {
+bool launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M, int N, int K, const GemmPlan& pl,
+                        hipStream_t st, const GemmGelu* gelu) {
     AUR_REQUIRE(N % 64 == 0 && pl.kw == 64 && K == pl.slices * 4 * pl.kw && ldx % 4 == 0, "gemm: shape");
     trace_launch("gemm_splitk_kernel");
     static const int mtw = [] {
         const char* e = getenv("AUR_GEMM_MTW");
         return (e && atoi(e) == 1) ? 1 : 2;
     }();
+    const GemmGelu none{nullptr, nullptr};
+    bool applied = false;
     if (pl.fused) {
         dim3 grid(N / 64, 1, (M + 31) / 32);
-        hipLaunchKernelGGL((gemm_splitk_kernel<true, 2>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices);
+        if (gelu) {
+            hipLaunchKernelGGL((gemm_splitk_kernel<true, 2, true>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices, *gelu);
+            applied = true;
+        } else {
+            hipLaunchKernelGGL((gemm_splitk_kernel<true, 2, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices, none);
+        }
     } else if (mtw == 1) {
         dim3 grid(N / 64, pl.slices, (M + 15) / 16);
-        hipLaunchKernelGGL((gemm_splitk_kernel<false, 1>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices);
+        hipLaunchKernelGGL((gemm_splitk_kernel<false, 1, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices, none);
     } else {
         dim3 grid(N / 64, pl.slices, (M + 31) / 32);
-        hipLaunchKernelGGL((gemm_splitk_kernel<false, 2>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices);
+        hipLaunchKernelGGL((gemm_splitk_kernel<false, 2, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices, none);
     }
     HIP_CHECK(hipGetLastError());
-}
-
-// Sum of the S split-K partial slabs of one float4 column group plus the bias, in the fixed order
-// ((p[0] + p[1]) + ... + p[S-1]) + bias.  Loads go out four at a time at clamped slab indices (a counted loop of
-// dependent `t += load` made hipcc wait for every slab separately: S + 1 serialized round trips per consumer kernel);
-// the surplus lanes of the last group add 0.
-__device__ __forceinline__ f32x4 slab_sum(const float* __restrict__ p0, long sstride, int S, const float* __restrict__ bias_n) {
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_n);
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 t = zero;
-    for (int s = 0; s < S; s += 4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(p0 + (long)s * sstride);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p0 + (long)min(s + 1, S - 1) * sstride);
-        const f32x4 c = *reinterpret_cast<const f32x4*>(p0 + (long)min(s + 2, S - 1) * sstride);
-        const f32x4 d = *reinterpret_cast<const f32x4*>(p0 + (long)min(s + 3, S - 1) * sstride);
-        t += a;
-        t += (s + 1 < S) ? b : zero;
-        t += (s + 2 < S) ? c : zero;
-        t += (s + 3 < S) ? d : zero;
-    }
-    return t + bv;
+    return applied;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -110,7 +110,7 @@ def main():
     gpt_sd = make_synthetic_gpt(dims.gpt, seed=1234, n_layer=args.layers)
     xtts_sd = make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd)
     eng = NativeEngine(n_layer=args.layers, max_seqs=args.batch, device=local_rank, profile=True,
-                       vocoder_fp16=(args.vocoder == "fp16"))
+                       vocoder_fp16=(args.vocoder == "fp16"), return_latents=False)   # audio + tokens, as TTSOutput
     eng.load_weights(pack_all(gpt_sd, xtts_sd))
     _log("weights resident")
 

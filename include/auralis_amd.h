@@ -44,6 +44,9 @@ typedef struct aur_config {
                                  0 = exact-f32 MFMA parity mode */
     int32_t second_pass;      /* 1 = A/B mode: recompute the latents with the reference's literal second GPT pass
                                  (XTTSv2.py:617-687) instead of the decode-time stash */
+    int32_t return_latents;   /* 1 = also copy each sequence's vocoder input latents to the host (aur_result.latents; parity
+                                 tests).  0 = audio and tokens only, as the reference's TTSOutput (saves ~1.1 MB of D2H
+                                 and host copies per 280-token utterance) */
 } aur_config;
 
 /* One named fp32 tensor.  Names are the packed names produced by auralis_amd/weights.py from the
