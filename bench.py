@@ -170,13 +170,18 @@ def main():
         audio_s = samples / 24000.0
         conv_s = st["conv_ms"] * 1e-3
         n_conv = max(1, st["conv_launches"])
-        traffic = None
+        # PMC-measured HBM bytes per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE passes, profiles/hbm_traffic.json; the
+        # counters cannot be read from inside this process)
+        traffic = gemm_traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.isfile(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"conv_{args.vocoder}_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get(f"conv_{args.vocoder}_bytes_per_launch")
+                if args.batch == 64 and args.layers == 30:
+                    gemm_traffic = tj.get("decode_gemm", {}).get("bytes_per_launch")
             except Exception:
-                traffic = None
+                traffic = gemm_traffic = None
         conv_kernel = "conv1d_mfma_f16_kernel" if args.vocoder == "fp16" else "conv1d_mfma_kernel"
         conv_gbps = st["conv_bytes"] / conv_s / 1e9 if conv_s > 0 else 0.0
         conv_tflops = st["conv_flops"] / conv_s / 1e12 if conv_s > 0 else 0.0
@@ -201,13 +206,14 @@ def main():
         roof_gemm = {
             "kernel": "gemm_splitk_kernel<false> (decode QKV / proj / FC / proj2 / mel-head, M = live sequences)",
             "bound": "hbm", "achieved": gemm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gemm_gbps / HBM_PEAK_GBPS,
-            "traffic": None, "avg_launch_ms": st["gemm_ms_raw"] / n_gemm, "avg_launch_ms_minus_event_overhead": st["gemm_ms"] / n_gemm,
+            "traffic": gemm_traffic, "avg_launch_ms": st["gemm_ms_raw"] / n_gemm, "avg_launch_ms_minus_event_overhead": st["gemm_ms"] / n_gemm,
             "event_pair_overhead_ms": st["event_pair_overhead_ms"], "launches_sampled": st["gemm_launches"],
             "algorithmic_bytes_per_launch": st["gemm_bytes"] / n_gemm, "total_ms_in_timed_region_est": est_gemm_total_ms,
             "mfma": {"achieved": gemm_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": gemm_tflops / FP32_MFMA_PEAK_TFLOPS},
             "note": "weights stream once per step (HBM) but at M = 64 exact-f32 MFMA time is of the same order; per-launch "
-                    "latency dominates (one 64x64x256 tile per CU)",
+                    "latency dominates (one 32x64x256 tile per workgroup, <= 2 workgroups per CU); traffic = weights once + "
+                    "the activation matrix once per XCD L2 (PMC, profiles/hbm_traffic.json)",
         }
         dominant, other = (roof_gemm, roof_conv) if est_gemm_total_ms > st["conv_ms"] else (roof_conv, roof_gemm)
         line = {
