@@ -10,12 +10,16 @@ Parity pin status
 * Vocoder (hifigan_forward / hifi_decoder_forward): PINNED against the reference's own
   `HifiDecoder` class imported unmodified in the build container (oracle/make_golden.py →
   tests/golden/vocoder_*.npz, and tests/test_oracle_vs_reference.py when /root/reference exists).
-* GPT (GPTOracle): the reference delegates this arithmetic to the un-vendored third-party
-  dependency vllm==0.6.4.post1 (setup.py:63) whose GPT2Block/Sampler are not under
-  /root/reference, and the reference's tests hold no golden vectors for it.
-  The restatement is cross-checked against transformers.GPT2Model (tests/test_oracle_gpt.py) and
-  follows the reference call sites cited per function below, but it is "parity unpinned" in the
-  strict sense: no reference-produced vector exists to pin it to.
+* GPT glue (GPTOracle.build_cond / mel_embed / forward_rows ordering / ln_f, apply_repetition_penalty): PINNED against
+  the reference's own `GPT2Model.forward`, `LearnedPositionEmbeddings` (vllm_mm_gpt.py) and `LogitsRepetitionPenalizer`
+  (vllm/hijack.py), executed unmodified in the build container through import stubs (oracle/ref_gpt_import.py,
+  oracle/make_golden_gpt.py → tests/golden/gpt_glue_L2.npz, tests/test_reference_gpt_glue.py).
+* GPT block arithmetic and the sampler: the reference delegates these to the un-vendored third-party dependency
+  vllm==0.6.4.post1 (setup.py:63): `GPT2Block` and `Sampler` are not under /root/reference and the reference's tests hold
+  no golden vectors for them.  In the fixture above vllm's block is replaced by the textbook GPT-2 block
+  built from transformers' Conv1D / gelu_new modules; the restatement is additionally cross-checked against
+  transformers.GPT2Model (tests/test_oracle_gpt.py) and the sampler follows vLLM 0.6.4's published order.
+  For these two pieces the oracle is "parity unpinned" in the strict sense: no reference-produced vector can exist.
 
 Reference citations are relative to /root/reference/src/auralis/.
 """
