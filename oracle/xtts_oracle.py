@@ -9,7 +9,7 @@ Parity pin status
 -----------------
 * Vocoder (hifigan_forward / hifi_decoder_forward): PINNED against the reference's own
   `HifiDecoder` class imported unmodified in the build container (oracle/make_golden.py →
-  tests/golden/vocoder_*.npz, and tests/test_oracle_vs_reference.py when /root/reference exists).
+  tests/golden/vocoder_*.npz, and live in tests/test_oracle_vocoder.py when /root/reference exists).
 * GPT glue (GPTOracle.build_cond / mel_embed / forward_rows ordering / ln_f, apply_repetition_penalty): PINNED against
   the reference's own `GPT2Model.forward`, `LearnedPositionEmbeddings` (vllm_mm_gpt.py) and `LogitsRepetitionPenalizer`
   (vllm/hijack.py), executed unmodified in the build container through import stubs (oracle/ref_gpt_import.py,

@@ -77,3 +77,30 @@ def test_hip_prefill_matches_reference_gpt2model():
         assert int(np.argmax(logits)) == int(np.argmax(G["logits_gen_rows"][0]))
     finally:
         e.close()
+
+
+from oracle.ref_gpt_import import reference_gpt_available  # noqa: E402
+
+
+@pytest.mark.skipif(not reference_gpt_available(), reason="/root/reference not present (GPU box)")
+@pytest.mark.parametrize("n_layer,n_text,n_tok", [(1, 3, 1), (3, 17, 9)])
+def test_oracle_against_live_reference_gpt2model(dims, n_layer, n_text, n_tok):
+    """Other depths / lengths than the committed fixture, with the reference module executed on the spot."""
+    from auralis_amd.checkpoint import (make_synthetic_conditioning, make_synthetic_gpt, make_synthetic_text_ids,
+                                        make_synthetic_xtts)
+    from oracle.ref_gpt_import import build_reference_gpt2model
+    gpt_sd = make_synthetic_gpt(dims.gpt, seed=77, n_layer=n_layer)
+    xtts_sd = make_synthetic_xtts(dims, seed=77, gpt_sd=gpt_sd)
+    gpt = O.GPTOracle(gpt_sd, xtts_sd)
+    cond, _ = make_synthetic_conditioning(dims)
+    ids = list(make_synthetic_text_ids(dims, n_text=n_text, seed=3))
+    toks = torch.randint(0, 1024, (n_tok,), generator=torch.Generator().manual_seed(n_tok)).tolist()
+    c = gpt.build_cond(cond, ids)
+    model = build_reference_gpt2model(gpt_sd, n_layer)
+    with torch.no_grad():
+        ref = model(input_ids=torch.tensor(toks), position_ids=torch.arange(1, n_tok + 1), kv_caches=[None] * n_layer,
+                    attn_metadata=None, intermediate_tensors=None, input_embeds=[c[None]], starting_sequence_start_ids=[0],
+                    is_profiling_run=False, is_logit_only=torch.tensor([False]))
+    x = torch.cat([c, gpt.mel_embed([1024] + toks, list(range(n_tok + 1)))], dim=0)
+    h, _ = gpt.forward_rows(x, None)
+    assert h.shape == ref.shape and (h - ref).abs().max().item() < 3e-5
