@@ -1,5 +1,6 @@
 #!/bin/bash
-# The driver's round-end commands on one box: full -m gpu suite, smoke(), default bench, rocprofv3 stats of the bench.
+# The driver's round-end commands on one GPU box: full -m gpu suite, smoke(), default bench, rocprofv3 stats of the bench.
+# usage (from the repo root, through gpurun): bash tools/gpu_round_check.sh <tag>   -> gpurun_out/<tag>_*, gpurun_out/prof_<tag>/
 exec < /dev/null
 TAG=${1:-final}
 mkdir -p gpurun_out
