@@ -1682,6 +1682,20 @@ int aur_reset_stats(aur_engine* e) {
     CHECK_PTR(e);
     return guarded([&] { e->impl.reset_stats(); });
 }
+int aur_dbg_gemm_tile_map(int32_t gx, int32_t gy, int32_t gz, int32_t group, int32_t* out3) {
+    CHECK_PTR(out3);
+    return guarded([&] {
+        AUR_REQUIRE(gx > 0 && gy > 0 && gz > 0 && group >= 0, "tile map: grid");
+        const int n = gx * gy * gz;
+        for (int L = 0; L < n; ++L) {
+            int nt, sl, mt;
+            aur::gemm_tile_map(L, gx, gy, gz, group, nt, sl, mt);
+            out3[3 * L] = nt;
+            out3[3 * L + 1] = sl;
+            out3[3 * L + 2] = mt;
+        }
+    });
+}
 int aur_dbg_gemm(aur_engine* e, const float* X, const float* W, float* out, int32_t M, int32_t N, int32_t K, int32_t kw) {
     CHECK_PTR(e);
     return guarded([&] { e->impl.dbg_gemm(X, W, out, M, N, K, kw); });

@@ -20,6 +20,48 @@ struct GemmPlan {
     int slabs;   // slabs the epilogue has to sum
 };
 GemmPlan gemm_plan(int M, int K);
+
+// Workgroup -> (column tile, K-slice, M-tile) of the split-K GEMM.  Workgroups are dispatched x-fastest and consecutive ids
+// go to consecutive XCDs, so ids that are 8 apart share an XCD (one L2):
+//  * nw = gx*gy weight tiles, a multiple of 8: each XCD owns nw/8 weight tiles and walks all gz M-tiles of one weight tile
+//    back to back (the weight tile leaves HBM once);
+//  * group > 0 (experiment, fused-slice plan with many M-tiles): the XCD walks its weight tiles inside blocks of `group`
+//    M-tiles, so that the activation rows of a block (group*32 rows) stay in L2 across the XCD's weight tiles instead of
+//    being re-fetched once per weight tile;
+//  * otherwise the plain order.
+// Any bijection is correct; results do not depend on it.
+__host__ __device__ inline void gemm_tile_map(int L, int gx, int gy, int gz, int group, int& ntile, int& slice, int& mtile) {
+    const int nw = gx * gy;
+    int wt;
+    if ((nw & 7) == 0) {
+        const int xcd = L & 7, slot = L >> 3, n_loc = nw >> 3;
+        if (group > 0 && group < gz) {
+            const int full = gz / group, per = n_loc * group;
+            int mg, wl, mi;
+            if (slot < full * per) {
+                mg = slot / per;
+                const int r = slot - mg * per;
+                wl = r / group;
+                mi = r - wl * group;
+            } else {
+                const int gt = gz - full * group, r = slot - full * per;
+                mg = full;
+                wl = r / gt;
+                mi = r - wl * gt;
+            }
+            mtile = mg * group + mi;
+            wt = wl * 8 + xcd;
+        } else {
+            mtile = slot % gz;
+            wt = (slot / gz) * 8 + xcd;
+        }
+    } else {
+        mtile = L / nw;
+        wt = L - mtile * nw;
+    }
+    ntile = wt % gx;
+    slice = wt / gx;
+}
 // Optional bias + gelu_new epilogue of the FC GEMM, fused-slice plan only (M > 128, i.e. prefill): the totals are in
 // registers, so act[m][n] = gelu_new(total + bias[n]) is written instead of the slab (same arithmetic order as
 // launch_bias_gelu on the slabs).  The split plan keeps the separate launch: a last-arriver tail inside the GEMM was

@@ -40,7 +40,7 @@ __device__ __forceinline__ f32x4 slab_sum(const float* __restrict__ p0, long sst
 template <bool FUSED, int MTW, bool GELU>
 __global__ __launch_bounds__(256) void gemm_splitk_kernel(const float* __restrict__ X, int ldx,
                                                           const float* __restrict__ W, float* __restrict__ P,
-                                                          int M, int N, int n_slices, GemmGelu ep) {
+                                                          int M, int N, int n_slices, GemmGelu ep, int tile_group) {
     // 4 waves = the 4 K-quarters of one 256-deep slice.  Each wave streams its 64 weight rows x 64 columns once
     // (16 float4 loads issued back to back, so one HBM latency covers the whole slice) and multiplies them with the
     // tile's activation rows.  Reduction order per output element is ((k0 + k1) + k2) + k3, then slices in order.
@@ -49,25 +49,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_kernel(const float* __restric
     __shared__ __attribute__((aligned(16))) float red[3][MR][68];
     const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    // Tile order: dispatch order is x fastest and consecutive workgroups go to consecutive XCDs, so the M-tiles that
-    // stream the SAME weight tile are given ids 8 apart => same XCD L2, adjacent in time (weights leave HBM once).
-    int ntile, slice, mtile;
-    {
-        const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
-        const int nw = gx * gy;
-        const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-        int wt;
-        if ((nw & 7) == 0) {
-            const int xcd = L & 7, slot = L >> 3;
-            mtile = slot % gz;
-            wt = (slot / gz) * 8 + xcd;
-        } else {
-            mtile = L / nw;
-            wt = L - mtile * nw;
-        }
-        ntile = wt % gx;
-        slice = wt / gx;
-    }
+    int ntile, slice, mtile;   // XCD-aware tile order, see gemm_tile_map
+    gemm_tile_map(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y, gridDim.z, tile_group,
+                  ntile, slice, mtile);
     const int n0 = ntile * 64, m0 = mtile * MR;
     const int s_begin = FUSED ? 0 : slice, s_end = FUSED ? n_slices : slice + 1;
 
@@ -180,22 +164,29 @@ bool launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M
         const char* e = getenv("AUR_GEMM_MTW");
         return (e && atoi(e) == 1) ? 1 : 2;
     }();
+    // AUR_GEMM_GROUP=<g>: M-tile blocks of g in the fused-slice plan when the activation panel of a block fits an L2 next
+    // to the XCD's weight tiles (K = 1024: g = 8 -> 1 MB); unmeasured experiment, default off
+    static const int group_env = [] {
+        const char* e = getenv("AUR_GEMM_GROUP");
+        return e ? atoi(e) : 0;
+    }();
+    const int group = (pl.fused && K <= 1024) ? group_env : 0;
     const GemmGelu none{nullptr, nullptr};
     bool applied = false;
     if (pl.fused) {
         dim3 grid(N / 64, 1, (M + 31) / 32);
         if (gelu) {
-            hipLaunchKernelGGL((gemm_splitk_kernel<true, 2, true>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices, *gelu);
+            hipLaunchKernelGGL((gemm_splitk_kernel<true, 2, true>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices, *gelu, group);
             applied = true;
         } else {
-            hipLaunchKernelGGL((gemm_splitk_kernel<true, 2, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices, none);
+            hipLaunchKernelGGL((gemm_splitk_kernel<true, 2, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices, none, group);
         }
     } else if (mtw == 1) {
         dim3 grid(N / 64, pl.slices, (M + 15) / 16);
-        hipLaunchKernelGGL((gemm_splitk_kernel<false, 1, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices, none);
+        hipLaunchKernelGGL((gemm_splitk_kernel<false, 1, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices, none, 0);
     } else {
         dim3 grid(N / 64, pl.slices, (M + 31) / 32);
-        hipLaunchKernelGGL((gemm_splitk_kernel<false, 2, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices, none);
+        hipLaunchKernelGGL((gemm_splitk_kernel<false, 2, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices, none, 0);
     }
     HIP_CHECK(hipGetLastError());
     return applied;

@@ -153,6 +153,10 @@ int aur_reset_stats(aur_engine* e);
 /* out[M][N] = X[M][K] @ W[K][N] via the split-K MFMA kernel + slab sum (kw = 0 picks the default). */
 int aur_dbg_gemm(aur_engine* e, const float* X, const float* W, float* out, int32_t M, int32_t N, int32_t K,
                  int32_t kw);
+/* Host-side evaluation of the GEMM kernel's workgroup -> (column tile, K-slice, M-tile) map for a (gx, gy, gz) grid
+ * (gpt_kernels.h gemm_tile_map; needs no GPU): out3[3*L + {0,1,2}] for L in [0, gx*gy*gz).  Lets the CPU tests check
+ * that every tile order in use is a bijection. */
+int aur_dbg_gemm_tile_map(int32_t gx, int32_t gy, int32_t gz, int32_t group, int32_t* out3);
 /* out[M][1024] = LayerNorm(h) rows */
 int aur_dbg_layernorm(aur_engine* e, const float* h, const float* gamma, const float* beta, float* out,
                       int32_t M);

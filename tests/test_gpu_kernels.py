@@ -21,7 +21,7 @@ def eng():
 @pytest.mark.parametrize("M,N,K,kw", [(64, 1024, 1024, 0), (5, 3072, 1024, 0), (64, 1024, 4096, 0),
                                       (103, 4096, 1024, 0), (300, 1024, 1024, 1), (130, 1088, 1024, 0),
                                       (1, 1024, 1024, 2), (33, 1024, 1024, 0), (300, 1024, 1024, 0),
-                                      (200, 1024, 4096, 0)])
+                                      (200, 1024, 4096, 0), (1500, 3072, 1024, 0)])
 def test_gemm_splitk(eng, M, N, K, kw):
     g = torch.Generator().manual_seed(M * 7 + N)
     X = torch.randn(M, K, generator=g)
