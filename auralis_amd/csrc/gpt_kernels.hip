@@ -165,7 +165,7 @@ bool launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M
         return (e && atoi(e) == 1) ? 1 : 2;
     }();
     // AUR_GEMM_GROUP=<g>: M-tile blocks of g in the fused-slice plan when the activation panel of a block fits an L2 next
-    // to the XCD's weight tiles (K = 1024: g = 8 -> 1 MB); unmeasured experiment, default off
+    // to the XCD's weight tiles (K = 1024: g = 8 -> 1 MB); experiment, default off (one r01 data point: no gain)
     static const int group_env = [] {
         const char* e = getenv("AUR_GEMM_GROUP");
         return e ? atoi(e) : 0;
