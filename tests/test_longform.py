@@ -59,3 +59,23 @@ def test_longform_mixed_languages_gpu(tmp_path, dims):
         assert np.array_equal(audio.array, again.array)                 # greedy: independent of the window / batching
     finally:
         tts.close()
+
+
+def test_book_scale_stream_host_overhead():
+    """BASELINE config 5 size (~450 k characters, > 2 000 chunks) through the facade with the fake engine: every chunk comes
+    back once and in order, and the host path stays far below the GPU's per-chunk time (~14 ms per chunk per GPU)."""
+    import time
+    paras = []
+    while sum(len(p) for p in paras) < 450_000:
+        paras += [EN, FR, DE]
+    reqs = build_requests(paras, [VOICE], seed=1)
+    fake = FakeNativeEngine(max_seqs=64)
+    tts = TTS(scheduler_max_concurrency=64).with_engine(XTTSv2Engine(fake, XTTSTokenizer(None)))
+    try:
+        t0 = time.perf_counter()
+        idx = [i for i, _ in stream_longform(tts, reqs, window=32)]
+        dt = time.perf_counter() - t0
+    finally:
+        tts.close()
+    assert idx == sorted(idx) and len(idx) == sum(_expected_chunks(reqs)) == len(fake.submitted) > 2000
+    assert dt / len(idx) < 5e-3, dt / len(idx)
