@@ -61,7 +61,7 @@ class aur_stats(C.Structure):
 EXPORTS = [
     "aur_last_error", "aur_version", "aur_engine_create", "aur_engine_destroy", "aur_load_weights",
     "aur_set_conditioning", "aur_set_conditioning_device", "aur_submit", "aur_step", "aur_poll_finished",
-    "aur_release", "aur_vocode", "aur_sync", "aur_get_stats", "aur_reset_stats", "aur_dbg_gemm",
+    "aur_release", "aur_vocode", "aur_sync", "aur_get_stats", "aur_reset_stats", "aur_dbg_gemm", "aur_dbg_gemm_rows",
     "aur_dbg_gemm_tile_map", "aur_dbg_layernorm", "aur_dbg_conv1d", "aur_dbg_conv1d_f16", "aur_dbg_prefill", "aur_dbg_sample",
 ]
 
@@ -102,6 +102,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "aur_get_stats": [eng, C.POINTER(aur_stats)],
         "aur_reset_stats": [eng],
         "aur_dbg_gemm": [eng, fp, fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32],
+        "aur_dbg_gemm_rows": [eng, fp, fp, fp, fp, fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32],
         "aur_dbg_gemm_tile_map": [C.c_int32, C.c_int32, C.c_int32, C.c_int32, ip],
         "aur_dbg_layernorm": [eng, fp, fp, fp, fp, C.c_int32],
         "aur_dbg_conv1d": [eng, fp, fp, fp, fp, fp, ip, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -267,6 +268,21 @@ class NativeEngine:
         assert K == K2
         out = np.empty((M, N), dtype=np.float32)
         self._check(self.lib.aur_dbg_gemm(self.h, _fp(X), _fp(W), _fp(out), M, N, K, kw))
+        return out
+
+    def dbg_gemm_rows(self, X, W, bias=None, gamma=None, beta=None, res=None, epi: int = 0) -> np.ndarray:
+        """Decode-regime GEMM: epi 0 bias, 1 bias + gelu_new, 2 res + (X @ W + bias); gamma/beta => LayerNorm prologue."""
+        X, W = _f32(X), _f32(W)
+        M, K = X.shape
+        K2, N = W.shape
+        assert K == K2
+        out = _f32(res).copy() if res is not None else np.zeros((M, N), dtype=np.float32)
+        bias = None if bias is None else _f32(bias)
+        ln = gamma is not None
+        gamma = None if gamma is None else _f32(gamma)
+        beta = None if beta is None else _f32(beta)
+        self._check(self.lib.aur_dbg_gemm_rows(self.h, _fp(X), _fp(W), _fp(bias), _fp(gamma), _fp(beta), _fp(out), M, N, K,
+                                               epi, int(ln)))
         return out
 
     def dbg_layernorm(self, h, gamma, beta) -> np.ndarray:

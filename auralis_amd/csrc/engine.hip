@@ -208,6 +208,7 @@ public:
         if (const char* e = getenv("AUR_DECODE_PIPELINE")) pipeline_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_SAMPLER_FULL_SORT")) sampler_full_sort_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_FUSE_GELU")) fuse_gelu_ = atoi(e) != 0;
+        if (const char* e = getenv("AUR_DECODE_GEMM")) rows_gemm_ = std::string(e) != "splitk";
 
         for (int i = 0; i < 2; ++i) {
             HIP_CHECK(hipEventCreateWithFlags(&ev_rb_[i], hipEventDisableTiming));
@@ -587,6 +588,41 @@ public:
             out[i] = t;
         }
     }
+    // decode-regime GEMM on host data: out = epi(LN?(X) @ W + bias); W is the plain [K][N] matrix, packed on the device by
+    // the same pack_wt16 the engine uses at load time.  epi: 0 bias, 1 bias + gelu_new, 2 out += (X @ W + bias).
+    void dbg_gemm_rows(const float* X, const float* Wm, const float* bias, const float* gamma, const float* beta, float* out,
+                       int M, int N, int K, int epi, bool ln) {
+        use();
+        AUR_REQUIRE(epi >= 0 && epi <= 2, "dbg_gemm_rows: epi in {0,1,2}");
+        AUR_REQUIRE(!ln || (gamma && beta), "dbg_gemm_rows: LN needs gamma and beta");
+        DevBuf dx, dw, dwt, db, dg, dbe, dout;
+        dx.ensure((size_t)M * K * 4);
+        dw.ensure((size_t)K * N * 4);
+        dwt.ensure((size_t)K * N * 4);
+        dout.ensure((size_t)M * N * 4);
+        HIP_CHECK(hipMemcpy(dx.p, X, (size_t)M * K * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dw.p, Wm, (size_t)K * N * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dout.p, out, (size_t)M * N * 4, hipMemcpyHostToDevice));
+        if (bias) {
+            db.ensure((size_t)N * 4);
+            HIP_CHECK(hipMemcpy(db.p, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+        }
+        if (ln) {
+            dg.ensure((size_t)K * 4);
+            dbe.ensure((size_t)K * 4);
+            HIP_CHECK(hipMemcpy(dg.p, gamma, (size_t)K * 4, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(dbe.p, beta, (size_t)K * 4, hipMemcpyHostToDevice));
+        }
+        launch_pack_wt16(dw.as<float>(), N, dwt.as<float>(), K, N, st_);
+        GemmRowsArgs a{};
+        a.X = dx.as<float>(); a.ldx = K; a.Wt = dwt.as<float>(); a.M = M; a.N = N; a.K = K;
+        a.bias = bias ? db.as<float>() : nullptr;
+        a.gamma = ln ? dg.as<float>() : nullptr; a.beta = ln ? dbe.as<float>() : nullptr; a.eps = 1e-5f;
+        a.out = dout.as<float>(); a.ldo = N;
+        launch_gemm_rows(a, ln, (GemmRowsEpi)epi, st_);
+        HIP_CHECK(hipStreamSynchronize(st_));
+        HIP_CHECK(hipMemcpy(out, dout.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    }
     void dbg_layernorm(const float* h, const float* gamma, const float* beta, float* out, int M) {
         use();
         DevBuf dh, dg, db, dout;
@@ -724,7 +760,16 @@ private:
     // ------------------------------------------------------------------ GPT
     struct LayerW {
         const float *ln1w, *ln1b, *wqkv, *bqkv, *wproj, *bproj, *ln2w, *ln2b, *wfc, *bfc, *wproj2, *bproj2;
+        const float *tqkv, *tproj, *tfc, *tproj2;   // pack_wt16 copies for the decode-regime GEMM (gemm_rows_kernel)
     };
+    // device-side repack of one [K][N] matrix into the decode GEMM's tile order (done once per load)
+    const float* packed_copy(const float* Wm, int ldw, int K, int N) {
+        packed_.emplace_back(new DevBuf());
+        DevBuf& b = *packed_.back();
+        b.ensure((size_t)K * N * sizeof(float));
+        launch_pack_wt16(Wm, ldw, b.as<float>(), K, N, st_);
+        return b.as<float>();
+    }
     void ensure_gpt() {
         if (gpt_ready_) return;
         layers_.clear();
@@ -738,7 +783,17 @@ private:
             l.ln2w = W(p + "ln_2.w", H); l.ln2b = W(p + "ln_2.b", H);
             l.wfc = W(p + "mlp.c_fc.w", (int64_t)H * 4 * H); l.bfc = W(p + "mlp.c_fc.b", 4 * H);
             l.wproj2 = W(p + "mlp.c_proj.w", (int64_t)4 * H * H); l.bproj2 = W(p + "mlp.c_proj.b", H);
+            l.tqkv = l.tproj = l.tfc = l.tproj2 = nullptr;
             layers_.push_back(l);
+        }
+        packed_.clear();
+        if (rows_gemm_) {
+            for (auto& l : layers_) {
+                l.tqkv = packed_copy(l.wqkv, 3 * H, H, 3 * H);
+                l.tproj = packed_copy(l.wproj, H, H, H);
+                l.tfc = packed_copy(l.wfc, 4 * H, H, 4 * H);
+                l.tproj2 = packed_copy(l.wproj2, H, 4 * H, H);
+            }
         }
         wte_ = W("gpt.wte", (int64_t)kMelVocab * H);
         wpe_ = W("gpt.wpe", (int64_t)kMaxLatRows * H);
@@ -746,6 +801,8 @@ private:
         fnw_ = W("final_norm.w", H); fnb_ = W("final_norm.b", H);
         headT_ = W("mel_head.wT", (int64_t)H * kHeadPad);
         headb_ = W("mel_head.b", kHeadPad);
+        thead_ = rows_gemm_ ? packed_copy(headT_, kHeadPad, H, kHeadPad) : nullptr;
+        HIP_CHECK(hipStreamSynchronize(st_));
         text_emb_ = W("text_emb");
         text_pos_ = W("text_pos");
         text_vocab_ = (int)(w_.at("text_emb").numel / H);
@@ -787,6 +844,57 @@ private:
         const bool applied = launch_gemm_splitk(X, ldx, Wm, P, M, N, K, pl, w.st, gelu);
         HIP_CHECK(hipEventRecord(ev.b, w.st));
         return applied;
+    }
+    // decode-regime GEMM launch (gemm_rows_kernel) with the same sampled event timing.  Algorithmic bytes of a launch:
+    // weights once + the activation rows once + the output tile once (the residual epilogue reads and writes it).
+    void gemm_rows(RowWs& w, const GemmRowsArgs& a, bool ln, GemmRowsEpi epi) {
+        if (!gemm_prof_now_) {
+            launch_gemm_rows(a, ln, epi, w.st);
+            return;
+        }
+        if (n_gemm_events_ == gemm_events_.size()) {
+            ConvEvent e{};
+            HIP_CHECK(hipEventCreate(&e.a));
+            HIP_CHECK(hipEventCreate(&e.b));
+            gemm_events_.push_back(e);
+        }
+        ConvEvent& ev = gemm_events_[n_gemm_events_++];
+        ev.flops = 2.0 * a.M * a.N * a.K;
+        ev.bytes = 4.0 * ((double)a.K * a.N + (double)a.M * a.K + (double)a.M * a.N * (epi == kEpiResidual ? 2.0 : 1.0));
+        HIP_CHECK(hipEventRecord(ev.a, w.st));
+        launch_gemm_rows(a, ln, epi, w.st);
+        HIP_CHECK(hipEventRecord(ev.b, w.st));
+    }
+    // One decode step through the blocks: 5 launches per layer (QKV GEMM with LN1 prologue and KV page write, attention,
+    // proj GEMM + residual, FC GEMM with LN2 prologue + gelu, proj2 GEMM + residual), no split-K slabs in HBM.  Leaves the
+    // residual stream in w.h (ln_f is applied by final_rows_kernel).
+    void forward_decode(RowWs& w, int M, const int* d_row_slot) {
+        float* h = w.h.as<float>();
+        const int* bt = block_tables_.as<int>();
+        const int* kvpos = slot_kvpos_.as<int>();
+        for (int l = 0; l < cfg_.n_layer; ++l) {
+            const LayerW& L = layers_[l];
+            float* kvl = kv_.as<float>() + (long)l * kv_layer_stride_;
+            GemmRowsArgs a{};
+            a.M = M; a.eps = 1e-5f;
+            a.X = h; a.ldx = kHidden; a.Wt = L.tqkv; a.N = 3 * kHidden; a.K = kHidden; a.bias = L.bqkv;
+            a.gamma = L.ln1w; a.beta = L.ln1b; a.out = w.qbuf.as<float>(); a.ldo = kHidden;
+            a.kv_layer = kvl; a.row_slot = d_row_slot; a.slot_kvpos = kvpos; a.block_tables = bt; a.max_blocks = kMaxBlocks;
+            gemm_rows(w, a, true, kEpiQkv);
+            launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, nullptr, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st);
+            a = GemmRowsArgs{};
+            a.M = M; a.X = w.att.as<float>(); a.ldx = kHidden; a.Wt = L.tproj; a.N = kHidden; a.K = kHidden; a.bias = L.bproj;
+            a.out = h; a.ldo = kHidden;
+            gemm_rows(w, a, false, kEpiResidual);
+            a = GemmRowsArgs{};
+            a.M = M; a.eps = 1e-5f; a.X = h; a.ldx = kHidden; a.Wt = L.tfc; a.N = 4 * kHidden; a.K = kHidden; a.bias = L.bfc;
+            a.gamma = L.ln2w; a.beta = L.ln2b; a.out = w.act.as<float>(); a.ldo = 4 * kHidden;
+            gemm_rows(w, a, true, kEpiBiasGelu);
+            a = GemmRowsArgs{};
+            a.M = M; a.X = w.act.as<float>(); a.ldx = 4 * kHidden; a.Wt = L.tproj2; a.N = kHidden; a.K = 4 * kHidden; a.bias = L.bproj2;
+            a.out = h; a.ldo = kHidden;
+            gemm_rows(w, a, false, kEpiResidual);
+        }
     }
     // Fixed cost of one HIP-event pair on an otherwise busy stream: recording events between back-to-back short
     // kernels serialises their launch processing, which inflates a ~12 us kernel by ~3 us.  Measured once as the
@@ -894,6 +1002,18 @@ private:
         gemm(w, w.ybuf.as<float>(), kHidden, headT_, w.P2.as<float>(), Ms, kHeadPad, kHidden, ph);
         SamplerArgs a = sampler_args(w, w.P2.as<float>(), ph.slabs, Ms, kHeadPad, headb_, has_next_kvpos ? w.i_next_kvpos.as<int>() : nullptr);
         launch_sampler(a, w.st);
+    }
+    // decode tail of the gemm_rows chain: rows are the live sequences in order (sample_row = identity), w.h holds the
+    // residual stream: ln_f + final_norm (+ second final_norm into the latent stash) -> mel_head GEMM (+ bias) -> sampler
+    void sample_kernels_decode(RowWs& w, int Ms) {
+        launch_final_rows(w.h.as<float>(), w.i_sample_slot.as<int>(), lnfw_, lnfb_, fnw_, fnb_, w.ybuf.as<float>(),
+                          latents_.as<float>(), (long)kMaxLatRows * kHidden, slot_ngen_.as<int>(), kMaxLatRows, Ms, 1e-5f, w.st);
+        GemmRowsArgs a{};
+        a.M = Ms; a.X = w.ybuf.as<float>(); a.ldx = kHidden; a.Wt = thead_; a.N = kHeadPad; a.K = kHidden; a.bias = headb_;
+        a.out = w.P2.as<float>(); a.ldo = kHeadPad;
+        gemm_rows(w, a, false, kEpiBias);
+        SamplerArgs sa = sampler_args(w, w.P2.as<float>(), 1, Ms, kHeadPad, zero_bias_.as<float>(), nullptr);
+        launch_sampler(sa, w.st);
     }
     void sample_readback(RowWs& w, int Ms, hipStream_t st, int* pin = nullptr) {
         if (!pin) pin = w.pin.as<int>();
@@ -1056,8 +1176,13 @@ private:
     // GEMMs are latency bound, the attention is bandwidth bound: the chains fill each other's gaps).
     void decode_kernels(RowWs& w, int Mk) {
         launch_embed_decode(w.i_row_slot.as<int>(), slot_tok_.as<int>(), slot_pos_.as<int>(), wte_, wpe_, w.h.as<float>(), Mk, w.st);
-        forward_rows(w, Mk, w.i_row_slot.as<int>(), nullptr);
-        sample_kernels(w, Mk, false);
+        if (rows_gemm_) {
+            forward_decode(w, Mk, w.i_row_slot.as<int>());
+            sample_kernels_decode(w, Mk);
+        } else {   // AUR_DECODE_GEMM=splitk: the round-1 chain (split-K slabs + LN / GELU epilogue launches), kept for A/B
+            forward_rows(w, Mk, w.i_row_slot.as<int>(), nullptr);
+            sample_kernels(w, Mk, false);
+        }
     }
     // ---- pipelined decode (default): the step's kernel chain depends only on device-resident state, so step s+1 is
     // enqueued BEFORE the host waits for the token / finished-flag read-back of step s (otherwise the GPU idles for the
@@ -1491,6 +1616,9 @@ private:
     std::unordered_map<std::string, Tensor> w_;
     bool gpt_ready_ = false, voc_ready_ = false;
     std::vector<LayerW> layers_;
+    std::vector<std::unique_ptr<DevBuf>> packed_;   // pack_wt16 copies (decode GEMM layout)
+    const float* thead_ = nullptr;
+    bool rows_gemm_ = true;             // AUR_DECODE_GEMM=splitk selects the round-1 decode chain
     const float *wte_ = nullptr, *wpe_ = nullptr, *lnfw_ = nullptr, *lnfb_ = nullptr, *fnw_ = nullptr, *fnb_ = nullptr,
                 *headT_ = nullptr, *headb_ = nullptr, *text_emb_ = nullptr, *text_pos_ = nullptr;
     int text_vocab_ = 0, text_positions_ = 0;
@@ -1699,6 +1827,14 @@ int aur_dbg_gemm_tile_map(int32_t gx, int32_t gy, int32_t gz, int32_t group, int
 int aur_dbg_gemm(aur_engine* e, const float* X, const float* W, float* out, int32_t M, int32_t N, int32_t K, int32_t kw) {
     CHECK_PTR(e);
     return guarded([&] { e->impl.dbg_gemm(X, W, out, M, N, K, kw); });
+}
+int aur_dbg_gemm_rows(aur_engine* e, const float* X, const float* W, const float* bias, const float* gamma, const float* beta,
+                      float* out, int32_t M, int32_t N, int32_t K, int32_t epi, int32_t ln) {
+    CHECK_PTR(e);
+    CHECK_PTR(X);
+    CHECK_PTR(W);
+    CHECK_PTR(out);
+    return guarded([&] { e->impl.dbg_gemm_rows(X, W, bias, gamma, beta, out, M, N, K, epi, ln != 0); });
 }
 int aur_dbg_layernorm(aur_engine* e, const float* h, const float* gamma, const float* beta, float* out, int32_t M) {
     CHECK_PTR(e);

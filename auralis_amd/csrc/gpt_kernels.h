@@ -75,6 +75,41 @@ struct GemmGelu {
 bool launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M, int N, int K, const GemmPlan& pl,
                         hipStream_t st, const GemmGelu* gelu = nullptr);
 
+// ---- decode-regime GEMM (M = live sequences; every weight leaves HBM once per step) ---------------------------------
+// One workgroup = 16 waves = one [16*MT rows] x [16 columns] output tile over the FULL K: wave w owns K-slice
+// [c*1024 + 64w, +64) of every 1024-deep chunk c, partial tiles are reduced through LDS in fixed wave order, and the
+// epilogue (bias | bias+gelu | bias+residual | QKV split + KV page write) runs on the totals, so there are no split-K
+// slabs in HBM and no separate LayerNorm / GELU launches.  LN: the A operand is LayerNorm(X) computed in the prologue
+// (two-pass statistics over the full row, which the workgroup holds in registers; K == 1024).
+// Weights come packed by pack_wt16: Wt[N/16][K/16][64 lanes][4], lane = 16*q + j, component s
+//   = W[16*kb + 4*q + s][16*nt + j], i.e. one 16 x 16 K-by-N block is 1 KiB, contiguous, and the float4 a lane loads IS its
+// B fragment for four consecutive v_mfma_f32_16x16x4_f32 steps (the A float4 X[row][16*kb + 4*q .. +3] likewise).
+enum GemmRowsEpi { kEpiBias = 0, kEpiBiasGelu = 1, kEpiResidual = 2, kEpiQkv = 3 };
+struct GemmRowsArgs {
+    const float* X;      // [M][ldx]
+    int ldx;
+    const float* Wt;     // packed (pack_wt16)
+    int M, N, K;
+    const float* bias;   // [N] or nullptr
+    const float* gamma;  // LN prologue (ln != 0): LayerNorm weight / bias over K == 1024
+    const float* beta;
+    float eps;
+    float* out;          // kEpiBias / kEpiBiasGelu: out[m][n] (ldo);  kEpiResidual: out[m][n] += total + bias;  kEpiQkv: q rows [M][1024]
+    int ldo;
+    float* kv_layer;     // kEpiQkv: paged K/V of this layer, written at (slot = row_slot[m], pos = slot_kvpos[slot])
+    const int* row_slot;
+    const int* slot_kvpos;
+    const int* block_tables;
+    int max_blocks;
+};
+void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream_t st);
+// Wt = pack_wt16(W), W row-major [K][ldw], N % 16 == 0, K % 16 == 0
+void launch_pack_wt16(const float* W, int ldw, float* Wt, int K, int N, hipStream_t st);
+// decode tail: y[j] = final_norm(ln_f(h[j])) -> ybuf;  latents[slot][ngen[slot]] = final_norm(y[j])
+void launch_final_rows(const float* h, const int* sample_slot, const float* lnf_w, const float* lnf_b, const float* fn_w,
+                       const float* fn_b, float* ybuf, float* latents, long lat_slot_stride, const int* slot_ngen,
+                       int max_lat_rows, int Ms, float eps, hipStream_t st);
+
 // h[m] += sum_s P[s][m] + bias (if S > 0); out[m] = LayerNorm(h[m]; gamma, beta, eps).  Rows of 1024.
 void launch_rows_ln(const float* P, int S, const float* bias, float* h, const float* gamma, const float* beta,
                     float* out, int M, float eps, hipStream_t st);

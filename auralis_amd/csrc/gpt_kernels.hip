@@ -7,6 +7,11 @@
 
 namespace aur {
 
+// paged KV layout of one layer: [block][K|V][head][token_in_block(16)][64]
+__device__ __forceinline__ long kv_offset(int blk, int kv, int head, int tok) {
+    return (((long)blk * 2 + kv) * kHeads + head) * (kKvBlockTokens * kHeadDim) + (long)tok * kHeadDim;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Split-K weight-streaming GEMM.  One workgroup = 4 waves = one 64x64 output tile over a K-range of 4*kw;
 // wave w streams rows [kbeg + w*kw, +kw) of W straight from HBM into registers as float4 (16 lanes x 16 B =
@@ -193,6 +198,253 @@ bool launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M
 }
 
 // ------------------------------------------------------------------------------------------------
+// Decode-regime GEMM: see gpt_kernels.h.  Reduction order of one output element: the MFMA k-chain of wave w over its
+// 64-wide slice of every chunk (chunks in order), then waves 0..15 in order — independent of M and of the other rows, so
+// continuous batching stays bitwise batch-invariant.
+__global__ __launch_bounds__(256) void pack_wt16_kernel(const float* __restrict__ W, int ldw, float* __restrict__ Wt, int K,
+                                                        int N) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // one float4 of Wt
+    const long total = (long)(N >> 4) * (K >> 4) * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const long blk = idx >> 6;
+    const int kb = (int)(blk % (K >> 4)), nt = (int)(blk / (K >> 4));
+    const int j = lane & 15, q = lane >> 4;
+    const float* src = W + (long)(16 * kb + 4 * q) * ldw + 16 * nt + j;
+    f32x4 v = {src[0], src[ldw], src[2L * ldw], src[3L * ldw]};
+    *reinterpret_cast<f32x4*>(Wt + idx * 4) = v;
+}
+
+void launch_pack_wt16(const float* W, int ldw, float* Wt, int K, int N, hipStream_t st) {
+    AUR_REQUIRE(N % 16 == 0 && K % 16 == 0 && ldw >= N, "pack_wt16: shape");
+    const long total = (long)(N >> 4) * (K >> 4) * 64;
+    trace_launch("pack_wt16_kernel");
+    hipLaunchKernelGGL(pack_wt16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, ldw, Wt, K, N);
+    HIP_CHECK(hipGetLastError());
+}
+
+template <int MT, int KCH, bool LN, int EPI, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
+    static_assert(!LN || KCH == 1, "LN prologue needs the whole row in one chunk");
+    static_assert(NW == 8 || NW == 16, "waves per workgroup");
+    constexpr int NB = 64 / NW;   // 16-deep K blocks per wave per 1024-deep chunk
+    __shared__ __attribute__((aligned(16))) float red[NW][MT * 256];
+    __shared__ __attribute__((aligned(16))) float part[LN ? 2 : 1][LN ? 16 * MT : 1][NW];
+    __shared__ __attribute__((aligned(16))) float gb[LN ? 2 : 1][LN ? 1024 : 4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    // workgroup -> (column tile, row group): the row groups of one column tile get ids 8 apart (same XCD, adjacent in
+    // dispatch order) so that the tile's weights leave HBM once and the other groups hit them in that XCD's L2
+    const int n_tiles = a.N >> 4, n_grp = (a.M + 16 * MT - 1) / (16 * MT);
+    int ntile, mgrp;
+    {
+        const int L = blockIdx.x;
+        if ((n_tiles & 7) == 0) {
+            const int xcd = L & 7, slot = L >> 3;
+            mgrp = slot % n_grp;
+            ntile = (slot / n_grp) * 8 + xcd;
+        } else {
+            mgrp = L % n_grp;
+            ntile = L / n_grp;
+        }
+    }
+    const int n0 = ntile * 16, m0 = mgrp * 16 * MT;
+    const f32x4* wt = reinterpret_cast<const f32x4*>(a.Wt) + (long)ntile * (a.K >> 4) * 64 + lane;
+    const float* xr[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int r = m0 + 16 * mt + j;
+        xr[mt] = a.X + (long)(r < a.M ? r : m0) * a.ldx + 4 * q;   // rows >= M alias the group's first row: never stored
+    }
+    f32x4 bf[KCH > 1 ? 2 : 1][NB], af[KCH > 1 ? 2 : 1][MT][NB];
+    auto load_chunk = [&](int c, int buf) {
+        const int kb0 = c * 64 + NB * w;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) bf[buf][b] = wt[(long)(kb0 + b) * 64];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) af[buf][mt][b] = *reinterpret_cast<const f32x4*>(xr[mt] + 16 * (kb0 + b));
+    };
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_chunk(0, 0);
+    if (LN) {
+        // gamma / beta go through LDS (8 KB, staged by the first 8 waves): holding this lane's values in registers next to
+        // the A registers of a 64-row tile spilled; they become visible with the barriers of the statistics passes
+        if (tid < 512) {
+            const float* src = (tid < 256) ? a.gamma : a.beta;
+            *reinterpret_cast<f32x4*>(&gb[tid >> 8][4 * (tid & 255)]) = *reinterpret_cast<const f32x4*>(src + 4 * (tid & 255));
+        }
+        __builtin_amdgcn_sched_barrier(0);   // every load of the workgroup is in flight before the first wait
+        float mean[MT], rstd[MT];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float t = 0.f;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const f32x4 v = af[0][mt][b];
+                    if (pass == 0) {
+                        t += (v[0] + v[1]) + (v[2] + v[3]);
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            const float d = v[s] - mean[mt];
+                            t = fmaf(d, d, t);
+                        }
+                    }
+                }
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                if (q == 0) part[pass][16 * mt + j][w] = t;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4* pp = reinterpret_cast<const f32x4*>(&part[pass][16 * mt + j][0]);
+                float tot = 0.f;
+#pragma unroll
+                for (int u = 0; u < NW / 4; ++u) {
+                    const f32x4 pv = pp[u];
+                    const float g4 = (pv[0] + pv[1]) + (pv[2] + pv[3]);
+                    tot = (u == 0) ? g4 : tot + g4;
+                }
+                if (pass == 0) mean[mt] = tot * (1.0f / 1024.0f);
+                else rstd[mt] = 1.0f / sqrtf(tot * (1.0f / 1024.0f) + a.eps);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            // k = 16*(NB*w + b) + 4q + s
+            const f32x4 gam = *reinterpret_cast<const f32x4*>(&gb[0][16 * (NB * w + b) + 4 * q]);
+            const f32x4 bet = *reinterpret_cast<const f32x4*>(&gb[1][16 * (NB * w + b) + 4 * q]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) af[0][mt][b][s] = (af[0][mt][b][s] - mean[mt]) * rstd[mt] * gam[s] + bet[s];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+        const int cur = (KCH > 1) ? (c & 1) : 0;
+        if (c + 1 < KCH) load_chunk(c + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);   // the next chunk's loads are issued before this chunk's MFMAs
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][mt][b][s], bf[cur][b][s], acc[mt], 0, 0, 0);
+    }
+    // D layout: row = 4*(lane>>4) + r, col = lane&15
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w][mt * 256 + r * 64 + lane] = acc[mt][r];
+    __syncthreads();
+    for (int e = tid; e < MT * 256; e += 64 * NW) {
+        float t = red[0][e];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) t += red[ww][e];
+        const int mt = e >> 8, r = (e >> 6) & 3, l = e & 63;
+        const int m = m0 + 16 * mt + 4 * (l >> 4) + r, n = n0 + (l & 15);
+        if (m < a.M) {
+            if (a.bias) t += a.bias[n];
+            if (EPI == kEpiBias) {
+                a.out[(long)m * a.ldo + n] = t;
+            } else if (EPI == kEpiBiasGelu) {
+                a.out[(long)m * a.ldo + n] = gelu_new(t);
+            } else if (EPI == kEpiResidual) {
+                float* p = a.out + (long)m * a.ldo + n;
+                *p = *p + t;
+            } else {
+                const int u = n / kHidden, d = n - u * kHidden;
+                if (u == 0) {
+                    a.out[(long)m * kHidden + d] = t;
+                } else {
+                    const int slot = a.row_slot[m];
+                    const int pos = a.slot_kvpos[slot];
+                    const int blk = a.block_tables[(long)slot * a.max_blocks + pos / kKvBlockTokens];
+                    a.kv_layer[kv_offset(blk, u - 1, d / kHeadDim, pos % kKvBlockTokens) + d % kHeadDim] = t;
+                }
+            }
+        }
+    }
+}
+
+// Workgroup shapes in use.  16 waves (K-slice 64 per wave, <= 128 VGPRs per lane) everywhere except the 64-row tiles with
+// the LN prologue: 64 A registers + the statistics spilled there, so those run as 8 waves with K-slices of 128 (<= 256
+// VGPRs).  K = 4096 needs two chunk buffers: at most 32 rows per workgroup.
+template <int KCH, bool LN, int EPI>
+static void launch_gemm_rows_mt(const GemmRowsArgs& a, int mt, int nw, hipStream_t st) {
+    const int n_tiles = a.N / 16;
+    const int n_grp = (a.M + 16 * mt - 1) / (16 * mt);
+    const dim3 grid((unsigned)(n_tiles * n_grp));
+    if constexpr (KCH == 1) {
+        if (mt == 4) {
+            if constexpr (LN) {
+                AUR_REQUIRE(nw == 8, "gemm_rows: 64-row LN tiles need 8-wave workgroups");
+                hipLaunchKernelGGL((gemm_rows_kernel<4, KCH, LN, EPI, 8>), grid, dim3(512), 0, st, a);
+            } else {
+                if (nw == 8) hipLaunchKernelGGL((gemm_rows_kernel<4, KCH, LN, EPI, 8>), grid, dim3(512), 0, st, a);
+                else hipLaunchKernelGGL((gemm_rows_kernel<4, KCH, LN, EPI, 16>), grid, dim3(1024), 0, st, a);
+            }
+            return;
+        }
+    }
+    AUR_REQUIRE(mt <= 2 || KCH == 1, "gemm_rows: rows per workgroup");
+    if (mt == 2) {
+        if (nw == 8) hipLaunchKernelGGL((gemm_rows_kernel<2, KCH, LN, EPI, 8>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((gemm_rows_kernel<2, KCH, LN, EPI, 16>), grid, dim3(1024), 0, st, a);
+    } else {
+        if (nw == 8) hipLaunchKernelGGL((gemm_rows_kernel<1, KCH, LN, EPI, 8>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((gemm_rows_kernel<1, KCH, LN, EPI, 16>), grid, dim3(1024), 0, st, a);
+    }
+}
+
+void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream_t st) {
+    AUR_REQUIRE(a.N % 16 == 0 && (a.K == 1024 || a.K == 4096) && a.ldx % 4 == 0 && a.M >= 1, "gemm_rows: shape");
+    AUR_REQUIRE(!ln || a.K == 1024, "gemm_rows: LN prologue needs K == 1024");
+    // rows per workgroup: the largest of 64 / 32 / 16 that still yields >= 192 workgroups (the chip has 256 CUs and a
+    // workgroup fills one), so N = 1024 GEMMs split the rows and re-read the column tile's weights from L2
+    static const int mt_env = [] {
+        const char* e = getenv("AUR_GEMM_ROWS_MT");
+        return e ? atoi(e) : 0;
+    }();
+    // waves per workgroup fix the K grouping of the reduction, so they depend on the GEMM kind only, never on M (a row's
+    // result must not change with the number of live rows): LN-prologue GEMMs 8 waves, the others 16
+    static const int nw_plain = [] {
+        const char* e = getenv("AUR_GEMM_ROWS_NW");
+        return (e && atoi(e) == 8) ? 8 : 16;
+    }();
+    static const int nw_ln = [] {
+        const char* e = getenv("AUR_GEMM_ROWS_NW_LN");
+        return (e && atoi(e) == 16) ? 16 : 8;
+    }();
+    const int nw = ln ? nw_ln : nw_plain;
+    int mt = 4;
+    while (mt > 1 && ((a.M + 16 * mt - 1) / (16 * mt)) * (a.N / 16) < 192 && a.M > 16 * (mt / 2)) mt >>= 1;
+    while (mt > 1 && a.M <= 16 * (mt / 2)) mt >>= 1;
+    if (mt_env == 1 || mt_env == 2 || mt_env == 4) mt = mt_env;
+    if (a.K == 4096 && mt > 2) mt = 2;
+    if (ln && nw == 16 && mt > 2) mt = 2;   // (64-row LN tiles exist as 8-wave workgroups only)
+    trace_launch("gemm_rows_kernel");
+    if (ln && epi == kEpiQkv) launch_gemm_rows_mt<1, true, kEpiQkv>(a, mt, nw, st);
+    else if (ln && epi == kEpiBiasGelu) launch_gemm_rows_mt<1, true, kEpiBiasGelu>(a, mt, nw, st);
+    else if (ln && epi == kEpiBias) launch_gemm_rows_mt<1, true, kEpiBias>(a, mt, nw, st);
+    else if (!ln && epi == kEpiResidual && a.K == 1024) launch_gemm_rows_mt<1, false, kEpiResidual>(a, mt, nw, st);
+    else if (!ln && epi == kEpiResidual && a.K == 4096) launch_gemm_rows_mt<4, false, kEpiResidual>(a, mt, nw, st);
+    else if (!ln && epi == kEpiBias && a.K == 1024) launch_gemm_rows_mt<1, false, kEpiBias>(a, mt, nw, st);
+    else if (!ln && epi == kEpiBias && a.K == 4096) launch_gemm_rows_mt<4, false, kEpiBias>(a, mt, nw, st);
+    else throw HipError("launch_gemm_rows: unsupported (ln, epilogue, K) combination");
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
 // residual + LayerNorm rows (one wave per 1024-wide row; statistics via wavefront shuffles)
 __global__ __launch_bounds__(256) void rows_ln_kernel(const float* __restrict__ P, int S,
                                                       const float* __restrict__ bias, float* __restrict__ h,
@@ -264,10 +516,6 @@ void launch_bias_gelu(const float* P, int S, const float* bias, float* act, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// paged KV layout of one layer: [block][K|V][head][token_in_block(16)][64]
-__device__ __forceinline__ long kv_offset(int blk, int kv, int head, int tok) {
-    return (((long)blk * 2 + kv) * kHeads + head) * (kKvBlockTokens * kHeadDim) + (long)tok * kHeadDim;
-}
 
 __global__ __launch_bounds__(256) void qkv_epilogue_kernel(const float* __restrict__ P, int S,
                                                            const float* __restrict__ bias, float* __restrict__ qbuf,
@@ -565,6 +813,42 @@ void launch_final_norm(const float* xn, const int* sample_row, const int* sample
     trace_launch("final_norm_kernel");
     hipLaunchKernelGGL(final_norm_kernel, dim3((Ms + 3) / 4), dim3(256), 0, st, xn, sample_row, sample_slot, gamma, beta,
                        ybuf, latents, lat_slot_stride, slot_ngen, max_lat_rows, Ms, eps);
+    HIP_CHECK(hipGetLastError());
+}
+
+// decode tail of the gemm_rows chain: the last block's residual add leaves h; ln_f and both final_norms run here
+__global__ __launch_bounds__(256) void final_rows_kernel(const float* __restrict__ h, const int* __restrict__ sample_slot,
+                                                         const float* __restrict__ lnf_w, const float* __restrict__ lnf_b,
+                                                         const float* __restrict__ fn_w, const float* __restrict__ fn_b,
+                                                         float* __restrict__ ybuf, float* __restrict__ latents,
+                                                         long lat_slot_stride, const int* __restrict__ slot_ngen,
+                                                         int max_lat_rows, int Ms, float eps) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= Ms) return;
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(h + (long)j * kHidden + 4 * (lane + 64 * u));
+    ln_wave(v, lnf_w, lnf_b, lane, eps);
+    ln_wave(v, fn_w, fn_b, lane, eps);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(ybuf + (long)j * kHidden + 4 * (lane + 64 * u)) = v[u];
+    const int slot = sample_slot[j];
+    const int idx = slot_ngen[slot];
+    if (latents && idx < max_lat_rows) {
+        ln_wave(v, fn_w, fn_b, lane, eps);
+        float* dst = latents + (long)slot * lat_slot_stride + (long)idx * kHidden;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(dst + 4 * (lane + 64 * u)) = v[u];
+    }
+}
+
+void launch_final_rows(const float* h, const int* sample_slot, const float* lnf_w, const float* lnf_b, const float* fn_w,
+                       const float* fn_b, float* ybuf, float* latents, long lat_slot_stride, const int* slot_ngen,
+                       int max_lat_rows, int Ms, float eps, hipStream_t st) {
+    trace_launch("final_rows_kernel");
+    hipLaunchKernelGGL(final_rows_kernel, dim3((Ms + 3) / 4), dim3(256), 0, st, h, sample_slot, lnf_w, lnf_b, fn_w, fn_b, ybuf,
+                       latents, lat_slot_stride, slot_ngen, max_lat_rows, Ms, eps);
     HIP_CHECK(hipGetLastError());
 }
 

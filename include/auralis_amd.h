@@ -153,6 +153,12 @@ int aur_reset_stats(aur_engine* e);
 /* out[M][N] = X[M][K] @ W[K][N] via the split-K MFMA kernel + slab sum (kw = 0 picks the default). */
 int aur_dbg_gemm(aur_engine* e, const float* X, const float* W, float* out, int32_t M, int32_t N, int32_t K,
                  int32_t kw);
+/* Decode-regime GEMM (gemm_rows_kernel: full-K workgroups, fused LayerNorm prologue and bias / gelu / residual epilogue;
+ * replaces one GPT2Block linear of vLLM's GPT2Attention / GPT2MLP at M = live sequences, vllm_mm_gpt.py:757-761):
+ * out[M][N] = epi(LN?(X[M][K]) @ W[K][N] + bias), epi 0 = bias, 1 = bias + gelu_new, 2 = out += (.. + bias).
+ * ln != 0 applies LayerNorm(gamma, beta, eps 1e-5) to the rows of X first (K must be 1024).  K in {1024, 4096}. */
+int aur_dbg_gemm_rows(aur_engine* e, const float* X, const float* W, const float* bias, const float* gamma,
+                      const float* beta, float* out, int32_t M, int32_t N, int32_t K, int32_t epi, int32_t ln);
 /* Host-side evaluation of the GEMM kernel's workgroup -> (column tile, K-slice, M-tile) map for a (gx, gy, gz) grid
  * (gpt_kernels.h gemm_tile_map; needs no GPU): out3[3*L + {0,1,2}] for L in [0, gx*gy*gz).  Lets the CPU tests check
  * that every tile order in use is a bijection. */

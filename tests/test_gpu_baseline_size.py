@@ -1,0 +1,79 @@
+"""GPU: parity at the size of BASELINE.json configs[1] (C2) and configs[2] (C3), on the engine configuration bench.py
+times (30 layers, 64 slots, fp16-input vocoder MFMA, latent stash, pipelined decode).
+
+Goldens: tests/golden/c2_L30_T280.npz and c3_L30_T280.npz, produced in the build container by oracle/make_golden_c2.py
+(CPU fp32 restatement of the reference path XTTSv2.py:762-814: AR tokens -> literal second pass -> HiFi-GAN).
+Contract (north_star): greedy mel-token ids bit-exact; waveform within 1e-3 RMS (and, because the synthetic vocoder is
+quiet, within 1 % of the signal RMS).  A mismatch reports the oracle's margin at the first differing step.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.gpu_util import SPK_KEY, make_engine, rms
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SAMPLING = dict(temperature=0.75, top_p=0.85, top_k=50, repetition_penalty=5.0)
+
+
+@pytest.fixture(scope="module")
+def bench_engine():
+    """The bench configuration (bench.py: NativeEngine(n_layer=30, max_seqs=64, vocoder_fp16=True)); latents are copied out
+    in addition so that the test can compare them."""
+    e, *_ = make_engine(30, max_seqs=64, vocoder_fp16=True, return_latents=True)
+    yield e
+    e.close()
+
+
+def _first_diff(a, b):
+    n = min(len(a), len(b))
+    for i in range(n):
+        if a[i] != b[i]:
+            return i
+    return None if len(a) == len(b) else n
+
+
+def test_c2_greedy_200char_bit_exact_and_waveform(bench_engine):
+    """C2: one 200-char utterance (70 text ids), greedy, 280 tokens at 30 layers: ids bit-exact, stash latents equal to the
+    oracle's literal second pass, waveform <= 1e-3 RMS and <= 1 % of signal."""
+    g = np.load(os.path.join(GOLD, "c2_L30_T280.npz"))
+    e = bench_engine
+    e.submit(g["text_ids"].tolist(), SPK_KEY, temperature=0.0, max_tokens=280, ignore_stop=True)
+    got = e.run_until_done()[0]
+    ref = g["tokens"].tolist()
+    d = _first_diff(got["tokens"].tolist(), ref)
+    assert d is None, (f"first differing step {d}: got {int(got['tokens'][d])} want {ref[d]}; oracle top-2 margin there "
+                       f"{float(g['margins'][d]):.3e} (min over the run {float(g['margins'].min()):.3e})")
+    assert got["latents"].shape == g["latents"].shape
+    lat_err = float(np.abs(got["latents"] - g["latents"]).max())
+    assert lat_err < 5e-3, lat_err          # unit-variance rows; decode-time stash vs literal second pass (XTTSv2.py:617-687)
+    wav = g["wav"]
+    assert got["wav"].shape == wav.shape == (312064,)
+    err, sig = rms(got["wav"] - wav), rms(wav)
+    assert err <= 1e-3 and err <= 1e-2 * sig, (err, sig)
+
+
+def test_c3_64_way_sampled_equals_oracle_and_solo(bench_engine):
+    """C3: 64 concurrent sampled sequences (T 0.75 / top_p 0.85 / top_k 50 / rep-pen 5.0, seeds 0..63) on the 64-slot
+    engine.  Seeds 0..7 equal the oracle's ids under the shared counter-hash noise for all 280 steps; every sequence
+    equals its own solo run bit for bit (ids and waveform)."""
+    g = np.load(os.path.join(GOLD, "c3_L30_T280.npz"))
+    e = bench_engine
+    ids = g["text_ids"].tolist()
+    T = int(g["tokens"].shape[1])
+    sid = {e.submit(ids, SPK_KEY, max_tokens=T, seed=s, ignore_stop=True, **SAMPLING): s for s in range(64)}
+    batch = {sid[o["seq_id"]]: o for o in e.run_until_done()}
+    assert len(batch) == 64
+    for k, s in enumerate(g["seeds"].tolist()):
+        ref = g["tokens"][k].tolist()
+        d = _first_diff(batch[s]["tokens"].tolist(), ref)
+        assert d is None, (f"seed {s}: first differing step {d}: got {int(batch[s]['tokens'][d])} want {ref[d]}; oracle race "
+                           f"ratio there {float(g['race_ratio'][k][d]):.6f}")
+    for s in range(64):
+        e.submit(ids, SPK_KEY, max_tokens=T, seed=s, ignore_stop=True, **SAMPLING)
+        solo = e.run_until_done()[0]
+        assert solo["tokens"].tolist() == batch[s]["tokens"].tolist(), s
+        assert np.array_equal(solo["wav"], batch[s]["wav"]), s

@@ -42,6 +42,50 @@ def test_gemm_is_batch_invariant_bitwise(eng):
     assert np.array_equal(big[:50], small)
 
 
+def _gelu_new(x):
+    return 0.5 * x * (1.0 + np.tanh(np.sqrt(2.0 / np.pi) * (x + 0.044715 * x ** 3)))
+
+
+# decode-regime GEMM (gemm_rows_kernel): M picks the rows-per-workgroup variant (16 / 32 / 64 rows), N the tile map
+# (N / 16 multiple of 8 or not), K = 4096 the two-buffer chunk loop; epi 0 bias, 1 bias + gelu, 2 residual
+@pytest.mark.parametrize("M,N,K,epi,ln", [(64, 3072, 1024, 0, True), (64, 4096, 1024, 1, True), (64, 1024, 1024, 2, False),
+                                          (64, 1024, 4096, 2, False), (64, 1088, 1024, 0, False), (1, 4096, 1024, 1, True),
+                                          (17, 1024, 4096, 2, False), (37, 3072, 1024, 0, True), (5, 1088, 1024, 0, False),
+                                          (130, 4096, 1024, 1, True), (200, 1024, 4096, 0, False), (48, 1024, 1024, 2, False)])
+def test_gemm_rows(eng, M, N, K, epi, ln):
+    g = torch.Generator().manual_seed(M * 11 + N + K + epi)
+    X = torch.randn(M, K, generator=g) * (3.0 if ln else 1.0) + (0.5 if ln else 0.0)
+    W = torch.randn(K, N, generator=g) * 0.05
+    bias = torch.randn(N, generator=g)
+    gamma = torch.randn(K, generator=g) if ln else None
+    beta = torch.randn(K, generator=g) if ln else None
+    res = torch.randn(M, N, generator=g) if epi == 2 else None
+    A = F.layer_norm(X, (K,), gamma, beta, 1e-5) if ln else X
+    ref = (A.double() @ W.double() + bias.double()).numpy()
+    if epi == 1:
+        ref = _gelu_new(ref)
+    if epi == 2:
+        ref = ref + res.double().numpy()
+    got = eng.dbg_gemm_rows(X.numpy(), W.numpy(), bias.numpy(), None if gamma is None else gamma.numpy(),
+                            None if beta is None else beta.numpy(), None if res is None else res.numpy(), epi)
+    err = np.abs(got - ref).max()
+    assert err < 2e-4 * max(1.0, np.abs(ref).max()), err
+
+
+def test_gemm_rows_is_batch_invariant_bitwise(eng):
+    """A row's result does not depend on how many other rows are live (16-, 32- and 64-row workgroup variants, row groups)."""
+    g = torch.Generator().manual_seed(5)
+    for K, N, ln in ((1024, 4096, True), (4096, 1024, False), (1024, 1024, False)):
+        X = torch.randn(150, K, generator=g)
+        W = torch.randn(K, N, generator=g) * 0.05
+        gamma = torch.randn(K, generator=g).numpy() if ln else None
+        beta = torch.randn(K, generator=g).numpy() if ln else None
+        full = eng.dbg_gemm_rows(X.numpy(), W.numpy(), None, gamma, beta, None, 0)
+        for m in (1, 16, 17, 33, 64, 100):
+            part = eng.dbg_gemm_rows(X[:m].numpy(), W.numpy(), None, gamma, beta, None, 0)
+            assert np.array_equal(full[:m], part), (K, N, m)
+
+
 def test_layernorm(eng):
     g = torch.Generator().manual_seed(0)
     h = torch.randn(37, 1024, generator=g) * 3 + 0.5
