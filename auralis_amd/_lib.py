@@ -60,7 +60,7 @@ class aur_stats(C.Structure):
 # every symbol include/auralis_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "aur_last_error", "aur_version", "aur_engine_create", "aur_engine_destroy", "aur_load_weights",
-    "aur_set_conditioning", "aur_set_conditioning_device", "aur_submit", "aur_step", "aur_poll_finished",
+    "aur_set_conditioning", "aur_set_conditioning_device", "aur_has_conditioning", "aur_submit", "aur_step", "aur_poll_finished",
     "aur_release", "aur_vocode", "aur_sync", "aur_get_stats", "aur_reset_stats", "aur_dbg_gemm", "aur_dbg_gemm_rows",
     "aur_dbg_gemm_tile_map", "aur_dbg_layernorm", "aur_dbg_conv1d", "aur_dbg_conv1d_f16", "aur_dbg_prefill", "aur_dbg_sample",
 ]
@@ -93,6 +93,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "aur_load_weights": [eng, C.POINTER(aur_tensor_desc), C.c_size_t],
         "aur_set_conditioning": [eng, C.c_uint64, fp, fp],
         "aur_set_conditioning_device": [eng, C.c_uint64, C.c_void_p, C.c_void_p],
+        "aur_has_conditioning": [eng, C.c_uint64, ip],
         "aur_submit": [eng, C.POINTER(aur_seq_desc), C.POINTER(C.c_uint64)],
         "aur_step": [eng, ip, ip],
         "aur_poll_finished": [eng, C.POINTER(aur_result), C.c_size_t, C.POINTER(C.c_size_t)],
@@ -187,6 +188,11 @@ class NativeEngine:
         s = _f32(np.asarray(speaker_embedding).reshape(512))
         self._check(self.lib.aur_set_conditioning(self.h, key, _fp(g), _fp(s)))
 
+    def has_conditioning(self, key: int) -> bool:
+        out = C.c_int32()
+        self._check(self.lib.aur_has_conditioning(self.h, key, C.byref(out)))
+        return bool(out.value)
+
     def set_conditioning_device(self, key: int, d_gpt_cond_ptr: int, d_spk_ptr: int):
         self._check(self.lib.aur_set_conditioning_device(self.h, key, C.c_void_p(d_gpt_cond_ptr), C.c_void_p(d_spk_ptr)))
 
@@ -215,8 +221,10 @@ class NativeEngine:
             r = res[i]
             item = {
                 "seq_id": r.seq_id,
-                "tokens": np.ctypeslib.as_array(r.tokens, shape=(r.n_tokens,)).copy(),
-                "wav": np.ctypeslib.as_array(r.wav, shape=(r.n_samples,)).copy(),
+                "tokens": (np.ctypeslib.as_array(r.tokens, shape=(r.n_tokens,)).copy() if r.n_tokens
+                           else np.zeros(0, dtype=np.int32)),
+                "wav": (np.ctypeslib.as_array(r.wav, shape=(r.n_samples,)).copy() if r.n_samples
+                        else np.zeros(0, dtype=np.float32)),   # failed sequences carry no audio (error != 0)
                 "error": r.error,
             }
             if want_latents and r.n_latent_rows:

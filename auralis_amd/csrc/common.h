@@ -12,7 +12,14 @@ namespace aur {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct HipError : std::runtime_error {
+// Typed failures: the C ABI maps the exception TYPE (not the message) to its AUR_E_* code.
+struct HipError : std::runtime_error {          // HIP runtime / kernel failure            -> AUR_E_HIP
+    using std::runtime_error::runtime_error;
+};
+struct InvalidArgument : std::runtime_error {   // bad argument, unknown id, shape mismatch -> AUR_E_INVALID
+    using std::runtime_error::runtime_error;
+};
+struct StateError : std::runtime_error {        // call not valid in the current state      -> AUR_E_STATE
     using std::runtime_error::runtime_error;
 };
 
@@ -26,7 +33,7 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
 #define HIP_CHECK(x) ::aur::hip_check((x), #x, __FILE__, __LINE__)
 #define AUR_REQUIRE(cond, msg)                                                          \
     do {                                                                                \
-        if (!(cond)) throw ::aur::HipError(std::string("requirement failed: ") + (msg)); \
+        if (!(cond)) throw ::aur::InvalidArgument(std::string("requirement failed: ") + (msg)); \
     } while (0)
 
 // AUR_DEBUG_SYNC=1: print each launch before it is issued and synchronise after it (fault localisation).

@@ -209,6 +209,7 @@ public:
         if (const char* e = getenv("AUR_SAMPLER_FULL_SORT")) sampler_full_sort_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_FUSE_GELU")) fuse_gelu_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_DECODE_GEMM")) rows_gemm_ = std::string(e) != "splitk";
+        if (const char* e = getenv("AUR_TEST_FAIL_STEP")) fail_at_step_ = atoi(e);
 
         for (int i = 0; i < 2; ++i) {
             HIP_CHECK(hipEventCreateWithFlags(&ev_rb_[i], hipEventDisableTiming));
@@ -252,6 +253,8 @@ public:
     // ------------------------------------------------------------------ weights
     void load(const aur_tensor_desc* t, size_t n) {
         use();
+        std::lock_guard<std::mutex> gl(gpu_mu_);   // not while a step is running
+        std::lock_guard<std::mutex> lk(mu_);       // submit() reads the table sizes under mu_
         for (size_t i = 0; i < n; ++i) {
             AUR_REQUIRE(t[i].name && t[i].data && t[i].numel > 0, "bad tensor desc");
             Tensor& dst = w_[t[i].name];
@@ -265,22 +268,50 @@ public:
     }
     const float* W(const std::string& name, int64_t numel = -1) const {
         auto it = w_.find(name);
-        if (it == w_.end()) throw HipError("weight not loaded: " + name);
+        if (it == w_.end()) throw StateError("weight not loaded: " + name);
         if (numel >= 0 && it->second.numel != numel)
-            throw HipError("weight " + name + " has " + std::to_string(it->second.numel) + " elements, expected " +
-                           std::to_string(numel));
+            throw InvalidArgument("weight " + name + " has " + std::to_string(it->second.numel) + " elements, expected " +
+                                  std::to_string(numel));
         return it->second.d();
     }
 
     // ------------------------------------------------------------------ conditioning
+    // Speaker table (caller holds mu_).  A row is pinned while any sequence submitted with it has not been delivered yet
+    // (refs: aur_submit .. end of its vocoder batch, or its failure).  When the table is full the least recently used
+    // unpinned voice is evicted; its two shared prefix KV blocks stay with the row and are overwritten by the newcomer.
     int speaker_row(uint64_t key, bool create) {
         auto it = spk_rows_.find(key);
-        if (it != spk_rows_.end()) return it->second;
+        if (it != spk_rows_.end()) {
+            spk_info_[it->second].last_use = ++spk_clock_;
+            return it->second;
+        }
         if (!create) return -1;
-        AUR_REQUIRE((int)spk_rows_.size() < cfg_.max_speakers, "speaker table full");
-        const int row = (int)spk_rows_.size();
+        int row = -1;
+        if ((int)spk_rows_.size() < cfg_.max_speakers) {
+            std::vector<char> used(cfg_.max_speakers, 0);
+            for (auto& kv : spk_rows_) used[kv.second] = 1;
+            for (int r = 0; r < cfg_.max_speakers && row < 0; ++r)
+                if (!used[r]) row = r;
+        } else {
+            uint64_t victim = 0;
+            for (auto& kv : spk_rows_) {
+                const SpeakerInfo& si = spk_info_[kv.second];
+                if (si.refs == 0 && (row < 0 || si.last_use < spk_info_[row].last_use)) {
+                    row = kv.second;
+                    victim = kv.first;
+                }
+            }
+            if (row < 0) throw StateError("speaker table full: every registered voice has undelivered sequences (raise aur_config.max_speakers)");
+            spk_rows_.erase(victim);
+            spk_info_[row].ready = false;
+        }
         spk_rows_[key] = row;
+        spk_info_[row].last_use = ++spk_clock_;
         return row;
+    }
+    bool has_conditioning(uint64_t key) {
+        std::lock_guard<std::mutex> lk(mu_);
+        return speaker_row(key, false) >= 0;
     }
     void set_conditioning(uint64_t key, const float* gpt_cond, const float* spk, bool device_ptrs) {
         std::lock_guard<std::mutex> gl(gpu_mu_);   // may be called while the driver thread is inside aur_step
@@ -289,7 +320,8 @@ public:
         {
             std::lock_guard<std::mutex> lk(mu_);
             row = speaker_row(key, true);
-            AUR_REQUIRE(spk_info_[row].live == 0, "speaker is in use by live sequences: register the new voice under a new key");
+            if (spk_info_[row].refs != 0)
+                throw StateError("speaker is in use by undelivered sequences: register the new voice under a new key");
         }
         const hipMemcpyKind kind = device_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
         HIP_CHECK(hipMemcpyAsync(spk_table_.as<float>() + (long)row * 32 * kHidden, gpt_cond,
@@ -358,16 +390,17 @@ public:
         AUR_REQUIRE(n_prompt + d.max_tokens + 4 <= kMaxBlocks * kKvBlockTokens, "prompt + max_tokens exceeds max_model_len");
         AUR_REQUIRE(n_prompt <= cfg_.max_prefill_rows, "prompt longer than max_prefill_rows");
         AUR_REQUIRE(d.repetition_penalty > 0.f, "repetition_penalty > 0");
+        std::lock_guard<std::mutex> lk(mu_);
         {   // reject bad text ids / positions here, not in the middle of a batched prefill
             auto te = w_.find("text_emb"), tp = w_.find("text_pos");
-            AUR_REQUIRE(te != w_.end() && tp != w_.end(), "weights not loaded");
+            if (te == w_.end() || tp == w_.end()) throw StateError("weights not loaded");
             const int vocab = (int)(te->second.numel / kHidden), npos = (int)(tp->second.numel / kHidden);
             AUR_REQUIRE(d.n_text <= npos, "text longer than the text position table");
             for (int i = 0; i < d.n_text; ++i) AUR_REQUIRE(d.text_ids[i] >= 0 && d.text_ids[i] < vocab, "text id out of range");
         }
-        std::lock_guard<std::mutex> lk(mu_);
         const int row = speaker_row(d.speaker_key, false);
         AUR_REQUIRE(row >= 0, "unknown speaker_key (call aur_set_conditioning first)");
+        spk_info_[row].refs++;
         auto s = std::make_unique<Seq>();
         s->id = next_id_++;
         s->text_ids.assign(d.text_ids, d.text_ids + d.n_text);
@@ -409,10 +442,69 @@ public:
     }
 
     // ------------------------------------------------------------------ one scheduler iteration
+    // A failure inside a step (HIP error, exhausted pool) must not leave slots, KV blocks and pool entries half-updated:
+    // every sequence that was in flight is failed (aur_result.error), its resources go back to the pools, and the
+    // exception continues to the caller.  The engine stays usable if the device is.
     void step(int* n_live, int* n_finished_total) {
         std::lock_guard<std::mutex> gl(gpu_mu_);
+        try {
+            step_locked(n_live, n_finished_total);
+        } catch (const InvalidArgument&) {
+            fail_in_flight(AUR_E_INVALID);
+            throw;
+        } catch (const StateError&) {
+            fail_in_flight(AUR_E_STATE);
+            throw;
+        } catch (...) {
+            fail_in_flight(AUR_E_HIP);
+            throw;
+        }
+    }
+    void fail_in_flight(int code) {
+        (void)hipStreamSynchronize(st_);
+        (void)hipStreamSynchronize(st_voc_);
+        (void)hipGetLastError();
+        infl_.on = false;
+        just_finished_.clear();
+        graph_active_.clear();
+        n_gemm_events_ = 0;
+        n_conv_events_ = 0;
+        gemm_prof_now_ = false;
+        voc_timed_ = false;
+        std::lock_guard<std::mutex> lk(mu_);
+        auto fail = [&](Seq* s) {
+            for (int b : s->blocks) free_blocks_.push_back(b);
+            s->blocks.clear();
+            if (s->pool_idx >= 0) latpool_free_.push_back(s->pool_idx);
+            s->pool_idx = -1;
+            if (s->slot >= 0) slot_owner_[s->slot] = nullptr;
+            s->slot = -1;
+            s->error = code;
+            s->wav = nullptr; s->n_samples = 0; s->latents = nullptr; s->n_latent_rows = 0;
+            spk_info_[s->spk_row].refs--;
+            s->state = SeqState::DONE;
+            done_.push_back(s);
+            finished_total_++;
+        };
+        for (Seq* s : slot_owner_)
+            if (s) fail(s);
+        for (Seq* s : voc_queue_) fail(s);
+        voc_queue_.clear();
+        if (voc_active_) {
+            for (Seq* s : voc_batch_)
+                if (s->state != SeqState::DONE) fail(s);
+            if (voc_block_) voc_block_->refs--;
+        }
+        voc_batch_.clear();
+        voc_active_ = false;
+    }
+    void step_locked(int* n_live, int* n_finished_total) {
         use();
         ensure_gpt();
+        if (fail_at_step_ > 0 && --fail_at_step_ == 0) {   // AUR_TEST_FAIL_STEP=n: fault injection for the recovery test
+            std::vector<Seq*> dummy;
+            throw HipError("injected failure (AUR_TEST_FAIL_STEP)");
+        }
         bool worked = false;
         // back-pressure: every running sequence must be able to park its latents when it finishes
         while ((int)latpool_free_.size() < cfg_.max_seqs) {
@@ -446,7 +538,6 @@ public:
                 waiting_.pop_front();
                 s->slot = slot;
                 slot_owner_[slot] = s;
-                spk_info_[s->spk_row].live++;
                 for (int b = 0; b < skip; ++b) h_block_tables_[(size_t)slot * kMaxBlocks + b] = si.blocks[b];
                 for (int b = 0; b < need; ++b) {
                     s->blocks.push_back(free_blocks_.back());
@@ -1078,7 +1169,7 @@ private:
         forward_rows(w, M, w.i_row_slot.as<int>(), w.i_row_pos.as<int>());
         for (size_t k = 0; k < seqs.size(); ++k) {
             Seq* s = seqs[k];
-            if (latpool_free_.empty()) throw HipError("latent pool exhausted");
+            if (latpool_free_.empty()) throw StateError("latent pool exhausted");
             s->pool_idx = latpool_free_.back();
             latpool_free_.pop_back();
             launch_double_norm_rows(w.xn.as<float>() + (long)lat_row0[k] * kHidden,
@@ -1093,7 +1184,7 @@ private:
         // park the stashed latents in the pool (D2D on the main stream, ordered before any later prefill that reuses
         // the slot) and release slot + KV blocks at once: the vocoder stage no longer occupies a batcher slot
         if (s->pool_idx < 0) {   // (the second-pass mode has already written the pool entry)
-            if (latpool_free_.empty()) throw HipError("latent pool exhausted");
+            if (latpool_free_.empty()) throw StateError("latent pool exhausted");
             s->pool_idx = latpool_free_.back();
             latpool_free_.pop_back();
             const size_t n = s->tokens.size() * (size_t)kHidden * sizeof(float);
@@ -1104,7 +1195,6 @@ private:
         std::lock_guard<std::mutex> lk(mu_);
         for (int b : s->blocks) free_blocks_.push_back(b);
         s->blocks.clear();
-        spk_info_[s->spk_row].live--;
         slot_owner_[s->slot] = nullptr;
         s->slot = -1;
         voc_queue_.push_back(s);
@@ -1596,6 +1686,7 @@ private:
             voc_block_->refs++;
             latpool_free_.push_back(s->pool_idx);
             s->pool_idx = -1;
+            spk_info_[s->spk_row].refs--;
             s->state = SeqState::DONE;
             done_.push_back(s);
             finished_total_++;
@@ -1618,6 +1709,7 @@ private:
     std::vector<LayerW> layers_;
     std::vector<std::unique_ptr<DevBuf>> packed_;   // pack_wt16 copies (decode GEMM layout)
     const float* thead_ = nullptr;
+    int fail_at_step_ = 0;              // AUR_TEST_FAIL_STEP=n: throw inside the n-th aur_step (recovery test)
     bool rows_gemm_ = true;             // AUR_DECODE_GEMM=splitk selects the round-1 decode chain
     const float *wte_ = nullptr, *wpe_ = nullptr, *lnfw_ = nullptr, *lnfb_ = nullptr, *fnw_ = nullptr, *fnb_ = nullptr,
                 *headT_ = nullptr, *headb_ = nullptr, *text_emb_ = nullptr, *text_pos_ = nullptr;
@@ -1635,8 +1727,10 @@ private:
     struct SpeakerInfo {
         int blocks[2] = {-1, -1};
         bool ready = false;
-        int live = 0;
+        int refs = 0;             // sequences submitted with this voice and not delivered yet
+        uint64_t last_use = 0;    // LRU clock
     };
+    uint64_t spk_clock_ = 0;
     std::vector<SpeakerInfo> spk_info_;
     bool share_prefix_ = true;        // AUR_SHARE_PREFIX=0 disables
     bool share_prefix_now_ = true;    // dbg_prefill turns it off to return every prompt row
@@ -1713,16 +1807,21 @@ static int guarded(F&& f) {
     try {
         f();
         return AUR_OK;
+    } catch (const aur::InvalidArgument& e) {
+        aur::g_last_error = e.what();
+        return AUR_E_INVALID;
+    } catch (const aur::StateError& e) {
+        aur::g_last_error = e.what();
+        return AUR_E_STATE;
     } catch (const aur::HipError& e) {
         aur::g_last_error = e.what();
-        const std::string m = e.what();
-        return (m.rfind("requirement failed", 0) == 0 || m.rfind("weight", 0) == 0) ? AUR_E_INVALID : AUR_E_HIP;
+        return AUR_E_HIP;
     } catch (const std::bad_alloc&) {
         aur::g_last_error = "out of host memory";
         return AUR_E_NOMEM;
     } catch (const std::exception& e) {
         aur::g_last_error = e.what();
-        return AUR_E_INVALID;
+        return AUR_E_HIP;
     }
 }
 #define CHECK_PTR(p)                                    \
@@ -1743,7 +1842,7 @@ int aur_engine_create(const aur_config* cfg, int device_id, aur_engine** out) {
     return guarded([&] {
         int n = 0;
         if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
-            throw aur::HipError("no HIP device visible: the MI355X path has no CPU fallback");
+            throw aur::StateError("no HIP device visible: the MI355X path has no CPU fallback");
         AUR_REQUIRE(device_id >= 0 && device_id < n, "device_id out of range");
         *out = new aur_engine(*cfg, device_id);
     });
@@ -1768,6 +1867,11 @@ int aur_set_conditioning_device(aur_engine* e, uint64_t key, const float* d_gpt_
     CHECK_PTR(d_gpt_cond);
     CHECK_PTR(d_spk);
     return guarded([&] { e->impl.set_conditioning(key, d_gpt_cond, d_spk, true); });
+}
+int aur_has_conditioning(aur_engine* e, uint64_t key, int32_t* out) {
+    CHECK_PTR(e);
+    CHECK_PTR(out);
+    return guarded([&] { *out = e->impl.has_conditioning(key) ? 1 : 0; });
 }
 int aur_submit(aur_engine* e, const aur_seq_desc* seq, uint64_t* seq_id) {
     CHECK_PTR(e);

@@ -101,6 +101,7 @@ struct GemmRowsArgs {
     const int* slot_kvpos;
     const int* block_tables;
     int max_blocks;
+    long long* prof;     // optional (tools/gemm_bench): 8 s_memtime stamps per workgroup, written by wave 0
 };
 void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream_t st);
 // Wt = pack_wt16(W), W row-major [K][ldw], N % 16 == 0, K % 16 == 0

@@ -266,10 +266,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) af[buf][mt][b] = *reinterpret_cast<const f32x4*>(xr[mt] + 16 * (kb0 + b));
     };
+    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 0] = (long long)__builtin_amdgcn_s_memtime();
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     load_chunk(0, 0);
+    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 1] = (long long)__builtin_amdgcn_s_memtime();
     if (LN) {
         // gamma / beta go through LDS (8 KB, staged by the first 8 waves): holding this lane's values in registers next to
         // the A registers of a 64-row tile spilled; they become visible with the barriers of the statistics passes
@@ -327,6 +329,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
                 for (int s = 0; s < 4; ++s) af[0][mt][b][s] = (af[0][mt][b][s] - mean[mt]) * rstd[mt] * gam[s] + bet[s];
         }
     }
+    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 2] = (long long)__builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int c = 0; c < KCH; ++c) {
         const int cur = (KCH > 1) ? (c & 1) : 0;
@@ -345,7 +348,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[w][mt * 256 + r * 64 + lane] = acc[mt][r];
+    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 3] = (long long)__builtin_amdgcn_s_memtime();
     __syncthreads();
+    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 4] = (long long)__builtin_amdgcn_s_memtime();
     for (int e = tid; e < MT * 256; e += 64 * NW) {
         float t = red[0][e];
 #pragma unroll
@@ -374,6 +379,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
             }
         }
     }
+    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 5] = (long long)__builtin_amdgcn_s_memtime();
 }
 
 // Workgroup shapes in use.  16 waves (K-slice 64 per wave, <= 128 VGPRs per lane) everywhere except the 64-row tiles with
@@ -440,7 +446,7 @@ void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream
     else if (!ln && epi == kEpiResidual && a.K == 4096) launch_gemm_rows_mt<4, false, kEpiResidual>(a, mt, nw, st);
     else if (!ln && epi == kEpiBias && a.K == 1024) launch_gemm_rows_mt<1, false, kEpiBias>(a, mt, nw, st);
     else if (!ln && epi == kEpiBias && a.K == 4096) launch_gemm_rows_mt<4, false, kEpiBias>(a, mt, nw, st);
-    else throw HipError("launch_gemm_rows: unsupported (ln, epilogue, K) combination");
+    else throw InvalidArgument("launch_gemm_rows: unsupported (ln, epilogue, K) combination");
     HIP_CHECK(hipGetLastError());
 }
 

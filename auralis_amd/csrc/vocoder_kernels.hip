@@ -300,7 +300,7 @@ void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
         case 11 * 16 + 1: launch_conv_mt<11, 1, 4>(a, st); break;
         case 11 * 16 + 3: launch_conv_mt<11, 3, 4>(a, st); break;
         case 11 * 16 + 5: launch_conv_mt<11, 5, 4>(a, st); break;
-        default: throw HipError("launch_conv1d: unsupported (kernel,dilation)");
+        default: throw InvalidArgument("launch_conv1d: unsupported (kernel,dilation)");
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -463,7 +463,7 @@ void launch_conv1d_f16(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
             case 3 * 16 + 1: launch_conv_f16_t<3, 1, true>(a, st); break;
             case 7 * 16 + 1: launch_conv_f16_t<7, 1, true>(a, st); break;
             case 11 * 16 + 1: launch_conv_f16_t<11, 1, true>(a, st); break;
-            default: throw HipError("launch_conv1d_f16: fp16 input only for k in {3,7,11}, dilation 1");
+            default: throw InvalidArgument("launch_conv1d_f16: fp16 input only for k in {3,7,11}, dilation 1");
         }
         HIP_CHECK(hipGetLastError());
         return;
@@ -479,7 +479,7 @@ void launch_conv1d_f16(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
         case 11 * 16 + 1: launch_conv_f16_t<11, 1, false>(a, st); break;
         case 11 * 16 + 3: launch_conv_f16_t<11, 3, false>(a, st); break;
         case 11 * 16 + 5: launch_conv_f16_t<11, 5, false>(a, st); break;
-        default: throw HipError("launch_conv1d_f16: unsupported (kernel,dilation)");
+        default: throw InvalidArgument("launch_conv1d_f16: unsupported (kernel,dilation)");
     }
     HIP_CHECK(hipGetLastError());
 }

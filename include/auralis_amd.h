@@ -128,6 +128,12 @@ int aur_set_conditioning(aur_engine* e, uint64_t speaker_key, const float* gpt_c
 int aur_set_conditioning_device(aur_engine* e, uint64_t speaker_key, const float* d_gpt_cond,
                                 const float* d_spk_emb);
 
+/* *out = 1 if speaker_key is registered (and marks it most recently used), else 0.  The table holds
+ * aur_config.max_speakers voices; when it is full, registering a new key evicts the least recently used voice that has
+ * no undelivered sequences (replaces the reference's unbounded per-request conditioning, XTTSv2.py:409-468: callers
+ * re-register an evicted voice). */
+int aur_has_conditioning(aur_engine* e, uint64_t speaker_key, int32_t* out);
+
 /* Queue a sequence (replaces llm_engine.generate, XTTSv2.py:752). */
 int aur_submit(aur_engine* e, const aur_seq_desc* seq, uint64_t* seq_id);
 

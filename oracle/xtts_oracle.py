@@ -14,6 +14,10 @@ Parity pin status
   the reference's own `GPT2Model.forward`, `LearnedPositionEmbeddings` (vllm_mm_gpt.py) and `LogitsRepetitionPenalizer`
   (vllm/hijack.py), executed unmodified in the build container through import stubs (oracle/ref_gpt_import.py,
   oracle/make_golden_gpt.py → tests/golden/gpt_glue_L2.npz, tests/test_reference_gpt_glue.py).
+* Sampler cross-check (not a pin): tests/test_oracle_sampler.py drives the same logits through two independent
+  restatements — transformers' TemperatureLogitsWarper / TopKLogitsWarper / TopPLogitsWarper (the code vLLM's
+  `_apply_top_k_top_p` was derived from) followed by the exponential race, and a numpy re-implementation written from
+  SURVEY Appendix A4 — and requires identical survivor sets and tokens, including explicit tie-group cases.
 * GPT block arithmetic and the sampler: the reference delegates these to the un-vendored third-party dependency
   vllm==0.6.4.post1 (setup.py:63): `GPT2Block` and `Sampler` are not under /root/reference and the reference's tests hold
   no golden vectors for them.  In the fixture above vllm's block is replaced by the textbook GPT-2 block
@@ -102,7 +106,10 @@ def sample_token(logits: Tensor, temperature: float, top_k: int, top_p: float,
         return int(torch.argmax(z).item())
     z = z / temperature
     V = z.shape[0]
-    z_sort, z_idx = z.sort(dim=-1, descending=False)
+    # tie order made explicit (vLLM's torch.sort leaves it to the backend): ascending by (value, id), i.e. a stable sort;
+    # a top-p cut that falls inside a group of equal logits therefore drops the smaller ids first.  The HIP sampler sorts
+    # the packed (value, id) keys and produces the same order (tests/test_oracle_sampler.py, tests/test_gpu_kernels.py)
+    z_sort, z_idx = z.sort(dim=-1, descending=False, stable=True)
     if top_k is not None and 0 < top_k < V:
         thr = z_sort[V - top_k]
         z_sort = z_sort.masked_fill(z_sort < thr, float("-inf"))

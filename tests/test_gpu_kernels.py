@@ -209,6 +209,23 @@ def test_sampler_matches_oracle_with_shared_noise(eng, T, top_k, top_p):
     assert agree == B, (agree, toks)
 
 
+def test_sampler_tie_groups_match_oracle(eng):
+    """Heavily tied logits: the top-k threshold keeps every tie at the k-th value and a top-p cut inside a tie group drops
+    the smaller ids first (ascending (value, id) order, the oracle's stated tie rule; CPU cross-check of that rule against
+    transformers' warpers and a numpy restatement: tests/test_oracle_sampler.py)."""
+    from oracle import xtts_oracle as O
+    g = torch.Generator().manual_seed(123)
+    B = 8
+    tied = torch.round(torch.randn(B, 1026, generator=g) * 2.0) * 0.5          # ~10 distinct values
+    coarse = torch.round(torch.randn(B, 1026, generator=g) * 40.0) / 8.0      # a few ties around the k-th value
+    for name, lg in (("tied", tied), ("coarse", coarse)):
+        for T, k, p in ((0.75, 50, 0.85), (1.0, 64, 0.5), (1.5, 7, 0.3), (0.9, -1, 0.6)):
+            for step in (0, 5):
+                toks = eng.dbg_sample(lg.numpy(), T, p, k, seed=900, step=step)
+                want = [O.sample_token(lg[r], T, k, p, O.exp_noise(900 + r, step, 1026)) for r in range(B)]
+                assert list(toks) == want, (name, T, k, p, step)
+
+
 def test_sampler_distribution_chi2(eng):
     """Exponential-race sampling reproduces softmax(top-k) frequencies (chi-square over 4000 draws)."""
     z = np.full(1026, -30.0, dtype=np.float32)
