@@ -61,6 +61,21 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// 64-lane sum on the DPP network (6 VALU adds + one readlane) instead of 6 dependent ds_bpermute round trips (~100 cycles
+// each): quad swaps, half-row and row mirrors leave every lane of a 16-lane row with the row sum; row_bcast15 / row_bcast31
+// carry it across the four rows into lane 63.  Fixed order => deterministic.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define AUR_DPP_ADD(ctrl, rmask)                                                                                         \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), (rmask), 0xF, false))
+    AUR_DPP_ADD(0xB1, 0xF);    // quad_perm [1,0,3,2]
+    AUR_DPP_ADD(0x4E, 0xF);    // quad_perm [2,3,0,1]
+    AUR_DPP_ADD(0x141, 0xF);   // row_half_mirror
+    AUR_DPP_ADD(0x140, 0xF);   // row_mirror
+    AUR_DPP_ADD(0x142, 0xA);   // row_bcast15 into rows 1 and 3
+    AUR_DPP_ADD(0x143, 0xC);   // row_bcast31 into rows 2 and 3
+#undef AUR_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void init_slots_kernel(const SlotInit* __restr
 struct RowWs {
     hipStream_t st = nullptr;
     int rows_cap = 0;
-    DevBuf h, xn, qbuf, att, act, P, P2, ybuf;
+    DevBuf h, xn, qbuf, att, act, P, P2, ybuf, stats;   // stats: LayerNorm partials of the packed residual stream [rows][64] float2
     DevBuf i_row_slot, i_row_pos, i_desc, i_sample_row, i_sample_slot, i_next_kvpos, i_out_tok;
     PinBuf pin;
     std::vector<int> sample_row, sample_slot;
@@ -687,18 +687,41 @@ public:
         AUR_REQUIRE(epi >= 0 && epi <= 2, "dbg_gemm_rows: epi in {0,1,2}");
         AUR_REQUIRE(!ln || (gamma && beta), "dbg_gemm_rows: LN needs gamma and beta");
         DevBuf dx, dw, dwt, db, dg, dbe, dout;
-        dx.ensure((size_t)M * K * 4);
+        const int mtt = (M + 63) / 64 * 4;                      // 16-row tiles of the packed activation buffers
+        const bool out_packed = (epi == kEpiBiasGelu || epi == kEpiResidual);
+        std::vector<float> hx((size_t)mtt * 16 * K, 0.f), ho((size_t)mtt * 16 * N, 0.f);
+        for (int m = 0; m < M; ++m)
+            for (int k = 0; k < K; ++k) hx[pk_off(m, k, mtt)] = X[(size_t)m * K + k];
+        for (int m = 0; m < M; ++m)
+            for (int n = 0; n < N; ++n) ho[out_packed ? pk_off(m, n, mtt) : (size_t)m * N + n] = out[(size_t)m * N + n];
+        dx.ensure(hx.size() * 4);
         dw.ensure((size_t)K * N * 4);
         dwt.ensure((size_t)K * N * 4);
-        dout.ensure((size_t)M * N * 4);
-        HIP_CHECK(hipMemcpy(dx.p, X, (size_t)M * K * 4, hipMemcpyHostToDevice));
+        dout.ensure(ho.size() * 4);
+        HIP_CHECK(hipMemcpy(dx.p, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(dw.p, Wm, (size_t)K * N * 4, hipMemcpyHostToDevice));
-        HIP_CHECK(hipMemcpy(dout.p, out, (size_t)M * N * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dout.p, ho.data(), ho.size() * 4, hipMemcpyHostToDevice));
         if (bias) {
             db.ensure((size_t)N * 4);
             HIP_CHECK(hipMemcpy(db.p, bias, (size_t)N * 4, hipMemcpyHostToDevice));
         }
+        DevBuf dst;
         if (ln) {
+            // LayerNorm partials per 16-column tile, as the residual-stream producers emit them (GemmRowsArgs)
+            std::vector<float2> hs((size_t)mtt * 16 * 64, make_float2(0.f, 0.f));
+            for (int m = 0; m < M; ++m)
+                for (int t = 0; t < 64; ++t) {
+                    float sm = 0.f, m2 = 0.f;
+                    for (int c = 0; c < 16; ++c) sm += X[(size_t)m * K + 16 * t + c];
+                    const float mu = sm * (1.0f / 16.0f);
+                    for (int c = 0; c < 16; ++c) {
+                        const float d = X[(size_t)m * K + 16 * t + c] - mu;
+                        m2 += d * d;
+                    }
+                    hs[(size_t)m * 64 + t] = make_float2(mu, m2);
+                }
+            dst.ensure(hs.size() * sizeof(float2));
+            HIP_CHECK(hipMemcpy(dst.p, hs.data(), hs.size() * sizeof(float2), hipMemcpyHostToDevice));
             dg.ensure((size_t)K * 4);
             dbe.ensure((size_t)K * 4);
             HIP_CHECK(hipMemcpy(dg.p, gamma, (size_t)K * 4, hipMemcpyHostToDevice));
@@ -706,13 +729,16 @@ public:
         }
         launch_pack_wt16(dw.as<float>(), N, dwt.as<float>(), K, N, st_);
         GemmRowsArgs a{};
-        a.X = dx.as<float>(); a.ldx = K; a.Wt = dwt.as<float>(); a.M = M; a.N = N; a.K = K;
+        a.X = dx.as<float>(); a.xmt = mtt; a.Wt = dwt.as<float>(); a.M = M; a.N = N; a.K = K;
         a.bias = bias ? db.as<float>() : nullptr;
         a.gamma = ln ? dg.as<float>() : nullptr; a.beta = ln ? dbe.as<float>() : nullptr; a.eps = 1e-5f;
-        a.out = dout.as<float>(); a.ldo = N;
+        a.stats_in = ln ? dst.as<float2>() : nullptr;
+        a.out = dout.as<float>(); a.ldo = N; a.omt = mtt;
         launch_gemm_rows(a, ln, (GemmRowsEpi)epi, st_);
         HIP_CHECK(hipStreamSynchronize(st_));
-        HIP_CHECK(hipMemcpy(out, dout.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(ho.data(), dout.p, ho.size() * 4, hipMemcpyDeviceToHost));
+        for (int m = 0; m < M; ++m)
+            for (int n = 0; n < N; ++n) out[(size_t)m * N + n] = ho[out_packed ? pk_off(m, n, mtt) : (size_t)m * N + n];
     }
     void dbg_layernorm(const float* h, const float* gamma, const float* beta, float* out, int M) {
         use();
@@ -904,7 +930,9 @@ private:
     void ensure_rows(RowWs& w, int M) {
         if (M <= w.rows_cap) return;
         graph_active_.clear();   // buffers move: a captured decode graph is stale
-        const int cap = std::max(M, 64);
+        const int cap = (std::max(M, 64) + 63) / 64 * 64;   // whole 64-row groups: the decode chain keeps its rows packed (pk_off)
+        w.ybuf.ensure((size_t)cap * kHidden * 4);
+        w.stats.ensure((size_t)cap * 64 * sizeof(float2));
         w.h.ensure((size_t)cap * kHidden * 4);
         w.xn.ensure((size_t)cap * kHidden * 4);
         w.qbuf.ensure((size_t)cap * kHidden * 4);
@@ -963,27 +991,29 @@ private:
         float* h = w.h.as<float>();
         const int* bt = block_tables_.as<int>();
         const int* kvpos = slot_kvpos_.as<int>();
+        const int mtt = w.rows_cap / 16;   // h, att, act are packed rows (pk_off) with this many 16-row tiles
         for (int l = 0; l < cfg_.n_layer; ++l) {
             const LayerW& L = layers_[l];
             float* kvl = kv_.as<float>() + (long)l * kv_layer_stride_;
             GemmRowsArgs a{};
             a.M = M; a.eps = 1e-5f;
-            a.X = h; a.ldx = kHidden; a.Wt = L.tqkv; a.N = 3 * kHidden; a.K = kHidden; a.bias = L.bqkv;
-            a.gamma = L.ln1w; a.beta = L.ln1b; a.out = w.qbuf.as<float>(); a.ldo = kHidden;
+            a.X = h; a.xmt = mtt; a.Wt = L.tqkv; a.N = 3 * kHidden; a.K = kHidden; a.bias = L.bqkv;
+            a.gamma = L.ln1w; a.beta = L.ln1b; a.stats_in = w.stats.as<float2>(); a.out = w.qbuf.as<float>(); a.ldo = kHidden;
             a.kv_layer = kvl; a.row_slot = d_row_slot; a.slot_kvpos = kvpos; a.block_tables = bt; a.max_blocks = kMaxBlocks;
             gemm_rows(w, a, true, kEpiQkv);
-            launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, nullptr, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st);
+            launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, nullptr, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, mtt);
             a = GemmRowsArgs{};
-            a.M = M; a.X = w.att.as<float>(); a.ldx = kHidden; a.Wt = L.tproj; a.N = kHidden; a.K = kHidden; a.bias = L.bproj;
-            a.out = h; a.ldo = kHidden;
+            a.M = M; a.X = w.att.as<float>(); a.xmt = mtt; a.Wt = L.tproj; a.N = kHidden; a.K = kHidden; a.bias = L.bproj;
+            a.out = h; a.omt = mtt; a.stats_out = w.stats.as<float2>();
             gemm_rows(w, a, false, kEpiResidual);
             a = GemmRowsArgs{};
-            a.M = M; a.eps = 1e-5f; a.X = h; a.ldx = kHidden; a.Wt = L.tfc; a.N = 4 * kHidden; a.K = kHidden; a.bias = L.bfc;
-            a.gamma = L.ln2w; a.beta = L.ln2b; a.out = w.act.as<float>(); a.ldo = 4 * kHidden;
+            a.M = M; a.eps = 1e-5f; a.X = h; a.xmt = mtt; a.Wt = L.tfc; a.N = 4 * kHidden; a.K = kHidden; a.bias = L.bfc;
+            a.gamma = L.ln2w; a.beta = L.ln2b; a.stats_in = w.stats.as<float2>(); a.out = w.act.as<float>(); a.omt = mtt;
             gemm_rows(w, a, true, kEpiBiasGelu);
             a = GemmRowsArgs{};
-            a.M = M; a.X = w.act.as<float>(); a.ldx = 4 * kHidden; a.Wt = L.tproj2; a.N = kHidden; a.K = 4 * kHidden; a.bias = L.bproj2;
-            a.out = h; a.ldo = kHidden;
+            a.M = M; a.X = w.act.as<float>(); a.xmt = mtt; a.Wt = L.tproj2; a.N = kHidden; a.K = 4 * kHidden; a.bias = L.bproj2;
+            a.out = h; a.omt = mtt;
+            if (l + 1 < cfg_.n_layer) a.stats_out = w.stats.as<float2>();   // (ln_f computes its own statistics in final_rows_kernel)
             gemm_rows(w, a, false, kEpiResidual);
         }
     }
@@ -1097,10 +1127,11 @@ private:
     // decode tail of the gemm_rows chain: rows are the live sequences in order (sample_row = identity), w.h holds the
     // residual stream: ln_f + final_norm (+ second final_norm into the latent stash) -> mel_head GEMM (+ bias) -> sampler
     void sample_kernels_decode(RowWs& w, int Ms) {
-        launch_final_rows(w.h.as<float>(), w.i_sample_slot.as<int>(), lnfw_, lnfb_, fnw_, fnb_, w.ybuf.as<float>(),
+        const int mtt = w.rows_cap / 16;
+        launch_final_rows(w.h.as<float>(), mtt, w.i_sample_slot.as<int>(), lnfw_, lnfb_, fnw_, fnb_, w.ybuf.as<float>(),
                           latents_.as<float>(), (long)kMaxLatRows * kHidden, slot_ngen_.as<int>(), kMaxLatRows, Ms, 1e-5f, w.st);
         GemmRowsArgs a{};
-        a.M = Ms; a.X = w.ybuf.as<float>(); a.ldx = kHidden; a.Wt = thead_; a.N = kHeadPad; a.K = kHidden; a.bias = headb_;
+        a.M = Ms; a.X = w.ybuf.as<float>(); a.xmt = mtt; a.Wt = thead_; a.N = kHeadPad; a.K = kHidden; a.bias = headb_;
         a.out = w.P2.as<float>(); a.ldo = kHeadPad;
         gemm_rows(w, a, false, kEpiBias);
         SamplerArgs sa = sampler_args(w, w.P2.as<float>(), 1, Ms, kHeadPad, zero_bias_.as<float>(), nullptr);
@@ -1265,7 +1296,8 @@ private:
     // AUR_DECODE_STREAMS=2 splits the live sequences into two chains on two streams inside the graph (the M = 32
     // GEMMs are latency bound, the attention is bandwidth bound: the chains fill each other's gaps).
     void decode_kernels(RowWs& w, int Mk) {
-        launch_embed_decode(w.i_row_slot.as<int>(), slot_tok_.as<int>(), slot_pos_.as<int>(), wte_, wpe_, w.h.as<float>(), Mk, w.st);
+        launch_embed_decode(w.i_row_slot.as<int>(), slot_tok_.as<int>(), slot_pos_.as<int>(), wte_, wpe_, w.h.as<float>(), Mk, w.st,
+                            rows_gemm_ ? w.rows_cap / 16 : 0, rows_gemm_ ? w.stats.as<float2>() : nullptr);
         if (rows_gemm_) {
             forward_decode(w, Mk, w.i_row_slot.as<int>());
             sample_kernels_decode(w, Mk);

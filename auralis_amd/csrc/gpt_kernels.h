@@ -84,30 +84,49 @@ bool launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M
 // Weights come packed by pack_wt16: Wt[N/16][K/16][64 lanes][4], lane = 16*q + j, component s
 //   = W[16*kb + 4*q + s][16*nt + j], i.e. one 16 x 16 K-by-N block is 1 KiB, contiguous, and the float4 a lane loads IS its
 // B fragment for four consecutive v_mfma_f32_16x16x4_f32 steps (the A float4 X[row][16*kb + 4*q .. +3] likewise).
+// Activations that feed these GEMMs live in HBM in MFMA-fragment order ("packed rows"): element (row m, column k) of an
+// [rows][K] matrix sits at pk_off(m, k, mtt), mtt = allocated rows / 16, i.e. one (16 rows x 16 columns) block is 1 KiB and
+// lane (q = (k>>2)&3, j = m&15) of a wave owns its float4 X[m][16*kb + 4q .. +3].  Every A load of the kernel is then one
+// contiguous 1 KiB request per wave (the row-major form costs 64 address cycles per wave-load: adjacent lanes are adjacent
+// ROWS, 4 KB apart; measured 16 B/clk/CU), and every epilogue writes whole 1 KiB blocks.
+__host__ __device__ inline long pk_off(int m, int k, int mtt) {
+    return ((((long)(k >> 4) * mtt + (m >> 4)) * 64 + ((k >> 2) & 3) * 16 + (m & 15)) << 2) + (k & 3);
+}
 enum GemmRowsEpi { kEpiBias = 0, kEpiBiasGelu = 1, kEpiResidual = 2, kEpiQkv = 3 };
 struct GemmRowsArgs {
-    const float* X;      // [M][ldx]
-    int ldx;
+    const float* X;      // packed rows, K columns
+    int xmt;             // 16-row tiles allocated in X (pk_off's mtt); >= ceil(M / 64) * 4
     const float* Wt;     // packed (pack_wt16)
     int M, N, K;
     const float* bias;   // [N] or nullptr
     const float* gamma;  // LN prologue (ln != 0): LayerNorm weight / bias over K == 1024
     const float* beta;
     float eps;
-    float* out;          // kEpiBias / kEpiBiasGelu: out[m][n] (ldo);  kEpiResidual: out[m][n] += total + bias;  kEpiQkv: q rows [M][1024]
+    float* out;          // kEpiBias: row-major out[m][n] (ldo);  kEpiBiasGelu: packed rows (omt);  kEpiResidual: packed rows,
+                         // out[m][n] += total + bias;  kEpiQkv: row-major q rows [M][1024]
     int ldo;
+    int omt;             // 16-row tiles allocated in a packed `out`
     float* kv_layer;     // kEpiQkv: paged K/V of this layer, written at (slot = row_slot[m], pos = slot_kvpos[slot])
     const int* row_slot;
     const int* slot_kvpos;
     const int* block_tables;
     int max_blocks;
+    // LayerNorm statistics travel as per-column-tile partials (mean_t, M2_t = sum (x - mean_t)^2 over the tile's 16 columns):
+    // the kernels that WRITE the residual stream (embed_decode, the kEpiResidual epilogue) emit stats[row][tile] for the 64
+    // tiles of a 1024-wide row, the LN prologue combines them (Chan's parallel variance, fixed order) instead of reducing the
+    // row itself, so its MFMAs can start on the first K block that arrives and need no workgroup-wide reduction.
+    const float2* stats_in;   // LN prologue: [rows][64]
+    float2* stats_out;        // kEpiResidual (N == 1024): [rows][64], may be nullptr
+    int nt_w;            // 1: non-temporal loads on the weight stream (read once per step by exactly one CU when there is a
+                         // single row group); launch_gemm_rows sets it from AUR_GEMM_NT
     long long* prof;     // optional (tools/gemm_bench): 8 s_memtime stamps per workgroup, written by wave 0
 };
 void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream_t st);
 // Wt = pack_wt16(W), W row-major [K][ldw], N % 16 == 0, K % 16 == 0
 void launch_pack_wt16(const float* W, int ldw, float* Wt, int K, int N, hipStream_t st);
-// decode tail: y[j] = final_norm(ln_f(h[j])) -> ybuf;  latents[slot][ngen[slot]] = final_norm(y[j])
-void launch_final_rows(const float* h, const int* sample_slot, const float* lnf_w, const float* lnf_b, const float* fn_w,
+// decode tail: y[j] = final_norm(ln_f(h[j])) -> ybuf;  latents[slot][ngen[slot]] = final_norm(y[j]);  h and ybuf are
+// packed rows with `mtt` 16-row tiles, latents row-major
+void launch_final_rows(const float* h, int mtt, const int* sample_slot, const float* lnf_w, const float* lnf_b, const float* fn_w,
                        const float* fn_b, float* ybuf, float* latents, long lat_slot_stride, const int* slot_ngen,
                        int max_lat_rows, int Ms, float eps, hipStream_t st);
 
@@ -124,9 +143,10 @@ void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, 
                          const int* block_tables, int max_blocks, int M, hipStream_t st);
 
 // causal attention of every row against its sequence's paged K/V (keys 0..pos), 16 heads x 64
+// out_mtt > 0: `out` is written as packed rows with that many 16-row tiles (decode chain, A operand of the proj GEMM)
 void launch_paged_attention(const float* qbuf, const float* kv_layer, const int* row_slot, const int* row_pos,
                             const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
-                            hipStream_t st);
+                            hipStream_t st, int out_mtt = 0);
 
 // decode rows (one new token per sequence): qkv epilogue + KV page write + attention in one launch, reading the QKV
 // GEMM slabs directly (bitwise the same result as launch_qkv_epilogue + launch_paged_attention)
@@ -138,8 +158,9 @@ void launch_qkv_attention_fused(const float* P, int S, const float* bias, float*
 void launch_embed_prompt(const int4* desc, const float* spk_cond, const float* text_emb, const float* text_pos,
                          const float* wte, const float* wpe, float* h, int M, hipStream_t st);
 // decode rows: h[m] = wte[tok[slot]] + wpe[pos[slot]]
+// h_mtt > 0: h is written as packed rows and stats[row][64] receives the LayerNorm partials of each row (GemmRowsArgs)
 void launch_embed_decode(const int* row_slot, const int* slot_tok, const int* slot_pos, const float* wte,
-                         const float* wpe, float* h, int M, hipStream_t st);
+                         const float* wpe, float* h, int M, hipStream_t st, int h_mtt = 0, float2* stats = nullptr);
 
 // y[j] = final_norm(xn[sample_row[j]]);  latents[slot][lat_idx[slot]] = final_norm(y[j])   (double final_norm,
 // XTTSv2.py:685-687 on top of vllm_mm_gpt.py:671)

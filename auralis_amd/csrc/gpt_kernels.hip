@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
     static_assert(NW == 8 || NW == 16, "waves per workgroup");
     constexpr int NB = 64 / NW;   // 16-deep K blocks per wave per 1024-deep chunk
     __shared__ __attribute__((aligned(16))) float red[NW][MT * 256];
-    __shared__ __attribute__((aligned(16))) float part[LN ? 2 : 1][LN ? 16 * MT : 1][NW];
+    __shared__ float rs[LN ? 16 * MT : 1][2];   // (mean, rstd) of the workgroup's rows
     __shared__ __attribute__((aligned(16))) float gb[LN ? 2 : 1][LN ? 1024 : 4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
@@ -250,83 +250,58 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
     }
     const int n0 = ntile * 16, m0 = mgrp * 16 * MT;
     const f32x4* wt = reinterpret_cast<const f32x4*>(a.Wt) + (long)ntile * (a.K >> 4) * 64 + lane;
-    const float* xr[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int r = m0 + 16 * mt + j;
-        xr[mt] = a.X + (long)(r < a.M ? r : m0) * a.ldx + 4 * q;   // rows >= M alias the group's first row: never stored
-    }
+    // packed rows: the float4 of lane `lane` for (16-row tile t, K block kb) is at ((kb * xmt + t) * 64 + lane); rows >= M of
+    // the last tiles are allocated but undefined: their products stay in their own (never stored) output rows
+    const f32x4* xp = reinterpret_cast<const f32x4*>(a.X) + (long)(mgrp * MT) * 64 + lane;
     f32x4 bf[KCH > 1 ? 2 : 1][NB], af[KCH > 1 ? 2 : 1][MT][NB];
     auto load_chunk = [&](int c, int buf) {
         const int kb0 = c * 64 + NB * w;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) bf[buf][b] = wt[(long)(kb0 + b) * 64];
+        for (int b = 0; b < NB; ++b)
+            bf[buf][b] = a.nt_w ? __builtin_nontemporal_load(&wt[(long)(kb0 + b) * 64]) : wt[(long)(kb0 + b) * 64];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int b = 0; b < NB; ++b) af[buf][mt][b] = *reinterpret_cast<const f32x4*>(xr[mt] + 16 * (kb0 + b));
+            for (int b = 0; b < NB; ++b) af[buf][mt][b] = xp[((long)(kb0 + b) * a.xmt + mt) * 64];
     };
     if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 0] = (long long)__builtin_amdgcn_s_memtime();
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // LN prologue inputs first: the statistics partials and gamma / beta are small and must not queue behind the tile loads
+    // (loads return in order).  Wave w combines rows w, w + NW, ...; lane t holds column tile t.
+    constexpr int RPW = LN ? 16 * MT / NW : 1;   // rows per wave
+    float2 pt[RPW];
+    f32x4 gbv = {0.f, 0.f, 0.f, 0.f};
+    if (LN) {
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) pt[u] = a.stats_in[(long)(m0 + w + NW * u) * 64 + lane];
+        if (tid < 512) gbv = *reinterpret_cast<const f32x4*>(((tid < 256) ? a.gamma : a.beta) + 4 * (tid & 255));
+    }
     load_chunk(0, 0);
     if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 1] = (long long)__builtin_amdgcn_s_memtime();
+    float mean[MT], rstd[MT];
     if (LN) {
-        // gamma / beta go through LDS (8 KB, staged by the first 8 waves): holding this lane's values in registers next to
-        // the A registers of a 64-row tile spilled; they become visible with the barriers of the statistics passes
-        if (tid < 512) {
-            const float* src = (tid < 256) ? a.gamma : a.beta;
-            *reinterpret_cast<f32x4*>(&gb[tid >> 8][4 * (tid & 255)]) = *reinterpret_cast<const f32x4*>(src + 4 * (tid & 255));
-        }
-        __builtin_amdgcn_sched_barrier(0);   // every load of the workgroup is in flight before the first wait
-        float mean[MT], rstd[MT];
+        __builtin_amdgcn_sched_barrier(0);   // everything above is in flight before the first wait
+        // gamma / beta go through LDS (8 KB): holding this lane's values in registers next to the A registers of a 64-row
+        // tile spilled
+        if (tid < 512) *reinterpret_cast<f32x4*>(&gb[tid >> 8][4 * (tid & 255)]) = gbv;
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float t = 0.f;
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const f32x4 v = af[0][mt][b];
-                    if (pass == 0) {
-                        t += (v[0] + v[1]) + (v[2] + v[3]);
-                    } else {
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            const float d = v[s] - mean[mt];
-                            t = fmaf(d, d, t);
-                        }
-                    }
-                }
-                t += __shfl_xor(t, 16, 64);
-                t += __shfl_xor(t, 32, 64);
-                if (q == 0) part[pass][16 * mt + j][w] = t;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const f32x4* pp = reinterpret_cast<const f32x4*>(&part[pass][16 * mt + j][0]);
-                float tot = 0.f;
-#pragma unroll
-                for (int u = 0; u < NW / 4; ++u) {
-                    const f32x4 pv = pp[u];
-                    const float g4 = (pv[0] + pv[1]) + (pv[2] + pv[3]);
-                    tot = (u == 0) ? g4 : tot + g4;
-                }
-                if (pass == 0) mean[mt] = tot * (1.0f / 1024.0f);
-                else rstd[mt] = 1.0f / sqrtf(tot * (1.0f / 1024.0f) + a.eps);
+        for (int u = 0; u < RPW; ++u) {
+            const int rr = w + NW * u;
+            const float mu = wave_sum_dpp(pt[u].x) * (1.0f / 64.0f);
+            const float d = pt[u].x - mu;
+            const float m2 = wave_sum_dpp(fmaf(16.0f * d, d, pt[u].y));
+            if (lane == 0) {
+                rs[rr][0] = mu;
+                rs[rr][1] = 1.0f / sqrtf(m2 * (1.0f / 1024.0f) + a.eps);
             }
         }
+        __syncthreads();
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            // k = 16*(NB*w + b) + 4q + s
-            const f32x4 gam = *reinterpret_cast<const f32x4*>(&gb[0][16 * (NB * w + b) + 4 * q]);
-            const f32x4 bet = *reinterpret_cast<const f32x4*>(&gb[1][16 * (NB * w + b) + 4 * q]);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) af[0][mt][b][s] = (af[0][mt][b][s] - mean[mt]) * rstd[mt] * gam[s] + bet[s];
+        for (int mt = 0; mt < MT; ++mt) {
+            mean[mt] = rs[16 * mt + j][0];
+            rstd[mt] = rs[16 * mt + j][1];
         }
     }
     if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 2] = (long long)__builtin_amdgcn_s_memtime();
@@ -334,14 +309,24 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
     for (int c = 0; c < KCH; ++c) {
         const int cur = (KCH > 1) ? (c & 1) : 0;
         if (c + 1 < KCH) load_chunk(c + 1, cur ^ 1);
-        __builtin_amdgcn_sched_barrier(0);   // the next chunk's loads are issued before this chunk's MFMAs
+        if (!LN) __builtin_amdgcn_sched_barrier(0);   // the next chunk's loads are issued before this chunk's MFMAs
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+        for (int b = 0; b < NB; ++b) {
+            if (LN) {   // k = 16*(NB*w + b) + 4q + s; normalised block by block so the MFMAs follow the data as it arrives
+                const f32x4 gam = *reinterpret_cast<const f32x4*>(&gb[0][16 * (NB * w + b) + 4 * q]);
+                const f32x4 bet = *reinterpret_cast<const f32x4*>(&gb[1][16 * (NB * w + b) + 4 * q]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        af[cur][mt][b][s] = (af[cur][mt][b][s] - mean[mt]) * rstd[mt] * gam[s] + bet[s];
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][mt][b][s], bf[cur][b][s], acc[mt], 0, 0, 0);
+        }
     }
     // D layout: row = 4*(lane>>4) + r, col = lane&15
 #pragma unroll
@@ -357,25 +342,40 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
         for (int ww = 1; ww < NW; ++ww) t += red[ww][e];
         const int mt = e >> 8, r = (e >> 6) & 3, l = e & 63;
         const int m = m0 + 16 * mt + 4 * (l >> 4) + r, n = n0 + (l & 15);
-        if (m < a.M) {
-            if (a.bias) t += a.bias[n];
-            if (EPI == kEpiBias) {
-                a.out[(long)m * a.ldo + n] = t;
-            } else if (EPI == kEpiBiasGelu) {
-                a.out[(long)m * a.ldo + n] = gelu_new(t);
-            } else if (EPI == kEpiResidual) {
-                float* p = a.out + (long)m * a.ldo + n;
-                *p = *p + t;
+        const bool ok = m < a.M;
+        if (a.bias) t += a.bias[n];
+        if (EPI == kEpiBias) {
+            if (ok) a.out[(long)m * a.ldo + n] = t;
+        } else if (EPI == kEpiBiasGelu) {
+            if (ok) a.out[pk_off(m, n, a.omt)] = gelu_new(t);
+        } else if (EPI == kEpiResidual) {
+            float* p = a.out + pk_off(m, n, a.omt);   // (rows >= M of the last tile are allocated)
+            const float v = *p + t;
+            if (ok) *p = v;
+            if (a.stats_out) {   // LayerNorm partials of this 16-column tile: the 16 lanes of a row are adjacent
+                float sm = v;
+                sm += __shfl_xor(sm, 8, 64);
+                sm += __shfl_xor(sm, 4, 64);
+                sm += __shfl_xor(sm, 2, 64);
+                sm += __shfl_xor(sm, 1, 64);
+                const float mu = sm * (1.0f / 16.0f);
+                const float d = v - mu;
+                float m2 = d * d;
+                m2 += __shfl_xor(m2, 8, 64);
+                m2 += __shfl_xor(m2, 4, 64);
+                m2 += __shfl_xor(m2, 2, 64);
+                m2 += __shfl_xor(m2, 1, 64);
+                if (ok && (l & 15) == 0) a.stats_out[(long)m * 64 + ntile] = make_float2(mu, m2);
+            }
+        } else if (ok) {
+            const int u = n / kHidden, d = n - u * kHidden;
+            if (u == 0) {
+                a.out[(long)m * kHidden + d] = t;
             } else {
-                const int u = n / kHidden, d = n - u * kHidden;
-                if (u == 0) {
-                    a.out[(long)m * kHidden + d] = t;
-                } else {
-                    const int slot = a.row_slot[m];
-                    const int pos = a.slot_kvpos[slot];
-                    const int blk = a.block_tables[(long)slot * a.max_blocks + pos / kKvBlockTokens];
-                    a.kv_layer[kv_offset(blk, u - 1, d / kHeadDim, pos % kKvBlockTokens) + d % kHeadDim] = t;
-                }
+                const int slot = a.row_slot[m];
+                const int pos = a.slot_kvpos[slot];
+                const int blk = a.block_tables[(long)slot * a.max_blocks + pos / kKvBlockTokens];
+                a.kv_layer[kv_offset(blk, u - 1, d / kHeadDim, pos % kKvBlockTokens) + d % kHeadDim] = t;
             }
         }
     }
@@ -392,13 +392,8 @@ static void launch_gemm_rows_mt(const GemmRowsArgs& a, int mt, int nw, hipStream
     const dim3 grid((unsigned)(n_tiles * n_grp));
     if constexpr (KCH == 1) {
         if (mt == 4) {
-            if constexpr (LN) {
-                AUR_REQUIRE(nw == 8, "gemm_rows: 64-row LN tiles need 8-wave workgroups");
-                hipLaunchKernelGGL((gemm_rows_kernel<4, KCH, LN, EPI, 8>), grid, dim3(512), 0, st, a);
-            } else {
-                if (nw == 8) hipLaunchKernelGGL((gemm_rows_kernel<4, KCH, LN, EPI, 8>), grid, dim3(512), 0, st, a);
-                else hipLaunchKernelGGL((gemm_rows_kernel<4, KCH, LN, EPI, 16>), grid, dim3(1024), 0, st, a);
-            }
+            if (nw == 8) hipLaunchKernelGGL((gemm_rows_kernel<4, KCH, LN, EPI, 8>), grid, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((gemm_rows_kernel<4, KCH, LN, EPI, 16>), grid, dim3(1024), 0, st, a);
             return;
         }
     }
@@ -413,8 +408,10 @@ static void launch_gemm_rows_mt(const GemmRowsArgs& a, int mt, int nw, hipStream
 }
 
 void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream_t st) {
-    AUR_REQUIRE(a.N % 16 == 0 && (a.K == 1024 || a.K == 4096) && a.ldx % 4 == 0 && a.M >= 1, "gemm_rows: shape");
-    AUR_REQUIRE(!ln || a.K == 1024, "gemm_rows: LN prologue needs K == 1024");
+    AUR_REQUIRE(a.N % 16 == 0 && (a.K == 1024 || a.K == 4096) && a.M >= 1 && a.xmt >= 4 * ((a.M + 63) / 64), "gemm_rows: shape");
+    AUR_REQUIRE((epi != kEpiBiasGelu && epi != kEpiResidual) || a.omt >= (a.M + 15) / 16, "gemm_rows: packed output rows");
+    AUR_REQUIRE(!ln || (a.K == 1024 && a.stats_in), "gemm_rows: LN prologue needs K == 1024 and the row statistics");
+    AUR_REQUIRE(!a.stats_out || (epi == kEpiResidual && a.N == 1024), "gemm_rows: statistics are emitted for 1024-wide residual rows");
     // rows per workgroup: the largest of 64 / 32 / 16 that still yields >= 192 workgroups (the chip has 256 CUs and a
     // workgroup fills one), so N = 1024 GEMMs split the rows and re-read the column tile's weights from L2
     static const int mt_env = [] {
@@ -434,18 +431,26 @@ void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream
     const int nw = ln ? nw_ln : nw_plain;
     int mt = 4;
     while (mt > 1 && ((a.M + 16 * mt - 1) / (16 * mt)) * (a.N / 16) < 192 && a.M > 16 * (mt / 2)) mt >>= 1;
+    // LN-prologue GEMMs (tools/gemm_bench, M = 64, MI355X): 16-row workgroups for N = 3072 (11.8 us vs 14.6 at 64 rows: the
+    // activation tile per workgroup shrinks 4x and L1 fill, ~40 B/clk/CU, is what bounds these kernels), 32 rows for N = 4096
+    if (ln) mt = (a.N >= 4096) ? 2 : 1;
     while (mt > 1 && a.M <= 16 * (mt / 2)) mt >>= 1;
     if (mt_env == 1 || mt_env == 2 || mt_env == 4) mt = mt_env;
     if (a.K == 4096 && mt > 2) mt = 2;
-    if (ln && nw == 16 && mt > 2) mt = 2;   // (64-row LN tiles exist as 8-wave workgroups only)
+    static const int nt_env = [] {
+        const char* e = getenv("AUR_GEMM_NT");
+        return e ? atoi(e) : 0;
+    }();
+    GemmRowsArgs b = a;
+    if (nt_env && (b.M + 16 * mt - 1) / (16 * mt) == 1) b.nt_w = 1;
     trace_launch("gemm_rows_kernel");
-    if (ln && epi == kEpiQkv) launch_gemm_rows_mt<1, true, kEpiQkv>(a, mt, nw, st);
-    else if (ln && epi == kEpiBiasGelu) launch_gemm_rows_mt<1, true, kEpiBiasGelu>(a, mt, nw, st);
-    else if (ln && epi == kEpiBias) launch_gemm_rows_mt<1, true, kEpiBias>(a, mt, nw, st);
-    else if (!ln && epi == kEpiResidual && a.K == 1024) launch_gemm_rows_mt<1, false, kEpiResidual>(a, mt, nw, st);
-    else if (!ln && epi == kEpiResidual && a.K == 4096) launch_gemm_rows_mt<4, false, kEpiResidual>(a, mt, nw, st);
-    else if (!ln && epi == kEpiBias && a.K == 1024) launch_gemm_rows_mt<1, false, kEpiBias>(a, mt, nw, st);
-    else if (!ln && epi == kEpiBias && a.K == 4096) launch_gemm_rows_mt<4, false, kEpiBias>(a, mt, nw, st);
+    if (ln && epi == kEpiQkv) launch_gemm_rows_mt<1, true, kEpiQkv>(b, mt, nw, st);
+    else if (ln && epi == kEpiBiasGelu) launch_gemm_rows_mt<1, true, kEpiBiasGelu>(b, mt, nw, st);
+    else if (ln && epi == kEpiBias) launch_gemm_rows_mt<1, true, kEpiBias>(b, mt, nw, st);
+    else if (!ln && epi == kEpiResidual && a.K == 1024) launch_gemm_rows_mt<1, false, kEpiResidual>(b, mt, nw, st);
+    else if (!ln && epi == kEpiResidual && a.K == 4096) launch_gemm_rows_mt<4, false, kEpiResidual>(b, mt, nw, st);
+    else if (!ln && epi == kEpiBias && a.K == 1024) launch_gemm_rows_mt<1, false, kEpiBias>(b, mt, nw, st);
+    else if (!ln && epi == kEpiBias && a.K == 4096) launch_gemm_rows_mt<4, false, kEpiBias>(b, mt, nw, st);
     else throw InvalidArgument("launch_gemm_rows: unsupported (ln, epilogue, K) combination");
     HIP_CHECK(hipGetLastError());
 }
@@ -575,7 +580,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
                                                               const int* __restrict__ slot_kvpos,
                                                               const int* __restrict__ block_tables, int max_blocks,
                                                               float* __restrict__ out, const float* __restrict__ P,
-                                                              int S, const float* __restrict__ bias, int M) {
+                                                              int S, const float* __restrict__ bias, int M, int out_mtt) {
     __shared__ float part_o[16][kHeadDim];
     __shared__ float part_m[16], part_l[16];
     const int m = blockIdx.x, head = blockIdx.y;
@@ -665,17 +670,18 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
             L += part_l[p] * w;
             O += part_o[p][threadIdx.x] * w;
         }
-        out[(long)m * kHidden + head * kHeadDim + threadIdx.x] = O / L;
+        const int col = head * kHeadDim + threadIdx.x;
+        out[out_mtt > 0 ? pk_off(m, col, out_mtt) : (long)m * kHidden + col] = O / L;
     }
 }
 
 void launch_paged_attention(const float* qbuf, const float* kv_layer, const int* row_slot, const int* row_pos,
                             const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
-                            hipStream_t st) {
+                            hipStream_t st, int out_mtt) {
     trace_launch("paged_attention_kernel");
     hipLaunchKernelGGL(paged_attention_kernel<false>, dim3(M, kHeads), dim3(256), 0, st, qbuf, const_cast<float*>(kv_layer),
                        row_slot, row_pos, slot_kvpos, block_tables, max_blocks, out, (const float*)nullptr, 0,
-                       (const float*)nullptr, M);
+                       (const float*)nullptr, M, out_mtt);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -684,7 +690,7 @@ void launch_qkv_attention_fused(const float* P, int S, const float* bias, float*
                                 hipStream_t st) {
     trace_launch("paged_attention_kernel<fused>");
     hipLaunchKernelGGL(paged_attention_kernel<true>, dim3(M, kHeads), dim3(256), 0, st, (const float*)nullptr, kv_layer,
-                       row_slot, (const int*)nullptr, slot_kvpos, block_tables, max_blocks, out, P, S, bias, M);
+                       row_slot, (const int*)nullptr, slot_kvpos, block_tables, max_blocks, out, P, S, bias, M, 0);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -720,19 +726,35 @@ __global__ __launch_bounds__(256) void embed_decode_kernel(const int* __restrict
                                                            const int* __restrict__ slot_tok,
                                                            const int* __restrict__ slot_pos,
                                                            const float* __restrict__ wte,
-                                                           const float* __restrict__ wpe, float* __restrict__ h) {
+                                                           const float* __restrict__ wpe, float* __restrict__ h, int h_mtt,
+                                                           float2* __restrict__ stats) {
     const int m = blockIdx.x;
     const int slot = row_slot[m];
     const int n = 4 * threadIdx.x;
     const f32x4 v = *reinterpret_cast<const f32x4*>(wte + (long)slot_tok[slot] * kHidden + n) +
                     *reinterpret_cast<const f32x4*>(wpe + (long)slot_pos[slot] * kHidden + n);
-    *reinterpret_cast<f32x4*>(h + (long)m * kHidden + n) = v;
+    *reinterpret_cast<f32x4*>(h + (h_mtt > 0 ? pk_off(m, n, h_mtt) : (long)m * kHidden + n)) = v;
+    if (stats) {   // LayerNorm partials per 16-column tile (4 adjacent lanes), same definition as the kEpiResidual epilogue
+        float sm = (v[0] + v[1]) + (v[2] + v[3]);
+        sm += __shfl_xor(sm, 2, 64);
+        sm += __shfl_xor(sm, 1, 64);
+        const float mu = sm * (1.0f / 16.0f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float d = v[c] - mu;
+            m2 = fmaf(d, d, m2);
+        }
+        m2 += __shfl_xor(m2, 2, 64);
+        m2 += __shfl_xor(m2, 1, 64);
+        if ((threadIdx.x & 3) == 0) stats[(long)m * 64 + (threadIdx.x >> 2)] = make_float2(mu, m2);
+    }
 }
 
 void launch_embed_decode(const int* row_slot, const int* slot_tok, const int* slot_pos, const float* wte,
-                         const float* wpe, float* h, int M, hipStream_t st) {
+                         const float* wpe, float* h, int M, hipStream_t st, int h_mtt, float2* stats) {
     trace_launch("embed_decode_kernel");
-    hipLaunchKernelGGL(embed_decode_kernel, dim3(M), dim3(256), 0, st, row_slot, slot_tok, slot_pos, wte, wpe, h);
+    hipLaunchKernelGGL(embed_decode_kernel, dim3(M), dim3(256), 0, st, row_slot, slot_tok, slot_pos, wte, wpe, h, h_mtt, stats);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -823,7 +845,7 @@ void launch_final_norm(const float* xn, const int* sample_row, const int* sample
 }
 
 // decode tail of the gemm_rows chain: the last block's residual add leaves h; ln_f and both final_norms run here
-__global__ __launch_bounds__(256) void final_rows_kernel(const float* __restrict__ h, const int* __restrict__ sample_slot,
+__global__ __launch_bounds__(256) void final_rows_kernel(const float* __restrict__ h, int mtt, const int* __restrict__ sample_slot,
                                                          const float* __restrict__ lnf_w, const float* __restrict__ lnf_b,
                                                          const float* __restrict__ fn_w, const float* __restrict__ fn_b,
                                                          float* __restrict__ ybuf, float* __restrict__ latents,
@@ -834,11 +856,11 @@ __global__ __launch_bounds__(256) void final_rows_kernel(const float* __restrict
     if (j >= Ms) return;
     f32x4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(h + (long)j * kHidden + 4 * (lane + 64 * u));
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(h + pk_off(j, 4 * (lane + 64 * u), mtt));
     ln_wave(v, lnf_w, lnf_b, lane, eps);
     ln_wave(v, fn_w, fn_b, lane, eps);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(ybuf + (long)j * kHidden + 4 * (lane + 64 * u)) = v[u];
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4*>(ybuf + pk_off(j, 4 * (lane + 64 * u), mtt)) = v[u];
     const int slot = sample_slot[j];
     const int idx = slot_ngen[slot];
     if (latents && idx < max_lat_rows) {
@@ -849,11 +871,11 @@ __global__ __launch_bounds__(256) void final_rows_kernel(const float* __restrict
     }
 }
 
-void launch_final_rows(const float* h, const int* sample_slot, const float* lnf_w, const float* lnf_b, const float* fn_w,
+void launch_final_rows(const float* h, int mtt, const int* sample_slot, const float* lnf_w, const float* lnf_b, const float* fn_w,
                        const float* fn_b, float* ybuf, float* latents, long lat_slot_stride, const int* slot_ngen,
                        int max_lat_rows, int Ms, float eps, hipStream_t st) {
     trace_launch("final_rows_kernel");
-    hipLaunchKernelGGL(final_rows_kernel, dim3((Ms + 3) / 4), dim3(256), 0, st, h, sample_slot, lnf_w, lnf_b, fn_w, fn_b, ybuf,
+    hipLaunchKernelGGL(final_rows_kernel, dim3((Ms + 3) / 4), dim3(256), 0, st, h, mtt, sample_slot, lnf_w, lnf_b, fn_w, fn_b, ybuf,
                        latents, lat_slot_stride, slot_ngen, max_lat_rows, Ms, eps);
     HIP_CHECK(hipGetLastError());
 }

@@ -113,6 +113,9 @@ int main(int argc, char** argv) {
     HIP_CHECK(hipMemcpy(dslot, hslot.data(), 256 * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dpos, hpos.data(), 256 * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dbt, hbt.data(), 64 * 66 * 4, hipMemcpyHostToDevice));
+    float2* dstats;
+    HIP_CHECK(hipMalloc(&dstats, 256 * 64 * sizeof(float2)));
+    HIP_CHECK(hipMemset(dstats, 0, 256 * 64 * sizeof(float2)));
     long long* dprof;
     HIP_CHECK(hipMalloc(&dprof, 4096 * 8 * 8));
 
@@ -134,15 +137,16 @@ int main(int argc, char** argv) {
             launch_pack_wt16(wsrc, s.N, wt[r], s.K, s.N, st);
         }
         HIP_CHECK(hipStreamSynchronize(st));
+        for (int nt : {0, 1})
         for (int nw : {16, 8})
             for (int mt : {1, 2, 4}) {
+                if (nt && (M + 16 * mt - 1) / (16 * mt) != 1) continue;
                 if (s.K == 4096 && mt == 4) continue;
-                if (s.ln && mt == 4 && nw == 16) continue;
                 if (16 * (mt / 2) >= M && mt > 1) continue;
                 GemmRowsArgs a{};
-                a.X = X; a.ldx = s.K; a.M = M; a.N = s.N; a.K = s.K; a.bias = bias; a.gamma = gamma; a.beta = beta; a.eps = 1e-5f;
+                a.X = X; a.xmt = 16; a.omt = 16; a.M = M; a.N = s.N; a.K = s.K; a.bias = bias; a.gamma = gamma; a.beta = beta; a.eps = 1e-5f;
                 a.out = (s.epi == kEpiResidual) ? hres : out; a.ldo = (s.epi == kEpiQkv) ? H : s.N;
-                a.kv_layer = kv; a.row_slot = dslot; a.slot_kvpos = dpos; a.block_tables = dbt; a.max_blocks = 66;
+                a.kv_layer = kv; a.row_slot = dslot; a.slot_kvpos = dpos; a.block_tables = dbt; a.max_blocks = 66; a.nt_w = nt; a.stats_in = dstats; a.stats_out = (s.epi == kEpiResidual && s.N == 1024) ? dstats : nullptr;
                 int it = 0;
                 const float us = time_us(st, 240, [&] {
                     a.Wt = wt[it++ % NREP];
@@ -166,8 +170,8 @@ int main(int argc, char** argv) {
                     for (int k = 0; k < 5; ++k) ph[k] += (double)(hp[g * 8 + k + 1] - hp[g * 8 + k]) / nwg;
                 }
                 const double mb = 4.0 * ((double)s.K * s.N + (double)M * s.K + (double)M * s.N) / 1e6;
-                printf("%s M=%d rows/wg=%2d waves=%2d wgs=%4d : %6.2f us/launch  %5.2f TB/s | cycles: span %6lld issue %5.0f ln+wait %6.0f mfma %6.0f bar %5.0f epi %5.0f\n",
-                       s.name, M, 16 * mt, nw, nwg, us, mb / us, t_max - t_min, ph[0], ph[1], ph[2], ph[3], ph[4]);
+                printf("%s M=%d nt=%d rows/wg=%2d waves=%2d wgs=%4d : %6.2f us/launch  %5.2f TB/s | cycles: span %6lld issue %5.0f ln+wait %6.0f mfma %6.0f bar %5.0f epi %5.0f\n",
+                       s.name, M, nt, 16 * mt, nw, nwg, us, mb / us, t_max - t_min, ph[0], ph[1], ph[2], ph[3], ph[4]);
             }
         // reference: the round-1 split-K kernel on the same shape (slab sums not included)
         {
@@ -204,19 +208,19 @@ int main(int argc, char** argv) {
         auto chain = [&] {
             for (int l = 0; l < 30; ++l) {
                 GemmRowsArgs a{};
-                a.M = M; a.eps = 1e-5f; a.X = hres; a.ldx = 1024; a.Wt = wq[l]; a.N = 3072; a.K = 1024; a.bias = bias; a.gamma = gamma;
-                a.beta = beta; a.out = qb; a.ldo = 1024; a.kv_layer = kv; a.row_slot = dslot; a.slot_kvpos = dpos; a.block_tables = dbt;
+                a.M = M; a.eps = 1e-5f; a.X = hres; a.xmt = 16; a.Wt = wq[l]; a.N = 3072; a.K = 1024; a.bias = bias; a.gamma = gamma;
+                a.beta = beta; a.stats_in = dstats; a.out = qb; a.ldo = 1024; a.kv_layer = kv; a.row_slot = dslot; a.slot_kvpos = dpos; a.block_tables = dbt;
                 a.max_blocks = 66;
                 launch_gemm_rows(a, true, kEpiQkv, st);
                 a = GemmRowsArgs{};
-                a.M = M; a.X = att; a.ldx = 1024; a.Wt = wp[l]; a.N = 1024; a.K = 1024; a.bias = bias; a.out = hres; a.ldo = 1024;
+                a.M = M; a.X = att; a.xmt = 16; a.Wt = wp[l]; a.N = 1024; a.K = 1024; a.bias = bias; a.out = hres; a.omt = 16; a.stats_out = dstats;
                 launch_gemm_rows(a, false, kEpiResidual, st);
                 a = GemmRowsArgs{};
-                a.M = M; a.eps = 1e-5f; a.X = hres; a.ldx = 1024; a.Wt = wf[l]; a.N = 4096; a.K = 1024; a.bias = bias; a.gamma = gamma;
-                a.beta = beta; a.out = act; a.ldo = 4096;
+                a.M = M; a.eps = 1e-5f; a.X = hres; a.xmt = 16; a.Wt = wf[l]; a.N = 4096; a.K = 1024; a.bias = bias; a.gamma = gamma;
+                a.beta = beta; a.stats_in = dstats; a.out = act; a.omt = 16;
                 launch_gemm_rows(a, true, kEpiBiasGelu, st);
                 a = GemmRowsArgs{};
-                a.M = M; a.X = act; a.ldx = 4096; a.Wt = w2[l]; a.N = 1024; a.K = 4096; a.bias = bias; a.out = hres; a.ldo = 1024;
+                a.M = M; a.X = act; a.xmt = 16; a.Wt = w2[l]; a.N = 1024; a.K = 4096; a.bias = bias; a.out = hres; a.omt = 16; a.stats_out = dstats;
                 launch_gemm_rows(a, false, kEpiResidual, st);
             }
         };
