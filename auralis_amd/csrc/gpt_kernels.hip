@@ -223,19 +223,21 @@ void launch_pack_wt16(const float* W, int ldw, float* Wt, int K, int N, hipStrea
     HIP_CHECK(hipGetLastError());
 }
 
-template <int MT, int KCH, bool LN, int EPI, int NW>
+template <int MT, int KCH, bool LN, int EPI, int NW, int NTL = 1>
 __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
+    // NTL = 16-column tiles per workgroup (each wave keeps MT x NTL accumulator tiles): 2 halves the activation bytes a
+    // workgroup pulls per weight byte; the K order of every output element is the same for NTL = 1 and 2 (bitwise equal)
     static_assert(!LN || KCH == 1, "LN prologue needs the whole row in one chunk");
     static_assert(NW == 8 || NW == 16, "waves per workgroup");
     constexpr int NB = 64 / NW;   // 16-deep K blocks per wave per 1024-deep chunk
-    __shared__ __attribute__((aligned(16))) float red[NW][MT * 256];
+    __shared__ __attribute__((aligned(16))) float red[NW][MT * NTL * 256];
     __shared__ float rs[LN ? 16 * MT : 1][2];   // (mean, rstd) of the workgroup's rows
     __shared__ __attribute__((aligned(16))) float gb[LN ? 2 : 1][LN ? 1024 : 4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
     // workgroup -> (column tile, row group): the row groups of one column tile get ids 8 apart (same XCD, adjacent in
     // dispatch order) so that the tile's weights leave HBM once and the other groups hit them in that XCD's L2
-    const int n_tiles = a.N >> 4, n_grp = (a.M + 16 * MT - 1) / (16 * MT);
+    const int n_tiles = a.N / (16 * NTL), n_grp = (a.M + 16 * MT - 1) / (16 * MT);
     int ntile, mgrp;
     {
         const int L = blockIdx.x;
@@ -248,26 +250,33 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
             ntile = L / n_grp;
         }
     }
-    const int n0 = ntile * 16, m0 = mgrp * 16 * MT;
-    const f32x4* wt = reinterpret_cast<const f32x4*>(a.Wt) + (long)ntile * (a.K >> 4) * 64 + lane;
+    const int n0 = ntile * 16 * NTL, m0 = mgrp * 16 * MT;
+    const long wt_tile = (long)(a.K >> 4) * 64;   // float4s of one packed 16-column tile
+    const f32x4* wt = reinterpret_cast<const f32x4*>(a.Wt) + (long)ntile * NTL * wt_tile + lane;
     // packed rows: the float4 of lane `lane` for (16-row tile t, K block kb) is at ((kb * xmt + t) * 64 + lane); rows >= M of
     // the last tiles are allocated but undefined: their products stay in their own (never stored) output rows
     const f32x4* xp = reinterpret_cast<const f32x4*>(a.X) + (long)(mgrp * MT) * 64 + lane;
-    f32x4 bf[KCH > 1 ? 2 : 1][NB], af[KCH > 1 ? 2 : 1][MT][NB];
+    f32x4 bf[KCH > 1 ? 2 : 1][NTL][NB], af[KCH > 1 ? 2 : 1][MT][NB];
     auto load_chunk = [&](int c, int buf) {
         const int kb0 = c * 64 + NB * w;
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
-            bf[buf][b] = a.nt_w ? __builtin_nontemporal_load(&wt[(long)(kb0 + b) * 64]) : wt[(long)(kb0 + b) * 64];
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const f32x4* src = &wt[t * wt_tile + (long)(kb0 + b) * 64];
+                bf[buf][t][b] = a.nt_w ? __builtin_nontemporal_load(src) : *src;
+            }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int b = 0; b < NB; ++b) af[buf][mt][b] = xp[((long)(kb0 + b) * a.xmt + mt) * 64];
     };
     if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 0] = (long long)__builtin_amdgcn_s_memtime();
-    f32x4 acc[MT];
+    f32x4 acc[MT][NTL];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     // LN prologue inputs first: the statistics partials and gamma / beta are small and must not queue behind the tile loads
     // (loads return in order).  Wave w combines rows w, w + NW, ...; lane t holds column tile t.
     constexpr int RPW = LN ? 16 * MT / NW : 1;   // rows per wave
@@ -324,24 +333,28 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][mt][b][s], bf[cur][b][s], acc[mt], 0, 0, 0);
+                for (int t = 0; t < NTL; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][mt][b][s], bf[cur][t][b][s], acc[mt][t], 0, 0, 0);
         }
     }
     // D layout: row = 4*(lane>>4) + r, col = lane&15
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int t = 0; t < NTL; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[w][mt * 256 + r * 64 + lane] = acc[mt][r];
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[w][(t * MT + mt) * 256 + r * 64 + lane] = acc[mt][t][r];
     if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 3] = (long long)__builtin_amdgcn_s_memtime();
     __syncthreads();
     if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 4] = (long long)__builtin_amdgcn_s_memtime();
-    for (int e = tid; e < MT * 256; e += 64 * NW) {
+    for (int e = tid; e < MT * NTL * 256; e += 64 * NW) {
         float t = red[0][e];
 #pragma unroll
         for (int ww = 1; ww < NW; ++ww) t += red[ww][e];
-        const int mt = e >> 8, r = (e >> 6) & 3, l = e & 63;
-        const int m = m0 + 16 * mt + 4 * (l >> 4) + r, n = n0 + (l & 15);
+        const int ct = (e >> 8) / MT, mt = (e >> 8) - ct * MT, r = (e >> 6) & 3, l = e & 63;
+        const int m = m0 + 16 * mt + 4 * (l >> 4) + r, n = n0 + 16 * ct + (l & 15);
         const bool ok = m < a.M;
         if (a.bias) t += a.bias[n];
         if (EPI == kEpiBias) {
@@ -365,7 +378,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
                 m2 += __shfl_xor(m2, 4, 64);
                 m2 += __shfl_xor(m2, 2, 64);
                 m2 += __shfl_xor(m2, 1, 64);
-                if (ok && (l & 15) == 0) a.stats_out[(long)m * 64 + ntile] = make_float2(mu, m2);
+                if (ok && (l & 15) == 0) a.stats_out[(long)m * 64 + ntile * NTL + ct] = make_float2(mu, m2);
             }
         } else if (ok) {
             const int u = n / kHidden, d = n - u * kHidden;
@@ -386,11 +399,20 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
 // the LN prologue: 64 A registers + the statistics spilled there, so those run as 8 waves with K-slices of 128 (<= 256
 // VGPRs).  K = 4096 needs two chunk buffers: at most 32 rows per workgroup.
 template <int KCH, bool LN, int EPI>
-static void launch_gemm_rows_mt(const GemmRowsArgs& a, int mt, int nw, hipStream_t st) {
-    const int n_tiles = a.N / 16;
+static void launch_gemm_rows_mt(const GemmRowsArgs& a, int mt, int nw, hipStream_t st, int ntl = 1) {
+    const int n_tiles = a.N / (16 * ntl);
     const int n_grp = (a.M + 16 * mt - 1) / (16 * mt);
     const dim3 grid((unsigned)(n_tiles * n_grp));
-    if constexpr (KCH == 1) {
+    if constexpr (KCH == 1 && LN) {   // 32-column workgroups exist for the LN-prologue GEMMs (N = 3072 / 4096) at 16 or 32 rows
+        if (ntl == 2) {
+            AUR_REQUIRE(a.N % 32 == 0 && mt <= 2 && nw == 8, "gemm_rows: 32-column workgroups: 16 / 32 rows, 8 waves");
+            if (mt == 2) hipLaunchKernelGGL((gemm_rows_kernel<2, KCH, LN, EPI, 8, 2>), grid, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((gemm_rows_kernel<1, KCH, LN, EPI, 8, 2>), grid, dim3(512), 0, st, a);
+            return;
+        }
+    }
+    AUR_REQUIRE(ntl == 1, "gemm_rows: column tiles per workgroup");
+    if constexpr (KCH == 1) {   // (two chunk buffers of a 64-row tile do not fit the 128-VGPR budget: K = 4096 caps at 32 rows)
         if (mt == 4) {
             if (nw == 8) hipLaunchKernelGGL((gemm_rows_kernel<4, KCH, LN, EPI, 8>), grid, dim3(512), 0, st, a);
             else hipLaunchKernelGGL((gemm_rows_kernel<4, KCH, LN, EPI, 16>), grid, dim3(1024), 0, st, a);
@@ -433,9 +455,20 @@ void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream
     while (mt > 1 && ((a.M + 16 * mt - 1) / (16 * mt)) * (a.N / 16) < 192 && a.M > 16 * (mt / 2)) mt >>= 1;
     // LN-prologue GEMMs (tools/gemm_bench, M = 64, MI355X): 16-row workgroups for N = 3072 (11.8 us vs 14.6 at 64 rows: the
     // activation tile per workgroup shrinks 4x and L1 fill, ~40 B/clk/CU, is what bounds these kernels), 32 rows for N = 4096
-    if (ln) mt = (a.N >= 4096) ? 2 : 1;
+    // ... and 16 rows x 32 columns per workgroup for N = 4096 (11.7 us vs 12.7 for 32 x 16 and 13.8 for 64 x 16)
+    static const int ntl_env = [] {
+        const char* e = getenv("AUR_GEMM_ROWS_NTL");
+        return e ? atoi(e) : 0;
+    }();
+    int ntl = 1;
+    if (ln) {
+        mt = 1;
+        ntl = (a.N >= 4096 && nw == 8) ? 2 : 1;
+        if (ntl_env == 1 || (ntl_env == 2 && nw == 8 && a.N % 32 == 0)) ntl = ntl_env;
+    }
     while (mt > 1 && a.M <= 16 * (mt / 2)) mt >>= 1;
     if (mt_env == 1 || mt_env == 2 || mt_env == 4) mt = mt_env;
+    if (ntl == 2 && mt > 2) mt = 2;
     if (a.K == 4096 && mt > 2) mt = 2;
     static const int nt_env = [] {
         const char* e = getenv("AUR_GEMM_NT");
@@ -444,9 +477,9 @@ void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream
     GemmRowsArgs b = a;
     if (nt_env && (b.M + 16 * mt - 1) / (16 * mt) == 1) b.nt_w = 1;
     trace_launch("gemm_rows_kernel");
-    if (ln && epi == kEpiQkv) launch_gemm_rows_mt<1, true, kEpiQkv>(b, mt, nw, st);
-    else if (ln && epi == kEpiBiasGelu) launch_gemm_rows_mt<1, true, kEpiBiasGelu>(b, mt, nw, st);
-    else if (ln && epi == kEpiBias) launch_gemm_rows_mt<1, true, kEpiBias>(b, mt, nw, st);
+    if (ln && epi == kEpiQkv) launch_gemm_rows_mt<1, true, kEpiQkv>(b, mt, nw, st, ntl);
+    else if (ln && epi == kEpiBiasGelu) launch_gemm_rows_mt<1, true, kEpiBiasGelu>(b, mt, nw, st, ntl);
+    else if (ln && epi == kEpiBias) launch_gemm_rows_mt<1, true, kEpiBias>(b, mt, nw, st, ntl);
     else if (!ln && epi == kEpiResidual && a.K == 1024) launch_gemm_rows_mt<1, false, kEpiResidual>(b, mt, nw, st);
     else if (!ln && epi == kEpiResidual && a.K == 4096) launch_gemm_rows_mt<4, false, kEpiResidual>(b, mt, nw, st);
     else if (!ln && epi == kEpiBias && a.K == 1024) launch_gemm_rows_mt<1, false, kEpiBias>(b, mt, nw, st);

@@ -65,10 +65,10 @@ static float time_us(hipStream_t st, int iters, F&& f) {
     return ms * 1000.f / iters;
 }
 
-static void launch_variant(const GemmRowsArgs& a, const Shape& s, int mt, int nw, hipStream_t st) {
-    if (s.ln && s.epi == kEpiQkv) launch_gemm_rows_mt<1, true, kEpiQkv>(a, mt, nw, st);
-    else if (s.ln && s.epi == kEpiBiasGelu) launch_gemm_rows_mt<1, true, kEpiBiasGelu>(a, mt, nw, st);
-    else if (s.ln && s.epi == kEpiBias) launch_gemm_rows_mt<1, true, kEpiBias>(a, mt, nw, st);
+static void launch_variant(const GemmRowsArgs& a, const Shape& s, int mt, int nw, hipStream_t st, int ntl = 1) {
+    if (s.ln && s.epi == kEpiQkv) launch_gemm_rows_mt<1, true, kEpiQkv>(a, mt, nw, st, ntl);
+    else if (s.ln && s.epi == kEpiBiasGelu) launch_gemm_rows_mt<1, true, kEpiBiasGelu>(a, mt, nw, st, ntl);
+    else if (s.ln && s.epi == kEpiBias) launch_gemm_rows_mt<1, true, kEpiBias>(a, mt, nw, st, ntl);
     else if (s.K == 1024 && s.epi == kEpiResidual) launch_gemm_rows_mt<1, false, kEpiResidual>(a, mt, nw, st);
     else if (s.K == 4096 && s.epi == kEpiResidual) launch_gemm_rows_mt<4, false, kEpiResidual>(a, mt, nw, st);
     else if (s.K == 1024 && s.epi == kEpiBias) launch_gemm_rows_mt<1, false, kEpiBias>(a, mt, nw, st);
@@ -137,9 +137,11 @@ int main(int argc, char** argv) {
             launch_pack_wt16(wsrc, s.N, wt[r], s.K, s.N, st);
         }
         HIP_CHECK(hipStreamSynchronize(st));
-        for (int nt : {0, 1})
+        for (int ntl : {1, 2})
+        for (int nt : {0})
         for (int nw : {16, 8})
             for (int mt : {1, 2, 4}) {
+                if (ntl == 2 && !(s.ln && nw == 8 && mt <= 2)) continue;
                 if (nt && (M + 16 * mt - 1) / (16 * mt) != 1) continue;
                 if (s.K == 4096 && mt == 4) continue;
                 if (16 * (mt / 2) >= M && mt > 1) continue;
@@ -150,15 +152,15 @@ int main(int argc, char** argv) {
                 int it = 0;
                 const float us = time_us(st, 240, [&] {
                     a.Wt = wt[it++ % NREP];
-                    launch_variant(a, s, mt, nw, st);
+                    launch_variant(a, s, mt, nw, st, ntl);
                 });
                 const int n_grp = (M + 16 * mt - 1) / (16 * mt);
-                const int nwg = (s.N / 16) * n_grp;
+                const int nwg = (s.N / (16 * ntl)) * n_grp;
                 // phase stamps of one launch
                 HIP_CHECK(hipMemsetAsync(dprof, 0, (size_t)nwg * 64, st));
                 a.prof = dprof;
                 a.Wt = wt[5];
-                launch_variant(a, s, mt, nw, st);
+                launch_variant(a, s, mt, nw, st, ntl);
                 HIP_CHECK(hipStreamSynchronize(st));
                 std::vector<long long> hp((size_t)nwg * 8);
                 HIP_CHECK(hipMemcpy(hp.data(), dprof, hp.size() * 8, hipMemcpyDeviceToHost));
@@ -170,8 +172,8 @@ int main(int argc, char** argv) {
                     for (int k = 0; k < 5; ++k) ph[k] += (double)(hp[g * 8 + k + 1] - hp[g * 8 + k]) / nwg;
                 }
                 const double mb = 4.0 * ((double)s.K * s.N + (double)M * s.K + (double)M * s.N) / 1e6;
-                printf("%s M=%d nt=%d rows/wg=%2d waves=%2d wgs=%4d : %6.2f us/launch  %5.2f TB/s | cycles: span %6lld issue %5.0f ln+wait %6.0f mfma %6.0f bar %5.0f epi %5.0f\n",
-                       s.name, M, nt, 16 * mt, nw, nwg, us, mb / us, t_max - t_min, ph[0], ph[1], ph[2], ph[3], ph[4]);
+                printf("%s M=%d cols/wg=%d rows/wg=%2d waves=%2d wgs=%4d : %6.2f us/launch  %5.2f TB/s | cycles: span %6lld issue %5.0f ln+wait %6.0f mfma %6.0f bar %5.0f epi %5.0f\n",
+                       s.name, M, 16 * ntl, 16 * mt, nw, nwg, us, mb / us, t_max - t_min, ph[0], ph[1], ph[2], ph[3], ph[4]);
             }
         // reference: the round-1 split-K kernel on the same shape (slab sums not included)
         {
