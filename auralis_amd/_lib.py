@@ -51,10 +51,18 @@ class aur_stats(C.Structure):
                 ("conv_bytes", C.c_double), ("gemm_launches", C.c_int64), ("gemm_ms", C.c_double), ("gemm_ms_raw", C.c_double),
                 ("event_pair_overhead_ms", C.c_double), ("gemm_flops", C.c_double),
                 ("gemm_bytes", C.c_double), ("vocoder_ms", C.c_double), ("gpt_ms", C.c_double),
-                ("kv_blocks_total", C.c_int64), ("kv_blocks_free", C.c_int64)]
+                ("kv_blocks_total", C.c_int64), ("kv_blocks_free", C.c_int64),
+                ("gemm_kind_launches", C.c_int64 * 5), ("gemm_kind_ms", C.c_double * 5), ("gemm_kind_bytes", C.c_double * 5),
+                ("gemm_kind_flops", C.c_double * 5), ("attn_launches", C.c_int64), ("attn_ms", C.c_double),
+                ("attn_bytes", C.c_double), ("decode_steps", C.c_int64), ("decode_ms", C.c_double), ("prefill_ms", C.c_double),
+                ("decode_weight_bytes", C.c_double), ("decode_kv_bytes", C.c_double)]
 
     def as_dict(self) -> Dict[str, float]:
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        out = {}
+        for n, _ in self._fields_:
+            v = getattr(self, n)
+            out[n] = list(v) if hasattr(v, "__len__") else v
+        return out
 
 
 # every symbol include/auralis_amd.h declares (checked by tests/test_abi.py)

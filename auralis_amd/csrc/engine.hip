@@ -557,6 +557,7 @@ public:
             float ms = 0.f;
             HIP_CHECK(hipEventElapsedTime(&ms, ev_a_, ev_b_));
             stats_.gpt_ms += ms;
+            stats_.prefill_ms += ms;
             worked = true;
         }
         // 2. decode step for every running sequence (GPU time is accounted per collected step inside decode)
@@ -875,6 +876,12 @@ private:
     static int frames_for(int n_lat) { return (int)std::floor((double)(4 * n_lat) * (24000.0 / 22050.0)); }
 
     // ------------------------------------------------------------------ GPT
+    struct ConvEvent {
+        hipEvent_t a, b;
+        double flops, bytes;
+        bool used;
+        int kind;   // decode profile events: 0..4 = GEMM kind (aur_stats.gemm_kind_*), 5 = paged attention
+    };
     struct LayerW {
         const float *ln1w, *ln1b, *wqkv, *bqkv, *wproj, *bproj, *ln2w, *ln2b, *wfc, *bfc, *wproj2, *bproj2;
         const float *tqkv, *tproj, *tfc, *tproj2;   // pack_wt16 copies for the decode-regime GEMM (gemm_rows_kernel)
@@ -957,8 +964,9 @@ private:
             gemm_events_.push_back(e);
         }
         ConvEvent& ev = gemm_events_[n_gemm_events_++];
+        ev.kind = -1;
         ev.flops = 2.0 * M * N * K;
-        ev.bytes = 4.0 * ((double)K * N + (double)M * K + (double)pl.slabs * M * N);
+        ev.bytes = 4.0 * ((double)K * N + (double)M * K + (double)M * N);   // weights + X + Y (the split-K slabs are implementation traffic)
         HIP_CHECK(hipEventRecord(ev.a, w.st));
         const bool applied = launch_gemm_splitk(X, ldx, Wm, P, M, N, K, pl, w.st, gelu);
         HIP_CHECK(hipEventRecord(ev.b, w.st));
@@ -966,11 +974,7 @@ private:
     }
     // decode-regime GEMM launch (gemm_rows_kernel) with the same sampled event timing.  Algorithmic bytes of a launch:
     // weights once + the activation rows once + the output tile once (the residual epilogue reads and writes it).
-    void gemm_rows(RowWs& w, const GemmRowsArgs& a, bool ln, GemmRowsEpi epi) {
-        if (!gemm_prof_now_) {
-            launch_gemm_rows(a, ln, epi, w.st);
-            return;
-        }
+    ConvEvent& prof_event(int kind, double flops, double bytes) {
         if (n_gemm_events_ == gemm_events_.size()) {
             ConvEvent e{};
             HIP_CHECK(hipEventCreate(&e.a));
@@ -978,8 +982,18 @@ private:
             gemm_events_.push_back(e);
         }
         ConvEvent& ev = gemm_events_[n_gemm_events_++];
-        ev.flops = 2.0 * a.M * a.N * a.K;
-        ev.bytes = 4.0 * ((double)a.K * a.N + (double)a.M * a.K + (double)a.M * a.N * (epi == kEpiResidual ? 2.0 : 1.0));
+        ev.kind = kind;
+        ev.flops = flops;
+        ev.bytes = bytes;
+        return ev;
+    }
+    void gemm_rows(RowWs& w, const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, int kind) {
+        if (!gemm_prof_now_) {
+            launch_gemm_rows(a, ln, epi, w.st);
+            return;
+        }
+        ConvEvent& ev = prof_event(kind, 2.0 * a.M * a.N * a.K,
+                                   4.0 * ((double)a.K * a.N + (double)a.M * a.K + (double)a.M * a.N * (epi == kEpiResidual ? 2.0 : 1.0)));
         HIP_CHECK(hipEventRecord(ev.a, w.st));
         launch_gemm_rows(a, ln, epi, w.st);
         HIP_CHECK(hipEventRecord(ev.b, w.st));
@@ -1000,21 +1014,28 @@ private:
             a.X = h; a.xmt = mtt; a.Wt = L.tqkv; a.N = 3 * kHidden; a.K = kHidden; a.bias = L.bqkv;
             a.gamma = L.ln1w; a.beta = L.ln1b; a.stats_in = w.stats.as<float2>(); a.out = w.qbuf.as<float>(); a.ldo = kHidden;
             a.kv_layer = kvl; a.row_slot = d_row_slot; a.slot_kvpos = kvpos; a.block_tables = bt; a.max_blocks = kMaxBlocks;
-            gemm_rows(w, a, true, kEpiQkv);
-            launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, nullptr, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, mtt);
+            gemm_rows(w, a, true, kEpiQkv, 0);
+            if (gemm_prof_now_) {
+                ConvEvent& ev = prof_event(5, 4.0 * kHidden * step_kv_tokens_, 8.0 * kHidden * step_kv_tokens_ + 8.0 * kHidden * M);
+                HIP_CHECK(hipEventRecord(ev.a, w.st));
+                launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, nullptr, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, mtt);
+                HIP_CHECK(hipEventRecord(ev.b, w.st));
+            } else {
+                launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, nullptr, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, mtt);
+            }
             a = GemmRowsArgs{};
             a.M = M; a.X = w.att.as<float>(); a.xmt = mtt; a.Wt = L.tproj; a.N = kHidden; a.K = kHidden; a.bias = L.bproj;
             a.out = h; a.omt = mtt; a.stats_out = w.stats.as<float2>();
-            gemm_rows(w, a, false, kEpiResidual);
+            gemm_rows(w, a, false, kEpiResidual, 1);
             a = GemmRowsArgs{};
             a.M = M; a.eps = 1e-5f; a.X = h; a.xmt = mtt; a.Wt = L.tfc; a.N = 4 * kHidden; a.K = kHidden; a.bias = L.bfc;
             a.gamma = L.ln2w; a.beta = L.ln2b; a.stats_in = w.stats.as<float2>(); a.out = w.act.as<float>(); a.omt = mtt;
-            gemm_rows(w, a, true, kEpiBiasGelu);
+            gemm_rows(w, a, true, kEpiBiasGelu, 2);
             a = GemmRowsArgs{};
             a.M = M; a.X = w.act.as<float>(); a.xmt = mtt; a.Wt = L.tproj2; a.N = kHidden; a.K = 4 * kHidden; a.bias = L.bproj2;
             a.out = h; a.omt = mtt;
             if (l + 1 < cfg_.n_layer) a.stats_out = w.stats.as<float2>();   // (ln_f computes its own statistics in final_rows_kernel)
-            gemm_rows(w, a, false, kEpiResidual);
+            gemm_rows(w, a, false, kEpiResidual, 3);
         }
     }
     // Fixed cost of one HIP-event pair on an otherwise busy stream: recording events between back-to-back short
@@ -1042,11 +1063,24 @@ private:
         for (size_t i = 0; i < n_gemm_events_; ++i) {
             float ms = 0.f;
             HIP_CHECK(hipEventElapsedTime(&ms, gemm_events_[i].a, gemm_events_[i].b));
+            const ConvEvent& ev = gemm_events_[i];
+            if (ev.kind == 5) {
+                stats_.attn_ms += ms;
+                stats_.attn_bytes += ev.bytes;
+                stats_.attn_launches++;
+                continue;
+            }
+            if (ev.kind >= 0 && ev.kind < 5) {
+                stats_.gemm_kind_ms[ev.kind] += ms;
+                stats_.gemm_kind_bytes[ev.kind] += ev.bytes;
+                stats_.gemm_kind_flops[ev.kind] += ev.flops;
+                stats_.gemm_kind_launches[ev.kind]++;
+            }
             stats_.gemm_ms_raw += ms;
             ms = std::max(0.f, ms - ovh);
             stats_.gemm_ms += ms;
-            stats_.gemm_flops += gemm_events_[i].flops;
-            stats_.gemm_bytes += gemm_events_[i].bytes;
+            stats_.gemm_flops += ev.flops;
+            stats_.gemm_bytes += ev.bytes;
             stats_.gemm_launches++;
         }
         n_gemm_events_ = 0;
@@ -1133,7 +1167,7 @@ private:
         GemmRowsArgs a{};
         a.M = Ms; a.X = w.ybuf.as<float>(); a.xmt = mtt; a.Wt = thead_; a.N = kHeadPad; a.K = kHidden; a.bias = headb_;
         a.out = w.P2.as<float>(); a.ldo = kHeadPad;
-        gemm_rows(w, a, false, kEpiBias);
+        gemm_rows(w, a, false, kEpiBias, 4);
         SamplerArgs sa = sampler_args(w, w.P2.as<float>(), 1, Ms, kHeadPad, zero_bias_.as<float>(), nullptr);
         launch_sampler(sa, w.st);
     }
@@ -1358,6 +1392,15 @@ private:
             graph_ok_ = true;
         }
         pin_rb_[f.buf].ensure(((size_t)cfg_.max_seqs * 2 + 16) * sizeof(int));
+        // algorithmic bytes of this step: every live sequence's context (prompt + tokens so far, + 1 if the previous step is
+        // still in flight) in K and V, all layers; the weights once
+        step_kv_tokens_ = 0.0;
+        for (int slot : active) {
+            const Seq* sq = slot_owner_[slot];
+            step_kv_tokens_ += (double)(sq->n_prompt + (int)sq->tokens.size() + (infl_.on ? 1 : 0));
+        }
+        stats_.decode_kv_bytes += 8.0 * kHidden * step_kv_tokens_ * cfg_.n_layer;
+        stats_.decode_weight_bytes += 4.0 * ((double)cfg_.n_layer * 12.0 * kHidden * kHidden + (double)kHidden * kMelVocab);
         HIP_CHECK(hipEventRecord(ev_ds_[f.buf], st_));
         if (use_graph) {
             HIP_CHECK(hipGraphLaunch(graph_exec_, st_));
@@ -1390,6 +1433,8 @@ private:
         float ms = 0.f;
         HIP_CHECK(hipEventElapsedTime(&ms, ev_ds_[f.buf], ev_de_[f.buf]));
         stats_.gpt_ms += ms;
+        stats_.decode_ms += ms;
+        stats_.decode_steps++;
         stats_.decode_rows += rows;
         if (f.profiled) collect_gemm_events();
         f.on = false;
@@ -1491,11 +1536,6 @@ private:
     }
 
     // ------------------------------------------------------------------ vocoder
-    struct ConvEvent {
-        hipEvent_t a, b;
-        double flops, bytes;
-        bool used;
-    };
     void ensure_voc() {
         if (voc_ready_) return;
         const bool f16 = cfg_.vocoder_fp16 != 0;
@@ -1811,6 +1851,7 @@ private:
     std::vector<ConvEvent> gemm_events_;
     size_t n_gemm_events_ = 0;
     bool gemm_prof_now_ = false;
+    double step_kv_tokens_ = 0.0;       // sum of context lengths of the step being launched (profile accounting)
     long decode_step_count_ = 0;
     float event_overhead_ms_ = -1.f;
     std::vector<int> h_meta_;

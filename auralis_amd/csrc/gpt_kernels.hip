@@ -256,7 +256,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
     // packed rows: the float4 of lane `lane` for (16-row tile t, K block kb) is at ((kb * xmt + t) * 64 + lane); rows >= M of
     // the last tiles are allocated but undefined: their products stay in their own (never stored) output rows
     const f32x4* xp = reinterpret_cast<const f32x4*>(a.X) + (long)(mgrp * MT) * 64 + lane;
-    f32x4 bf[KCH > 1 ? 2 : 1][NTL][NB], af[KCH > 1 ? 2 : 1][MT][NB];
+    // K = 4096: three chunk buffers, i.e. the loads run two chunks (2 x 1024 of K) ahead of the MFMAs; with two buffers
+    // every chunk exposed a full memory latency (16 MFMAs = 512 cycles of cover per chunk: 12 us per launch at M = 32 and 64)
+    constexpr int NBUF = (KCH > 1) ? ((MT * NTL <= 1) ? 3 : 2) : 1;
+    f32x4 bf[NBUF][NTL][NB], af[NBUF][MT][NB];
     auto load_chunk = [&](int c, int buf) {
         const int kb0 = c * 64 + NB * w;
 #pragma unroll
@@ -314,11 +317,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
         }
     }
     if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 2] = (long long)__builtin_amdgcn_s_memtime();
+    if (NBUF == 3) load_chunk(1, 1);
 #pragma unroll
     for (int c = 0; c < KCH; ++c) {
-        const int cur = (KCH > 1) ? (c & 1) : 0;
-        if (c + 1 < KCH) load_chunk(c + 1, cur ^ 1);
-        if (!LN) __builtin_amdgcn_sched_barrier(0);   // the next chunk's loads are issued before this chunk's MFMAs
+        const int cur = c % NBUF;
+        if (c + NBUF - 1 < KCH) load_chunk(c + NBUF - 1, (c + NBUF - 1) % NBUF);
+        if (!LN) __builtin_amdgcn_sched_barrier(0);   // the next chunks' loads are issued before this chunk's MFMAs
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             if (LN) {   // k = 16*(NB*w + b) + 4q + s; normalised block by block so the MFMAs follow the data as it arrives

@@ -35,36 +35,188 @@ def _log(msg: str):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, n_tokens: int, budget_s: float = 30.0):
-    """Time the CPU oracle (kind 'port') on a bounded sample of the same workload: ONE utterance, greedy,
-    up to n_tokens mel tokens (prefill + decode + literal second pass + vocoder).  The decode loop stops early
-    when `budget_s` is used up, so the leg is bounded whatever the host looks like."""
+def cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, n_tokens: int = 280):
+    """CPU baseline (kind "port": the torch-CPU fp32 restatement of the reference path in oracle/) on this box's host cores.
+
+    Sample = BASELINE configs[1] (C2) IN FULL: one 200-char utterance, 70 text ids, greedy, `n_tokens` = 280 mel tokens ->
+    prefill + 279 decode steps + the reference's literal second pass (XTTSv2.py:617-687) + HiFi-GAN -> 312 064 samples,
+    with per-stage times; configs[0] (C1: 50-char utterance, 18 text ids, 70 tokens) is timed next to it.  The thread count
+    is swept first on an 8-token probe (more threads than the GEMV-sized matmuls can use makes the decode loop slower:
+    round 1 measured 0.35 s/token at 64 threads against 36 ms/token at 8) and the best one is used."""
     from oracle import xtts_oracle as O
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    torch.set_num_threads(max(1, min(cores, 64)))
     gpt = O.GPTOracle(gpt_sd, xtts_sd)
     w = O.vocoder_effective_weights(xtts_sd)
     c = gpt.build_cond(cond, text_ids)
-    t0 = time.perf_counter()
-    out = gpt.generate(c, O.SamplingCfg(temperature=0.0, max_tokens=8, ignore_stop=True))
-    t_probe = time.perf_counter() - t0
-    # scale the sample so that prefill + decode + second pass + vocoder stay near the budget
-    per_tok = max(1e-3, t_probe / 8.0)
-    n = int(max(8, min(n_tokens, budget_s / (3.0 * per_tok))))
-    _log(f"cpu_baseline: probe 8 tokens in {t_probe:.2f}s on {torch.get_num_threads()} threads -> sample {n} tokens")
-    t0 = time.perf_counter()
-    out = gpt.generate(c, O.SamplingCfg(temperature=0.0, max_tokens=n, ignore_stop=True))
-    t1 = time.perf_counter()
-    lat = gpt.second_pass_latents(c, out["tokens"])
-    t2 = time.perf_counter()
-    wav = O.hifi_decoder_forward(w, lat, spk)
-    t3 = time.perf_counter()
-    ns = wav.numel()
+    sweep = {}
+    for nt in sorted({t for t in (4, 8, 16, 32, 64) if t <= cores} | {min(cores, 8)}):
+        torch.set_num_threads(nt)
+        gpt.generate(c, O.SamplingCfg(temperature=0.0, max_tokens=2, ignore_stop=True))          # warm-up
+        t0 = time.perf_counter()
+        gpt.generate(c, O.SamplingCfg(temperature=0.0, max_tokens=8, ignore_stop=True))
+        sweep[nt] = (time.perf_counter() - t0) / 8.0
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    _log("cpu_baseline: thread sweep (s per token incl. prefill share) " + ", ".join(f"{k}: {v:.3f}" for k, v in sweep.items())
+         + f" -> {best} threads")
+
+    def run(ids, n):
+        cc = gpt.build_cond(cond, ids)
+        t0 = time.perf_counter()
+        out = gpt.generate(cc, O.SamplingCfg(temperature=0.0, max_tokens=n, ignore_stop=True))
+        t1 = time.perf_counter()
+        lat = gpt.second_pass_latents(cc, out["tokens"])
+        t2 = time.perf_counter()
+        wav = O.hifi_decoder_forward(w, lat, spk)
+        t3 = time.perf_counter()
+        ns = wav.numel()
+        return {"samples": ns, "wall_s": t3 - t0, "ar_tokens_s": t1 - t0, "second_pass_s": t2 - t1, "vocoder_s": t3 - t2,
+                "samples_per_s": ns / (t3 - t0), "rtf": (t3 - t0) / (ns / 24000.0)}
+
+    c2 = run(text_ids, n_tokens)
+    c1 = run(list(text_ids[:17]) + [text_ids[-1]], 70)
     return {
-        "value": ns / (t3 - t0), "unit": "audio-samples/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"1 utterance, 70 text tokens, {n} mel tokens greedy -> {ns} samples: prefill+decode "
-                  f"{t1 - t0:.2f}s, second pass {t2 - t1:.2f}s, vocoder {t3 - t2:.2f}s (torch CPU fp32 oracle)",
-        "rtf": (t3 - t0) / (ns / 24000.0),
+        "value": c2["samples_per_s"], "unit": "audio-samples/s", "cores": best, "kind": "port",
+        "sample": f"BASELINE configs[1] in full: 1 utterance, 70 text ids, {n_tokens} mel tokens greedy -> {c2['samples']} samples in "
+                  f"{c2['wall_s']:.2f} s (prefill + AR decode {c2['ar_tokens_s']:.2f} s, literal second pass "
+                  f"{c2['second_pass_s']:.2f} s, HiFi-GAN {c2['vocoder_s']:.2f} s); torch CPU fp32 oracle, {best} threads "
+                  f"(best of the sweep, box has {cores} cores)",
+        "rtf": c2["rtf"], "c2": c2, "c1_50char_70_tokens": c1, "thread_sweep_s_per_token": {str(k): v for k, v in sweep.items()},
+        "host_cores": cores,
+    }
+
+
+GEMM_KINDS = ["qkv (LN1 prologue, KV page write) [64x1024]x[1024x3072]", "attn proj (+residual) [64x1024]x[1024x1024]",
+              "fc (LN2 prologue, gelu) [64x1024]x[1024x4096]", "mlp proj (+residual) [64x4096]x[4096x1024]",
+              "mel head [64x1024]x[1024x1088]"]
+GEMM_KERNEL_RE = ["gemm_rows_kernel<.*true, 3", "gemm_rows_kernel<1, 1, false, 2", "gemm_rows_kernel<.*true, 1",
+                  "gemm_rows_kernel<1, 4, false, 2", "gemm_rows_kernel<1, 1, false, 0"]
+
+
+def _rocprof_avgs():
+    """Average kernel durations (us) of the committed rocprofv3 --kernel-trace --stats summary of this command."""
+    import csv
+    import glob
+    import re
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_bench_kernel_stats.csv")))
+    if not paths:
+        return None, {}
+    rows = {}
+    with open(paths[-1]) as f:
+        for r in csv.DictReader(f):
+            rows[r["Name"]] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)
+
+    def avg(pattern):
+        n = t = 0.0
+        for name, (calls, us) in rows.items():
+            if re.search(pattern, name):
+                n += calls
+                t += calls * us
+        return (t / n) if n else None
+    return os.path.relpath(paths[-1], ROOT), {"avg": avg}
+
+
+def _traffic():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    except Exception:
+        return {}
+
+
+def build_report(args, st, dims, world, samples, dt, audio_s):
+    prof_path, prof = _rocprof_avgs()
+    tj = _traffic()
+    pmc = tj.get("r02_decode", {})
+    avg = prof.get("avg", lambda _p: None)
+
+    def roof(kernel, ms, n, nbytes, flops, mfma_peak, rocprof_re, pmc_key, note):
+        ms_l = ms / max(1, n)
+        gbps = (nbytes / max(1, n)) / (ms_l * 1e-3) / 1e9 if ms_l > 0 else 0.0
+        r = {"kernel": kernel, "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+             "traffic": None,
+             "avg_launch_ms": ms_l, "launches_timed": n, "algorithmic_bytes_per_launch": nbytes / max(1, n), "note": note}
+        pm = pmc.get(pmc_key) if pmc_key else None
+        if pm:   # PMC FETCH_SIZE (x2) + WRITE_SIZE of the committed rocprofv3 --pmc passes of this command (profiles/hbm_traffic.json);
+            # the ratio to that run's algorithmic bytes carries over to this run's launch size (attention grows with the context)
+            r["traffic"] = pm["ratio_to_algorithmic"] * nbytes / max(1, n)
+            r["traffic_source"] = {"file": "profiles/hbm_traffic.json[r02_decode]", "measured_bytes_per_launch": pm["bytes_per_launch"],
+                                   "algorithmic_bytes_per_launch_in_that_run": pm["algorithmic_bytes_per_launch_in_that_run"],
+                                   "ratio": pm["ratio_to_algorithmic"]}
+        if flops:
+            tf = (flops / max(1, n)) / (ms_l * 1e-3) / 1e12 if ms_l > 0 else 0.0
+            r["mfma"] = {"achieved": tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tf / mfma_peak}
+        us = avg(rocprof_re) if rocprof_re else None
+        if us:
+            g2 = (nbytes / max(1, n)) / (us * 1e-6) / 1e9
+            r["rocprof"] = {"avg_launch_us": us, "achieved": g2, "frac": g2 / HBM_PEAK_GBPS, "source": prof_path}
+        return r
+
+    conv_kernel = "conv1d_mfma_f16_kernel" if args.vocoder == "fp16" else "conv1d_mfma_kernel"
+    # SURVEY 8(d) counts the vocoder's layer-granular activation traffic in fp32 (21 301 B per output sample); conv_bytes is the
+    # same accounting in the dtype each tensor is really stored in (the ResBlock intermediate is fp16)
+    roof_conv = roof(f"{conv_kernel} (HiFi-GAN convs, all instantiations)", st["conv_ms"], st["conv_launches"], st["conv_bytes"],
+                     st["conv_flops"], FP32_MFMA_PEAK_TFLOPS if args.vocoder == "fp32" else 2500.0, conv_kernel, None,
+                     "bytes counted as stored (fp32 activations, fp16 ResBlock intermediate)")
+    roof_conv["traffic"] = tj.get(f"conv_{args.vocoder}_bytes_per_launch")
+    if st["conv_ms"] > 0:
+        g = 21301.0 * samples / world / (st["conv_ms"] * 1e-3) / 1e9
+        roof_conv["survey_8d_fp32_bytes"] = {"bytes_per_sample": 21301, "achieved": g, "frac": g / HBM_PEAK_GBPS}
+    roof_attn = roof("paged_attention_kernel<false> (decode: one query row per sequence against its paged fp32 K/V)",
+                     st["attn_ms"], st["attn_launches"], st["attn_bytes"], 0.0, 1.0, r"paged_attention_kernel<false>", "attention",
+                     "algorithmic bytes = K and V rows of every live sequence's context (8 KiB per token per layer) + q + out")
+    gemms = []
+    for k in range(5):
+        gemms.append(roof("gemm_rows_kernel: " + GEMM_KINDS[k], st["gemm_kind_ms"][k], st["gemm_kind_launches"][k],
+                          st["gemm_kind_bytes"][k], st["gemm_kind_flops"][k], FP32_MFMA_PEAK_TFLOPS, GEMM_KERNEL_RE[k],
+                          ["gemm_qkv", "gemm_proj", "gemm_fc", "gemm_proj2", "gemm_head"][k],
+                          "algorithmic bytes = weights + activation rows in + rows out (fp32 as stored); exact-f32 MFMA"))
+    roof_gemm_all = roof("gemm_rows_kernel (all five decode GEMMs together)", st["gemm_ms_raw"], st["gemm_launches"], st["gemm_bytes"],
+                         st["gemm_flops"], FP32_MFMA_PEAK_TFLOPS, None, None, "family aggregate of the entries in decode_gemm_kernels")
+    # which single kernel has the most GPU time in the timed region?  (sampled per-launch averages x launches per step)
+    n_dec = max(1, st["decode_steps"])
+    est = {"attn": roof_attn["avg_launch_ms"] * args.layers * n_dec, "conv": st["conv_ms"]}
+    for k in range(4):
+        est[f"gemm{k}"] = gemms[k]["avg_launch_ms"] * args.layers * n_dec
+    top = max(est, key=est.get)
+    dominant = roof_attn if top == "attn" else roof_conv if top == "conv" else gemms[int(top[4:])]
+    dominant = dict(dominant, est_total_ms_in_timed_region=est[top], est_total_ms_of_candidates=est)
+    # whole decode step against the HBM roofline: weights once per step + K/V of every live context
+    dstep = None
+    if st["decode_steps"]:
+        ms = st["decode_ms"] / st["decode_steps"]
+        b32 = (st["decode_weight_bytes"] + st["decode_kv_bytes"]) / st["decode_steps"]
+        dstep = {"ms_per_step": ms, "steps": st["decode_steps"],
+                 "fp32_as_stored": {"bytes_per_step": b32, "achieved_GBps": b32 / ms / 1e6, "frac": b32 / ms / 1e6 / HBM_PEAK_GBPS},
+                 "survey_8d_fp16": {"bytes_per_step": b32 / 2, "achieved_GBps": b32 / 2 / ms / 1e6,
+                                    "frac": b32 / 2 / ms / 1e6 / HBM_PEAK_GBPS},
+                 "note": "fp32 weights and K/V are what this engine stores and streams (exact-f32 parity mode); SURVEY 8(d) quotes the "
+                         "reference GPU path's fp16 storage, i.e. half the bytes for the same step"}
+    return {
+        "metric": "audio_samples_per_s (64-way batch; rtf = wall_s / audio_s alongside)",
+        "value": samples / dt, "unit": "audio-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.vocoder == "fp32" else "f32 (GPT) + f16-in/f32-acc MFMA (vocoder convs)", "data": "synthetic",
+        "rtf": dt / audio_s, "audio_sec_per_wall_sec": audio_s / dt,
+        "config": {"workload": f"{args.batch} concurrent 200-char utterances per GPU (70 text tokens -> "
+                               f"{args.tokens} mel tokens fixed-length -> {dims.voc.samples_for_latents(args.tokens)} "
+                               f"samples each), T=0.75 top_p=0.85 top_k=50 rep_pen=5.0, shared speaker latent, "
+                               f"continuous batching; BASELINE.json configs[2]"
+                               + ("; consecutive steps pipelined (vocoder of batch k overlaps GPT of batch k+1)" if args.pipeline else ""),
+                   "utterances_per_gpu": args.batch, "mel_tokens": args.tokens, "gpt_layers": args.layers,
+                   "vocoder_mfma_inputs": args.vocoder,
+                   "parallelism": f"dp{world} (independent utterances, 1 RCCL broadcast of conditioning)"},
+        "roofline": dominant,
+        "roofline_second_kernel": roof_conv,
+        "decode_gemm_kernels": gemms,
+        "decode_gemm_family": roof_gemm_all,
+        "decode_attention": roof_attn,
+        "decode_step_roofline": dstep,
+        "event_pair_overhead_ms": st["event_pair_overhead_ms"],
+        "breakdown_ms_per_step": {"gpt": st["gpt_ms"] / args.steps, "gpt_prefill": st["prefill_ms"] / args.steps,
+                                  "gpt_decode": st["decode_ms"] / args.steps, "vocoder": st["vocoder_ms"] / args.steps,
+                                  "vocoder_convs": st["conv_ms"] / args.steps,
+                                  "gpt_ms_per_decode_step": st["decode_ms"] / max(1, st["decode_steps"]),
+                                  "gpt_ms_per_decode_step_incl_prefill_share": st["gpt_ms"] / max(1, st["steps"])},
     }
 
 
@@ -82,7 +234,7 @@ def main():
     ap.add_argument("--pipeline", action="store_true",
                     help="queue all steps at once so the vocoder of batch k overlaps the GPT of batch k+1 (measured "
                          "neutral on MI355X in fp32: both stages want the same CUs)")
-    ap.add_argument("--cpu-tokens", type=int, default=64)
+    ap.add_argument("--cpu-tokens", type=int, default=280, help="mel tokens of the CPU-baseline utterance (280 = C2 in full)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,74 +320,7 @@ def main():
 
     if rank == 0:
         audio_s = samples / 24000.0
-        conv_s = st["conv_ms"] * 1e-3
-        n_conv = max(1, st["conv_launches"])
-        # PMC-measured HBM bytes per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE passes, profiles/hbm_traffic.json; the
-        # counters cannot be read from inside this process)
-        traffic = gemm_traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.isfile(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get(f"conv_{args.vocoder}_bytes_per_launch")
-                if args.batch == 64 and args.layers == 30:
-                    gemm_traffic = tj.get("decode_gemm", {}).get("bytes_per_launch")
-            except Exception:
-                traffic = gemm_traffic = None
-        conv_kernel = "conv1d_mfma_f16_kernel" if args.vocoder == "fp16" else "conv1d_mfma_kernel"
-        conv_gbps = st["conv_bytes"] / conv_s / 1e9 if conv_s > 0 else 0.0
-        conv_tflops = st["conv_flops"] / conv_s / 1e12 if conv_s > 0 else 0.0
-        roof_conv = {
-            "kernel": f"{conv_kernel} (HiFi-GAN convs, all instantiations)",
-            "bound": "hbm", "achieved": conv_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": conv_gbps / HBM_PEAK_GBPS,
-            "traffic": traffic, "avg_launch_ms": st["conv_ms"] / n_conv, "launches": st["conv_launches"],
-            "algorithmic_bytes_per_launch": st["conv_bytes"] / n_conv, "total_ms_in_timed_region": st["conv_ms"],
-            "mfma": {"achieved": conv_tflops, "unit": "TFLOP/s",
-                     "peak": FP32_MFMA_PEAK_TFLOPS if args.vocoder == "fp32" else 2500.0,
-                     "frac": conv_tflops / (FP32_MFMA_PEAK_TFLOPS if args.vocoder == "fp32" else 2500.0)},
-        }
-        # decode GEMMs: HIP-event pairs around every launch of each 16th decode step (sampled)
-        # `achieved` uses the RAW event intervals (kernel + dispatch latency exposed by the event records: conservative);
-        # the empty-event-pair overhead and the overhead-corrected average are reported next to it, and the rocprofv3
-        # per-kernel average (pure execution time) is in profiles/.
-        gemm_s = st["gemm_ms_raw"] * 1e-3
-        n_gemm = max(1, st["gemm_launches"])
-        gemm_gbps = st["gemm_bytes"] / gemm_s / 1e9 if gemm_s > 0 else 0.0
-        gemm_tflops = st["gemm_flops"] / gemm_s / 1e12 if gemm_s > 0 else 0.0
-        est_gemm_total_ms = (st["gemm_ms"] / n_gemm) * 121.0 * max(0, st["steps"] - args.steps)   # overhead-corrected
-        roof_gemm = {
-            "kernel": "gemm_splitk_kernel<false> (decode QKV / proj / FC / proj2 / mel-head, M = live sequences)",
-            "bound": "hbm", "achieved": gemm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gemm_gbps / HBM_PEAK_GBPS,
-            "traffic": gemm_traffic, "avg_launch_ms": st["gemm_ms_raw"] / n_gemm, "avg_launch_ms_minus_event_overhead": st["gemm_ms"] / n_gemm,
-            "event_pair_overhead_ms": st["event_pair_overhead_ms"], "launches_sampled": st["gemm_launches"],
-            "algorithmic_bytes_per_launch": st["gemm_bytes"] / n_gemm, "total_ms_in_timed_region_est": est_gemm_total_ms,
-            "mfma": {"achieved": gemm_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": gemm_tflops / FP32_MFMA_PEAK_TFLOPS},
-            "note": "weights stream once per step (HBM) but at M = 64 exact-f32 MFMA time is of the same order; per-launch "
-                    "latency dominates (one 32x64x256 tile per workgroup, <= 2 workgroups per CU); traffic = weights once + "
-                    "the activation matrix once per XCD L2 (PMC, profiles/hbm_traffic.json)",
-        }
-        dominant, other = (roof_gemm, roof_conv) if est_gemm_total_ms > st["conv_ms"] else (roof_conv, roof_gemm)
-        line = {
-            "metric": "audio_samples_per_s (64-way batch; rtf = wall_s / audio_s alongside)",
-            "value": samples / dt, "unit": "audio-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.vocoder == "fp32" else "f32 (GPT) + f16-in/f32-acc MFMA (vocoder convs)", "data": "synthetic",
-            "rtf": dt / audio_s, "audio_sec_per_wall_sec": audio_s / dt,
-            "config": {"workload": f"{args.batch} concurrent 200-char utterances per GPU (70 text tokens -> "
-                                   f"{args.tokens} mel tokens fixed-length -> {dims.voc.samples_for_latents(args.tokens)} "
-                                   f"samples each), T=0.75 top_p=0.85 top_k=50 rep_pen=5.0, shared speaker latent, "
-                                   f"continuous batching; BASELINE.json configs[2]"
-                                   + ("; consecutive steps pipelined (vocoder of batch k overlaps GPT of batch k+1)" if args.pipeline else ""),
-                       "utterances_per_gpu": args.batch, "mel_tokens": args.tokens, "gpt_layers": args.layers,
-                       "vocoder_mfma_inputs": args.vocoder,
-                       "parallelism": f"dp{world} (independent utterances, 1 RCCL broadcast of conditioning)"},
-            "roofline": dominant,
-            "roofline_second_kernel": other,
-            "breakdown_ms_per_step": {"gpt": st["gpt_ms"] / args.steps, "vocoder": st["vocoder_ms"] / args.steps,
-                                      "vocoder_convs": st["conv_ms"] / args.steps,
-                                      "gpt_ms_per_decode_step": st["gpt_ms"] / max(1, st["steps"])},
-        }
+        line = build_report(args, st, dims, world, samples, dt, audio_s)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, args.cpu_tokens)
         else:

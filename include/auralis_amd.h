@@ -109,6 +109,22 @@ typedef struct aur_stats {
     double gpt_ms;                 /* prefill + decode + sampling, event-timed per step */
     int64_t kv_blocks_total;
     int64_t kv_blocks_free;
+    /* profile == 1, same sampled decode steps as gemm_*: per-kernel splits.  GEMM kinds: 0 qkv, 1 attn proj, 2 fc, 3 mlp proj,
+     * 4 mel head.  Times are raw HIP-event intervals on the launch stream; bytes are ALGORITHMIC (weights + activations in
+     * + activations out, fp32 as stored; attention: K and V rows of every live sequence's whole context + q + out). */
+    int64_t gemm_kind_launches[5];
+    double gemm_kind_ms[5];
+    double gemm_kind_bytes[5];
+    double gemm_kind_flops[5];
+    int64_t attn_launches;
+    double attn_ms;
+    double attn_bytes;
+    /* every decode step (not sampled): event time and algorithmic bytes of the whole step */
+    int64_t decode_steps;
+    double decode_ms;              /* embed .. sampler of the decode steps (gpt_ms = decode_ms + prefill_ms) */
+    double prefill_ms;
+    double decode_weight_bytes;    /* block + head weights, once per step, fp32 as stored */
+    double decode_kv_bytes;        /* K/V rows read by attention, all layers, fp32 as stored */
 } aur_stats;
 
 const char* aur_last_error(void);
