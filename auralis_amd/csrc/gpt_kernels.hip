@@ -240,15 +240,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
     const int n_tiles = a.N / (16 * NTL), n_grp = (a.M + 16 * MT - 1) / (16 * MT);
     int ntile, mgrp;
     {
+        // (the grid is padded to a multiple of 8 column tiles: the mel head has 68, and with the plain order its four row
+        // groups landed on four XCDs and pulled the weights from HBM four times: PMC 18.7 MB per launch for 4.5 MB of weights)
         const int L = blockIdx.x;
-        if ((n_tiles & 7) == 0) {
-            const int xcd = L & 7, slot = L >> 3;
-            mgrp = slot % n_grp;
-            ntile = (slot / n_grp) * 8 + xcd;
-        } else {
-            mgrp = L % n_grp;
-            ntile = L / n_grp;
-        }
+        const int xcd = L & 7, slot = L >> 3;
+        mgrp = slot % n_grp;
+        ntile = (slot / n_grp) * 8 + xcd;
+        if (ntile >= n_tiles) return;
     }
     const int n0 = ntile * 16 * NTL, m0 = mgrp * 16 * MT;
     const long wt_tile = (long)(a.K >> 4) * 64;   // float4s of one packed 16-column tile
@@ -256,9 +254,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
     // packed rows: the float4 of lane `lane` for (16-row tile t, K block kb) is at ((kb * xmt + t) * 64 + lane); rows >= M of
     // the last tiles are allocated but undefined: their products stay in their own (never stored) output rows
     const f32x4* xp = reinterpret_cast<const f32x4*>(a.X) + (long)(mgrp * MT) * 64 + lane;
-    // K = 4096: three chunk buffers, i.e. the loads run two chunks (2 x 1024 of K) ahead of the MFMAs; with two buffers
-    // every chunk exposed a full memory latency (16 MFMAs = 512 cycles of cover per chunk: 12 us per launch at M = 32 and 64)
-    constexpr int NBUF = (KCH > 1) ? ((MT * NTL <= 1) ? 3 : 2) : 1;
+    // K = 4096: two chunk buffers (the loads run one 1024-deep chunk ahead of the MFMAs).  Three buffers measured slower
+    // (13.6 vs 12.3 us at M = 64): the launch is bound by the 512 KB each workgroup pulls through its L1, not by latency.
+    constexpr int NBUF = (KCH > 1) ? 2 : 1;
     f32x4 bf[NBUF][NTL][NB], af[NBUF][MT][NB];
     auto load_chunk = [&](int c, int buf) {
         const int kb0 = c * 64 + NB * w;
@@ -406,7 +404,7 @@ template <int KCH, bool LN, int EPI>
 static void launch_gemm_rows_mt(const GemmRowsArgs& a, int mt, int nw, hipStream_t st, int ntl = 1) {
     const int n_tiles = a.N / (16 * ntl);
     const int n_grp = (a.M + 16 * mt - 1) / (16 * mt);
-    const dim3 grid((unsigned)(n_tiles * n_grp));
+    const dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * n_grp));   // whole groups of 8 column tiles (one per XCD); surplus workgroups exit
     if constexpr (KCH == 1 && LN) {   // 32-column workgroups exist for the LN-prologue GEMMs (N = 3072 / 4096) at 16 or 32 rows
         if (ntl == 2) {
             AUR_REQUIRE(a.N % 32 == 0 && mt <= 2 && nw == 8, "gemm_rows: 32-column workgroups: 16 / 32 rows, 8 waves");

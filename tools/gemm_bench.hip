@@ -155,7 +155,7 @@ int main(int argc, char** argv) {
                     launch_variant(a, s, mt, nw, st, ntl);
                 });
                 const int n_grp = (M + 16 * mt - 1) / (16 * mt);
-                const int nwg = (s.N / (16 * ntl)) * n_grp;
+                const int nwg = ((s.N / (16 * ntl) + 7) / 8 * 8) * n_grp;
                 // phase stamps of one launch
                 HIP_CHECK(hipMemsetAsync(dprof, 0, (size_t)nwg * 64, st));
                 a.prof = dprof;
