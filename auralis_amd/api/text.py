@@ -58,10 +58,50 @@ def split_sentence(text: str, lang: str, text_split_length: int = 250) -> List[s
     return [c[:-1] + " " if c.endswith(".") else c for c in chunks if c]
 
 
-class XTTSTokenizer:
-    """ids for one chunk.  bos/eos = [START]/[STOP]; synthetic stand-in uses ids 261/0 like the survey's fixture."""
+def preprocess_text(text: str, lang: str) -> str:
+    """XTTSTokenizerFast.preprocess_text (tokenizer.py:805-820): multilingual cleaners for the 15 alphabetic tags, then
+    romanisation for zh (pypinyin TONE3, tokenizer.py:727-730) and ko (hangul_romanize academic, :737-738); ja goes through
+    cutlet romaji + lowercase (:732-735); every other tag through basic_cleaners (lowercase + collapse whitespace, :721-725).
+    The BPE vocabulary is built on ROMANISED text: without the transliteration package the ids would be garbage, so a
+    missing package is an error, never a silent pass-through."""
+    from .cleaners import multilingual_cleaners
+    base = lang.split("-")[0]
+    if base in {"ar", "cs", "de", "en", "es", "fr", "hu", "it", "nl", "pl", "pt", "ru", "tr", "zh", "ko"}:
+        text = multilingual_cleaners(text, base)
+        if base == "zh":
+            try:
+                import pypinyin
+            except ImportError as e:
+                raise NotImplementedError("language 'zh-cn' needs the pypinyin package (pinyin transliteration before BPE, as "
+                                          "the reference does)") from e
+            text = "".join(p[0] for p in pypinyin.pinyin(text, style=pypinyin.Style.TONE3, heteronym=False,
+                                                          neutral_tone_with_five=True))
+        if base == "ko":
+            try:
+                from hangul_romanize import Transliter
+                from hangul_romanize.rule import academic
+            except ImportError as e:
+                raise NotImplementedError("language 'ko' needs the hangul_romanize package (romanisation before BPE, as the "
+                                          "reference does)") from e
+            text = Transliter(academic).translit(text)
+        return text
+    if base == "ja":
+        try:
+            import cutlet
+        except ImportError as e:
+            raise NotImplementedError("language 'ja' needs the cutlet package (romaji before BPE, as the reference does)") from e
+        return cutlet.Cutlet().romaji(text).lower()
+    return re.sub(r"\s+", " ", text.lower())
 
-    def __init__(self, tokenizer_file: Optional[str] = None, vocab_size: int = 6681):
+
+class XTTSTokenizer:
+    """ids for one chunk.  bos/eos = [START]/[STOP].
+
+    A real checkpoint needs its tokenizer.json (the reference loads it from the gpt_model repo): without one the constructor
+    raises.  `synthetic=True` selects a deterministic stand-in vocabulary (ids 261/0 as bos/eos like the survey's fixture)
+    for the seeded synthetic checkpoints of the tests and the bench; it is never chosen implicitly."""
+
+    def __init__(self, tokenizer_file: Optional[str] = None, vocab_size: int = 6681, synthetic: bool = False):
         self.vocab_size = vocab_size
         self._tok = None
         if tokenizer_file and os.path.isfile(tokenizer_file):
@@ -69,18 +109,24 @@ class XTTSTokenizer:
             self._tok = Tokenizer.from_file(tokenizer_file)
             self.bos_token_id = self._tok.token_to_id("[START]")
             self.eos_token_id = self._tok.token_to_id("[STOP]")
-        else:
+            if self.bos_token_id is None or self.eos_token_id is None:
+                raise ValueError(f"{tokenizer_file}: no [START] / [STOP] tokens (not an XTTS tokenizer.json)")
+        elif synthetic:
             self.bos_token_id, self.eos_token_id = 261, 0
+        else:
+            raise FileNotFoundError(
+                f"tokenizer.json not found ({tokenizer_file!r}): text ids for a real checkpoint need the XTTS BPE vocabulary "
+                "(AstraMindAI/xtts2-gpt ships it next to gpt2_model.safetensors); pass synthetic=True only for the seeded "
+                "synthetic checkpoints")
 
     def char_limit(self, lang: str) -> int:
         return CHAR_LIMITS.get(lang.split("-")[0], 250)
 
     def encode_chunk(self, text: str, lang: str) -> List[int]:
-        from .cleaners import multilingual_cleaners
         base = lang.split("-")[0]
         code = "zh-cn" if base == "zh" else base
-        clean = multilingual_cleaners(text, lang)           # tokenizer.py:708-719 order
-        s = f"[{code}]{clean}".replace(" ", "[SPACE]")
+        clean = preprocess_text(text, lang)                 # tokenizer.py:805-820
+        s = f"[{code}]{clean}".replace(" ", "[SPACE]")      # tokenizer.py:914-917
         if self._tok is not None:
             ids = self._tok.encode(s, add_special_tokens=False).ids
         else:

@@ -8,6 +8,7 @@ auralis_amd/conditioning.py, SURVEY §8f #1, on the GPU through PyTorch-ROCm), a
 from __future__ import annotations
 
 import asyncio
+import collections
 import hashlib
 import json
 import os
@@ -39,7 +40,8 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
                  gpt_max_audio_tokens: int = 605, conditioning_weights: Optional[dict] = None):
         self.native = native_engine
         self.conditioning_weights = conditioning_weights   # xtts-v2.safetensors tensors of the once-per-speaker modules
-        self._cond_cache = {}
+        self._cond_cache = collections.OrderedDict()   # LRU, bounded (a serving process sees an open-ended set of voices)
+        self._cond_cache_max = 64
         self.tokenizer = tokenizer
         self.max_concurrency = max_concurrency
         self.gpt_max_audio_tokens = gpt_max_audio_tokens
@@ -71,10 +73,15 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
             p = os.path.join(pretrained_model_name_or_path, cand)
             if os.path.isfile(p):
                 tok_file = p
+        synthetic_tok = False
+        cfg_path = os.path.join(pretrained_model_name_or_path, "core_xttsv2", "config.json")
+        if tok_file is None and os.path.isfile(cfg_path):
+            with open(cfg_path) as f:
+                synthetic_tok = bool(json.load(f).get("synthetic_tokenizer", False))
         vocab = xtts_sd["text_embedding.weight"].shape[0]
         cond_w = {k: v for k, v in xtts_sd.items()
                   if k.startswith(("conditioning_", "hifigan_decoder.speaker_encoder.", "mel_stats"))}
-        return cls(native, XTTSTokenizer(tok_file, vocab_size=vocab), max_concurrency=max_concurrency,
+        return cls(native, XTTSTokenizer(tok_file, vocab_size=vocab, synthetic=synthetic_tok), max_concurrency=max_concurrency,
                    conditioning_weights=cond_w if any(k.startswith("conditioning_encoder.") for k in cond_w) else None)
 
     @property
@@ -117,28 +124,47 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
                 raise NotImplementedError(
                     "this checkpoint carries no conditioning_encoder / perceiver / speaker_encoder weights: pass "
                     "precomputed conditioning (.npz or dict with gpt_cond_latent [1,32,1024], speaker_embedding [1,512,1])")
-            import hashlib as _h
-
             import torch
 
             from .. import conditioning as Cn
-            key = _h.blake2b(b"|".join(r.encode() if isinstance(r, str) else bytes(r[:4096]) + str(len(r)).encode()
-                                       for r in refs) + f"{max_ref_length}/{gpt_cond_len}/{gpt_cond_chunk_len}".encode(),
-                             digest_size=16).digest()
-            if key not in self._cond_cache:
+            # cache key = full content of every reference (a path is keyed by the bytes it holds now, not by its name) + every
+            # parameter that changes the result
+            hk = hashlib.blake2b(digest_size=16)
+            for r in refs:
+                if isinstance(r, (bytes, bytearray, memoryview)):
+                    data = bytes(r)
+                else:
+                    with open(r, "rb") as f:
+                        data = f.read()
+                hk.update(len(data).to_bytes(8, "little"))
+                hk.update(data)
+            hk.update(f"{max_ref_length}/{gpt_cond_len}/{gpt_cond_chunk_len}/{librosa_trim_db}/{sound_norm_refs}/{load_sr}".encode())
+            key = hk.digest()
+            if key in self._cond_cache:
+                self._cond_cache.move_to_end(key)
+            else:
                 dev = "cuda" if torch.cuda.is_available() else "cpu"
                 g_t, s_t = await asyncio.to_thread(Cn.get_conditioning_latents, self.conditioning_weights, refs,
                                                    max_ref_length, gpt_cond_len, gpt_cond_chunk_len, sound_norm_refs,
                                                    load_sr, dev)
                 self._cond_cache[key] = (g_t.float().cpu().numpy(), s_t.float().cpu().numpy())
+                while len(self._cond_cache) > self._cond_cache_max:
+                    self._cond_cache.popitem(last=False)
             g, s = self._cond_cache[key]
         g = np.asarray(getattr(g, "numpy", lambda: g)(), dtype=np.float32).reshape(1, 32, 1024)
         s = np.asarray(getattr(s, "numpy", lambda: s)(), dtype=np.float32).reshape(1, 512, 1)
         return g, s
 
     def _register_speaker(self, g: np.ndarray, s: np.ndarray) -> int:
+        """Content-addressed speaker key.  The engine's speaker table is bounded (aur_config.max_speakers) and evicts the least
+        recently used idle voice, so presence is asked of the engine itself (aur_has_conditioning, which also refreshes the
+        voice's LRU stamp) instead of being mirrored in an ever-growing Python dict; an evicted voice is simply re-registered."""
         key = int.from_bytes(hashlib.blake2b(g.tobytes() + s.tobytes(), digest_size=8).digest(), "little")
-        if key not in self._speakers:
+        has = getattr(self.native, "has_conditioning", None)
+        if has is not None:
+            if not has(key):
+                self.native.set_conditioning(key, g, s)
+        elif key not in self._speakers:   # engines without the query (test doubles)
             self.native.set_conditioning(key, g, s)
             self._speakers[key] = True
         return key
@@ -157,7 +183,9 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
         for idx, text_ids in enumerate(chunks):
             if request.seed is None:
                 self._seed_counter += 1
-                seed = (hash(request.request_id) ^ self._seed_counter) & 0xFFFFFFFF
+                # stable across processes (Python's hash() of a str is salted per process)
+                seed = (int.from_bytes(hashlib.blake2b(str(request.request_id).encode(), digest_size=4).digest(), "little")
+                        ^ self._seed_counter) & 0xFFFFFFFF
             else:
                 seed = (request.seed + idx) & 0xFFFFFFFF
             fut = self.driver.submit(loop, text_ids=text_ids, speaker_key=key, temperature=request.temperature,

@@ -204,7 +204,10 @@ def make_synthetic_text_ids(dims: XTTSDims, n_text: int = 70, seed: int = 11):
     return [261] + body + [0]
 
 
-def save_checkpoint(root: str, gpt_sd: Dict[str, Tensor], xtts_sd: Dict[str, Tensor], dims: XTTSDims) -> None:
+def save_checkpoint(root: str, gpt_sd: Dict[str, Tensor], xtts_sd: Dict[str, Tensor], dims: XTTSDims,
+                    synthetic_tokenizer: bool = False) -> None:
+    """Write the two safetensors + configs.  synthetic_tokenizer=True marks the directory as a seeded synthetic checkpoint
+    whose text ids come from the stand-in vocabulary (api/text.py); a real checkpoint must carry tokenizer.json instead."""
     from safetensors.torch import save_file
     os.makedirs(os.path.join(root, "gpt"), exist_ok=True)
     os.makedirs(os.path.join(root, "core_xttsv2"), exist_ok=True)
@@ -218,7 +221,8 @@ def save_checkpoint(root: str, gpt_sd: Dict[str, Tensor], xtts_sd: Dict[str, Ten
                    "stop_audio_token": dims.gpt.stop_token, "max_audio_tokens": dims.gpt.max_audio_tokens,
                    "activation_function": dims.gpt.activation}, f)
     with open(os.path.join(root, "core_xttsv2", "config.json"), "w") as f:
-        json.dump({"model_type": "xtts", "gpt_config": {"num_hidden_layers": n_layer}}, f)
+        json.dump({"model_type": "xtts", "gpt_config": {"num_hidden_layers": n_layer},
+                   **({"synthetic_tokenizer": True} if synthetic_tokenizer else {})}, f)
 
 
 def load_checkpoint(root: str) -> Tuple[Dict[str, Tensor], Dict[str, Tensor]]:

@@ -22,7 +22,7 @@ def test_config0_cpu_reference_path(dims):
     tokens -> second-pass latents (XTTSv2.py:617-687) -> HiFi-GAN -> 24 kHz waveform.  Deterministic, finite, right length."""
     text = "The quick brown fox jumps over the lazy dog today."
     assert len(text) == 50 and get_language(text) == "en"
-    tok = XTTSTokenizer(None)
+    tok = XTTSTokenizer(None, synthetic=True)
     chunks = split_sentence(text, "en", tok.char_limit("en"))
     assert chunks == [text]
     ids = tok.encode_chunk(chunks[0], "en")

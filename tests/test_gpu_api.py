@@ -14,7 +14,7 @@ def test_tts_facade_end_to_end(tmp_path, dims):
     sd = {k: v.clone() for k, v in gpt_sd.items()}
     sd["mel_head.bias"][1025] = 3.0      # let sequences stop naturally after a handful of tokens
     xtts_sd = make_synthetic_xtts(dims, seed=1234, gpt_sd=sd)
-    save_checkpoint(str(tmp_path), sd, xtts_sd, dims)
+    save_checkpoint(str(tmp_path), sd, xtts_sd, dims, synthetic_tokenizer=True)
     cond, spk = make_synthetic_conditioning(dims)
     voice = {"gpt_cond_latent": cond.numpy(), "speaker_embedding": spk.numpy()}
     text = ("The quick brown fox jumps over the lazy dog near the river bank. It was a bright cold day in April, and "

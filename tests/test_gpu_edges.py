@@ -133,3 +133,107 @@ def test_pipelined_decode_equals_synchronous(dims, monkeypatch):
     for x, y in zip(a, b):
         assert x["tokens"].tolist() == y["tokens"].tolist()
         assert np.array_equal(x["wav"], y["wav"]) and np.array_equal(x["latents"], y["latents"])
+
+
+def test_failed_step_releases_slots_blocks_and_engine_stays_usable(dims, monkeypatch):
+    """A throw inside aur_step (here injected: AUR_TEST_FAIL_STEP) fails the sequences that were in flight (error code in
+    their results, no audio), returns their slots / KV blocks / pool entries, keeps queued sequences, and the engine
+    goes on to produce the same output as a fresh one."""
+    ids = [make_synthetic_text_ids(dims, n_text=10 + k, seed=50 + k) for k in range(3)]
+    monkeypatch.delenv("AUR_TEST_FAIL_STEP", raising=False)
+    ref_e, *_ = make_engine(2, max_seqs=2)
+    try:
+        ref_e.submit(ids[2], SPK_KEY, temperature=0.0, max_tokens=12, ignore_stop=True)
+        ref = ref_e.run_until_done()[0]
+    finally:
+        ref_e.close()
+    monkeypatch.setenv("AUR_TEST_FAIL_STEP", "3")
+    e, *_ = make_engine(2, max_seqs=2)
+    try:
+        sids = [e.submit(i, SPK_KEY, temperature=0.0, max_tokens=12, ignore_stop=True) for i in ids]   # 2 slots: the third waits
+        e.step()
+        e.step()
+        with pytest.raises(AurError) as ei:
+            e.step()
+        assert ei.value.code == -2 and "injected" in str(ei.value)
+        failed = e.poll()
+        assert sorted(o["seq_id"] for o in failed) == sids[:2]
+        assert all(o["error"] == -2 and len(o["wav"]) == 0 for o in failed)
+        outs = e.run_until_done()                                      # the queued sequence is admitted and finishes
+        assert [o["seq_id"] for o in outs] == [sids[2]] and outs[0]["error"] == 0
+        assert outs[0]["tokens"].tolist() == ref["tokens"].tolist() and np.array_equal(outs[0]["wav"], ref["wav"])
+        st = e.stats()
+        assert st["kv_blocks_total"] - st["kv_blocks_free"] == 2        # only the speaker's shared prefix blocks
+        e.submit(ids[0], SPK_KEY, temperature=0.0, max_tokens=5, ignore_stop=True)
+        assert len(e.run_until_done()[0]["tokens"]) == 5
+    finally:
+        e.close()
+
+
+def test_speaker_table_evicts_lru_idle_voice_and_pins_busy_ones(dims):
+    """aur_config.max_speakers voices at most; a new key evicts the least recently used voice without undelivered
+    sequences (its prefix KV blocks are recycled), never a busy one; an evicted key must be registered again."""
+    e, _, _, cond, spk = make_engine(2, max_seqs=2, max_speakers=2)      # SPK_KEY holds 1 of the 2 rows
+    try:
+        g = torch.Generator().manual_seed(5)
+
+        def voice():
+            c = torch.randn(1, 32, 1024, generator=g) * 0.02
+            s = torch.randn(1, 512, 1, generator=g)
+            return c.numpy(), (s / s.norm()).numpy()
+        v1, v2, v3 = voice(), voice(), voice()
+        ids = make_synthetic_text_ids(dims, n_text=12, seed=4)
+        e.set_conditioning(1001, *v1)
+        e.submit(ids, 1001, temperature=0.0, max_tokens=8, ignore_stop=True)
+        first = e.run_until_done()[0]
+        assert e.has_conditioning(SPK_KEY) and e.has_conditioning(1001)   # (the queries refresh the LRU stamps: 1001 newest)
+        assert e.has_conditioning(SPK_KEY)                                # SPK_KEY newest, 1001 is now the LRU voice
+        e.set_conditioning(1002, *v2)                                     # table full -> evicts 1001
+        assert not e.has_conditioning(1001) and e.has_conditioning(1002) and e.has_conditioning(SPK_KEY)
+        with pytest.raises(AurError):
+            e.submit(ids, 1001, max_tokens=4)
+        e.submit(ids, SPK_KEY, temperature=0.0, max_tokens=20, ignore_stop=True)
+        e.submit(ids, 1002, temperature=0.0, max_tokens=20, ignore_stop=True)
+        e.step()
+        with pytest.raises(AurError) as ei:                               # both voices have undelivered sequences
+            e.set_conditioning(1003, *v3)
+        assert ei.value.code == -3 and "speaker table full" in str(ei.value)
+        assert len(e.run_until_done()) == 2
+        e.set_conditioning(1001, *v1)                                     # back in, on a recycled row and prefix blocks
+        e.submit(ids, 1001, temperature=0.0, max_tokens=8, ignore_stop=True)
+        again = e.run_until_done()[0]
+        assert again["tokens"].tolist() == first["tokens"].tolist() and np.array_equal(again["wav"], first["wav"])
+    finally:
+        e.close()
+
+
+def test_rccl_world1_broadcast_and_device_pointer_registration_equal_host_path(dims):
+    """The multi-GPU leg on one GPU: torch.distributed "nccl" (= RCCL) with world_size 1, the conditioning broadcast into a
+    device buffer, aur_set_conditioning_device on that buffer: tokens and audio equal the host-pointer registration."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from auralis_amd.parallel import broadcast_conditioning
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    e, _, _, cond, spk = make_engine(2, max_seqs=2)
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        ids = make_synthetic_text_ids(dims, n_text=15, seed=8)
+        e.submit(ids, SPK_KEY, temperature=0.8, top_k=50, top_p=0.85, max_tokens=14, seed=3, ignore_stop=True)
+        host = e.run_until_done()[0]
+        buf = broadcast_conditioning(e, 777, cond, spk, src=0, device=torch.device("cuda", 0))
+        assert buf.is_cuda and buf.numel() == 32 * 1024 + 512 and e.has_conditioning(777)
+        e.submit(ids, 777, temperature=0.8, top_k=50, top_p=0.85, max_tokens=14, seed=3, ignore_stop=True)
+        dev = e.run_until_done()[0]
+        assert dev["tokens"].tolist() == host["tokens"].tolist() and np.array_equal(dev["wav"], host["wav"])
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        e.close()

@@ -68,7 +68,7 @@ def test_split_sentence_respects_limit_and_keeps_words():
 
 
 def test_tokenizer_contract():
-    tok = XTTSTokenizer(None, vocab_size=6681)
+    tok = XTTSTokenizer(None, vocab_size=6681, synthetic=True)
     ids = tok.encode_chunk("Hello world", "en")
     assert ids[0] == tok.bos_token_id and ids[-1] == tok.eos_token_id
     assert all(0 <= i < 6681 for i in ids) and ids == tok.encode_chunk("Hello world", "en")
@@ -126,7 +126,7 @@ def test_driver_resolves_futures_and_fails_loudly():
 
 def _tts(fake=None):
     fake = fake or FakeNativeEngine(max_seqs=3)
-    eng = XTTSv2Engine(fake, XTTSTokenizer(None), max_concurrency=3)
+    eng = XTTSv2Engine(fake, XTTSTokenizer(None, synthetic=True), max_concurrency=3)
     return TTS(scheduler_max_concurrency=3).with_engine(eng), fake
 
 
@@ -185,7 +185,7 @@ def test_wav_reference_goes_through_conditioning_encoders(tmp_path, dims):
     w = make_synthetic_conditioning_weights(dims, seed=5)
     w["mel_stats"] = __import__("torch").ones(80)
     fake = FakeNativeEngine(max_seqs=3)
-    eng = XTTSv2Engine(fake, XTTSTokenizer(None), max_concurrency=3, conditioning_weights=w)
+    eng = XTTSv2Engine(fake, XTTSTokenizer(None, synthetic=True), max_concurrency=3, conditioning_weights=w)
     tts = TTS(scheduler_max_concurrency=3).with_engine(eng)
     try:
         for ref in (str(tmp_path / "v.wav"), (tmp_path / "v.wav").read_bytes()):
@@ -202,3 +202,134 @@ def test_registry_and_from_pretrained_errors(tmp_path):
     assert MODEL_REGISTRY["xtts"] is XTTSv2Engine
     with pytest.raises(FileNotFoundError):
         TTS().from_pretrained(str(tmp_path))
+
+
+# ---------------------------------------------------------------------------------------------------------- text front-end
+def test_tokenizer_requires_tokenizer_json_unless_synthetic(tmp_path):
+    """No silent stand-in vocabulary for a real checkpoint (the converter's output carries no tokenizer.json)."""
+    with pytest.raises(FileNotFoundError):
+        XTTSTokenizer(None)
+    with pytest.raises(FileNotFoundError):
+        XTTSTokenizer(str(tmp_path / "tokenizer.json"))
+    assert XTTSTokenizer(None, synthetic=True).bos_token_id == 261
+
+
+def test_tokenizer_json_branch_matches_the_bpe_file():
+    """ids = BPE("[lang]" + cleaned text with " " -> "[SPACE]") wrapped in [START]/[STOP] (tokenizer.py:914-917,
+    XTTSv2.py:520-521), on a small committed BPE file with the XTTS special tokens."""
+    import os
+
+    from tokenizers import Tokenizer
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_xtts_tokenizer.json")
+    tok = XTTSTokenizer(path)
+    raw = Tokenizer.from_file(path)
+    assert (tok.bos_token_id, tok.eos_token_id) == (raw.token_to_id("[START]"), raw.token_to_id("[STOP]"))
+    ids = tok.encode_chunk("Hello there, my Friend", "en")
+    want = raw.encode("[en]hello[SPACE]there,[SPACE]my[SPACE]friend", add_special_tokens=False).ids
+    assert ids == [tok.bos_token_id] + want + [tok.eos_token_id]
+    assert raw.token_to_id("[SPACE]") in ids and raw.token_to_id("[en]") == ids[1]
+    ids_fr = tok.encode_chunk("Bonjour mon ami", "fr")
+    assert ids_fr[1] == raw.token_to_id("[fr]")
+    chunks = tok.batch_encode_with_split(" ".join([PARA] * 3), "en")
+    assert len(chunks) >= 3 and all(c[0] == tok.bos_token_id and c[-1] == tok.eos_token_id for c in chunks)
+
+
+@pytest.mark.parametrize("lang,pkg,text", [("zh-cn", "pypinyin", "你好世界"), ("ja", "cutlet", "こんにちは世界"),
+                                           ("ko", "hangul_romanize", "안녕하세요")])
+def test_cjk_needs_transliteration_never_raw_ids(lang, pkg, text):
+    """zh / ja / ko are romanised before BPE (tokenizer.py:805-820); without the package the call fails loudly."""
+    import importlib.util
+
+    from auralis_amd.api.text import preprocess_text
+    if importlib.util.find_spec(pkg) is None:
+        with pytest.raises(NotImplementedError) as ei:
+            XTTSTokenizer(None, synthetic=True).encode_chunk(text, lang)
+        assert pkg in str(ei.value)
+    else:
+        out = preprocess_text(text, lang)
+        assert out and all(ord(c) < 0x3000 for c in out)
+
+
+def test_other_tags_use_basic_cleaners():
+    from auralis_amd.api.text import preprocess_text
+    assert preprocess_text("  NaMaSte   DUNIYA ", "hi") == " namaste duniya "
+
+
+# ---------------------------------------------------------------------------------------------------------- conditioning cache
+def test_conditioning_cache_keys_on_full_content_and_parameters(tmp_path, dims, monkeypatch):
+    """Two references that share length and their first bytes must not collide; a path is keyed by what it holds now;
+    every conditioning parameter is part of the key."""
+    import torch
+
+    from auralis_amd import conditioning as Cn
+    calls = []
+
+    def fake_latents(w, refs, max_ref_length, gpt_cond_len, gpt_cond_chunk_len, sound_norm_refs, load_sr, dev):
+        calls.append((len(refs), gpt_cond_len, sound_norm_refs))
+        k = float(len(calls))
+        return torch.full((1, 32, 1024), k), torch.full((1, 512, 1), k)
+    monkeypatch.setattr(Cn, "get_conditioning_latents", fake_latents)
+    eng = XTTSv2Engine(FakeNativeEngine(max_seqs=2), XTTSTokenizer(None, synthetic=True), conditioning_weights={"x": 1})
+    try:
+        head = b"RIFF" + bytes(8000)
+        a, b = head + b"\\x01" * 4000, head + b"\\x02" * 4000           # same length, same first 8 KB
+        run = lambda *args, **kw: asyncio.run(eng.get_audio_conditioning(*args, **kw))
+        ga, _ = run([a])
+        gb, _ = run([b])
+        assert len(calls) == 2 and float(ga[0, 0, 0]) != float(gb[0, 0, 0])
+        run([a])
+        assert len(calls) == 2                                       # cached
+        run([a], gpt_cond_len=3)
+        run([a], sound_norm_refs=True)
+        assert len(calls) == 4                                       # parameters are part of the key
+        p = tmp_path / "v.wav"
+        p.write_bytes(a)
+        run([str(p)])
+        assert len(calls) == 4                                       # same bytes as `a`: cache hit through the path
+        p.write_bytes(b"RIFF" + bytes(9000))
+        run([str(p)])
+        assert len(calls) == 5                                       # file replaced -> recomputed
+        eng._cond_cache_max = 2
+        run([b"RIFF" + bytes(100)])
+        assert len(eng._cond_cache) <= 2                             # bounded
+    finally:
+        asyncio.run(eng.shutdown())
+
+
+def test_evicted_speaker_is_registered_again():
+    """The engine's speaker table is bounded and evicts idle voices: registration asks the engine, not a Python mirror."""
+    class EvictingFake(FakeNativeEngine):
+        def has_conditioning(self, key):
+            return key in self.speakers
+
+        def set_conditioning(self, key, g, s):
+            if len(self.speakers) >= 1:
+                self.speakers.clear()                                 # capacity 1: every new voice evicts the old one
+            super().set_conditioning(key, g, s)
+            self.registrations = getattr(self, "registrations", 0) + 1
+    fake = EvictingFake(max_seqs=2)
+    eng = XTTSv2Engine(fake, XTTSTokenizer(None, synthetic=True))
+    try:
+        g1, s1 = np.ones((1, 32, 1024), np.float32), np.ones((1, 512, 1), np.float32)
+        g2 = g1 * 2
+        k1 = eng._register_speaker(g1, s1)
+        k2 = eng._register_speaker(g2, s1)
+        assert k1 != k2 and fake.registrations == 2
+        assert eng._register_speaker(g2, s1) == k2 and fake.registrations == 2      # still resident
+        assert eng._register_speaker(g1, s1) == k1 and fake.registrations == 3      # was evicted -> registered again
+    finally:
+        asyncio.run(eng.shutdown())
+
+
+def test_default_seeds_do_not_depend_on_the_process_hash_salt():
+    import subprocess
+    import sys
+    code = ("import hashlib;rid='req-42';"
+            "print(int.from_bytes(hashlib.blake2b(rid.encode(),digest_size=4).digest(),'little'))")
+    a = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env={"PYTHONHASHSEED": "1"}).stdout
+    b = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env={"PYTHONHASHSEED": "2"}).stdout
+    assert a == b and a.strip().isdigit()
+    import inspect
+
+    from auralis_amd.api import xtts_engine
+    assert "hash(request.request_id)" not in inspect.getsource(xtts_engine)

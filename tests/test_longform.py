@@ -27,7 +27,7 @@ def test_longform_requests_and_order_cpu():
     reqs = build_requests(paras, [VOICE], seed=7)
     assert [r.language for r in reqs] == ["en", "fr", "de", "en", "fr", "de"]
     fake = FakeNativeEngine(max_seqs=3)
-    tts = TTS(scheduler_max_concurrency=3).with_engine(XTTSv2Engine(fake, XTTSTokenizer(None)))
+    tts = TTS(scheduler_max_concurrency=3).with_engine(XTTSv2Engine(fake, XTTSTokenizer(None, synthetic=True)))
     try:
         got = list(stream_longform(tts, reqs, window=3))
         idx = [i for i, _ in got]
@@ -44,7 +44,7 @@ def test_longform_mixed_languages_gpu(tmp_path, dims):
     from auralis_amd.checkpoint import make_synthetic_conditioning, make_synthetic_gpt, make_synthetic_xtts, save_checkpoint
     gpt_sd = make_synthetic_gpt(dims.gpt, seed=1234, n_layer=2)
     gpt_sd["mel_head.bias"][1025] = 3.0          # natural stops after a handful of tokens
-    save_checkpoint(str(tmp_path), gpt_sd, make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd), dims)
+    save_checkpoint(str(tmp_path), gpt_sd, make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd), dims, synthetic_tokenizer=True)
     cond, spk = make_synthetic_conditioning(dims)
     voice = {"gpt_cond_latent": cond.numpy(), "speaker_embedding": spk.numpy()}
     reqs = build_requests(split_paragraphs(BOOK), [voice], seed=3, temperature=0.0)
@@ -70,7 +70,7 @@ def test_book_scale_stream_host_overhead():
         paras += [EN, FR, DE]
     reqs = build_requests(paras, [VOICE], seed=1)
     fake = FakeNativeEngine(max_seqs=64)
-    tts = TTS(scheduler_max_concurrency=64).with_engine(XTTSv2Engine(fake, XTTSTokenizer(None)))
+    tts = TTS(scheduler_max_concurrency=64).with_engine(XTTSv2Engine(fake, XTTSTokenizer(None, synthetic=True)))
     try:
         t0 = time.perf_counter()
         idx = [i for i, _ in stream_longform(tts, reqs, window=32)]
@@ -93,13 +93,25 @@ def _sharded_worker(rank, world, port, out_dir):
     paras = [EN, FR, DE] * 9 + [EN[:100]]
     reqs = build_requests(paras, [VOICE], seed=1)
     fake = FakeNativeEngine(max_seqs=4)
-    tts = TTS(scheduler_max_concurrency=4).with_engine(XTTSv2Engine(fake, XTTSTokenizer(None)))
+    tts = TTS(scheduler_max_concurrency=4).with_engine(XTTSv2Engine(fake, XTTSTokenizer(None, synthetic=True)))
+    import time
+
+    from auralis_amd.longform import stream_sharded
     try:
         out = synthesize_sharded(tts, reqs, window=3, paragraphs_per_block=4)
+        # streamed form: rank 0 must hand out the first chunk long before the last one exists anywhere
+        t0 = time.perf_counter()
+        stamps, idx, total = [], [], 0
+        for i, pcm in stream_sharded(tts, reqs, window=3, paragraphs_per_block=4):
+            stamps.append(time.perf_counter() - t0)
+            idx.append(i)
+            total += len(pcm)
+        t_end = time.perf_counter() - t0
     finally:
         tts.close()
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), n=np.int64(-1 if out is None else len(out.array)),
-             submitted=np.int64(len(fake.submitted)))
+             submitted=np.int64(len(fake.submitted)), idx=np.asarray(idx, np.int64), stamps=np.asarray(stamps),
+             t_end=np.float64(t_end), streamed=np.int64(total))
     dist.destroy_process_group()
 
 
@@ -115,12 +127,18 @@ def test_sharded_book_on_two_ranks_gloo(tmp_path):
     paras = [EN, FR, DE] * 9 + [EN[:100]]
     reqs = build_requests(paras, [VOICE], seed=1)
     fake = FakeNativeEngine(max_seqs=4)
-    tts = TTS(scheduler_max_concurrency=4).with_engine(XTTSv2Engine(fake, XTTSTokenizer(None)))
+    tts = TTS(scheduler_max_concurrency=4).with_engine(XTTSv2Engine(fake, XTTSTokenizer(None, synthetic=True)))
     try:
         single = TTSOutput.combine_outputs([c for _, c in stream_longform(tts, reqs, window=3)])
     finally:
         tts.close()
     r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
     assert int(r1["n"]) == -1 and int(r0["n"]) == len(single.array)           # same audio length as one process
-    assert int(r0["submitted"]) + int(r1["submitted"]) == len(fake.submitted)  # every chunk synthesised exactly once
+    assert int(r0["submitted"]) + int(r1["submitted"]) == 2 * len(fake.submitted)  # (two passes) every chunk exactly once per pass
     assert int(r0["submitted"]) > 0 and int(r1["submitted"]) > 0
+    # streamed pass: chunks of all 28 paragraphs in paragraph order on rank 0, nothing on rank 1, same amount of audio,
+    # and the first chunk is out well before the book is finished (ordered re-emission, not an end-of-book gather)
+    idx = r0["idx"].tolist()
+    assert idx == sorted(idx) and sorted(set(idx)) == list(range(len(paras))) and len(r1["idx"]) == 0
+    assert len(idx) == sum(_expected_chunks(reqs)) and int(r0["streamed"]) == len(single.array)
+    assert r0["stamps"][0] < 0.5 * float(r0["t_end"])

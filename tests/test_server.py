@@ -21,7 +21,7 @@ def _npz_voice():
 
 
 def test_speech_endpoint_roundtrip(tmp_path):
-    tts = TTS(scheduler_max_concurrency=2).with_engine(XTTSv2Engine(FakeNativeEngine(max_seqs=2), XTTSTokenizer(None)))
+    tts = TTS(scheduler_max_concurrency=2).with_engine(XTTSv2Engine(FakeNativeEngine(max_seqs=2), XTTSTokenizer(None, synthetic=True)))
     try:
         client = fastapi_testclient.TestClient(create_app(tts))
         r = client.post("/v1/audio/speech", json={"input": "Hello from the server side of things.", "model": "xtts",
