@@ -170,7 +170,8 @@ public:
         const int S = cfg_.max_seqs;
         n_blocks_ = (long)S * kMaxBlocks + 2L * cfg_.max_speakers;   // + 2 shared prefix blocks per speaker
         kv_layer_stride_ = n_blocks_ * kKvBlockElems;
-        kv_.ensure((size_t)cfg_.n_layer * kv_layer_stride_ * sizeof(float));
+        kv_half_ = cfg_.kv_fp16 != 0;
+        kv_.ensure((size_t)cfg_.n_layer * kv_layer_stride_ * (kv_half_ ? 2 : 4));
         for (int b = (int)n_blocks_ - 1; b >= 0; --b) free_blocks_.push_back(b);
         auto ints = [&](DevBuf& b, size_t n) {
             b.ensure(n * sizeof(int));
@@ -209,6 +210,7 @@ public:
         if (const char* e = getenv("AUR_SAMPLER_FULL_SORT")) sampler_full_sort_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_FUSE_GELU")) fuse_gelu_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_DECODE_GEMM")) rows_gemm_ = std::string(e) != "splitk";
+        AUR_REQUIRE(rows_gemm_ || !kv_half_, "kv_fp16 needs the gemm_rows decode chain (AUR_DECODE_GEMM=splitk keeps fp32 K/V)");
         if (const char* e = getenv("AUR_TEST_FAIL_STEP")) fail_at_step_ = atoi(e);
 
         for (int i = 0; i < 2; ++i) {
@@ -1008,20 +1010,20 @@ private:
         const int mtt = w.rows_cap / 16;   // h, att, act are packed rows (pk_off) with this many 16-row tiles
         for (int l = 0; l < cfg_.n_layer; ++l) {
             const LayerW& L = layers_[l];
-            float* kvl = kv_.as<float>() + (long)l * kv_layer_stride_;
+            void* kvl = kv_layer(l);
             GemmRowsArgs a{};
             a.M = M; a.eps = 1e-5f;
             a.X = h; a.xmt = mtt; a.Wt = L.tqkv; a.N = 3 * kHidden; a.K = kHidden; a.bias = L.bqkv;
             a.gamma = L.ln1w; a.beta = L.ln1b; a.stats_in = w.stats.as<float2>(); a.out = w.qbuf.as<float>(); a.ldo = kHidden;
-            a.kv_layer = kvl; a.row_slot = d_row_slot; a.slot_kvpos = kvpos; a.block_tables = bt; a.max_blocks = kMaxBlocks;
+            a.kv_layer = kvl; a.kv_half = kv_half_ ? 1 : 0; a.row_slot = d_row_slot; a.slot_kvpos = kvpos; a.block_tables = bt; a.max_blocks = kMaxBlocks;
             gemm_rows(w, a, true, kEpiQkv, 0);
             if (gemm_prof_now_) {
-                ConvEvent& ev = prof_event(5, 4.0 * kHidden * step_kv_tokens_, 8.0 * kHidden * step_kv_tokens_ + 8.0 * kHidden * M);
+                ConvEvent& ev = prof_event(5, 4.0 * kHidden * step_kv_tokens_, (kv_half_ ? 4.0 : 8.0) * kHidden * step_kv_tokens_ + 8.0 * kHidden * M);
                 HIP_CHECK(hipEventRecord(ev.a, w.st));
-                launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, nullptr, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, mtt);
+                launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, nullptr, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, mtt, kv_half_);
                 HIP_CHECK(hipEventRecord(ev.b, w.st));
             } else {
-                launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, nullptr, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, mtt);
+                launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, nullptr, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, mtt, kv_half_);
             }
             a = GemmRowsArgs{};
             a.M = M; a.X = w.att.as<float>(); a.xmt = mtt; a.Wt = L.tproj; a.N = kHidden; a.K = kHidden; a.bias = L.bproj;
@@ -1096,13 +1098,13 @@ private:
         const int S1 = p1.slabs, S4 = p4.slabs;
         for (int l = 0; l < cfg_.n_layer; ++l) {
             const LayerW& L = layers_[l];
-            float* kvl = kv_.as<float>() + (long)l * kv_layer_stride_;
+            void* kvl = kv_layer(l);
             gemm(w, xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, p1);
-            if (d_row_pos == nullptr) {   // decode: one fused launch
-                launch_qkv_attention_fused(P, S1, L.bqkv, kvl, d_row_slot, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st);
+            if (d_row_pos == nullptr) {   // decode (round-1 chain, fp32 K/V only): one fused launch
+                launch_qkv_attention_fused(P, S1, L.bqkv, (float*)kvl, d_row_slot, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st);
             } else {
-                launch_qkv_epilogue(P, S1, L.bqkv, w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, w.st);
-                launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st);
+                launch_qkv_epilogue(P, S1, L.bqkv, w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, w.st, kv_half_);
+                launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, 0, kv_half_);
             }
             gemm(w, w.att.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, p1);
             launch_rows_ln(P, S1, L.bproj, h, L.ln2w, L.ln2b, xn, M, 1e-5f, w.st);
@@ -1399,7 +1401,7 @@ private:
             const Seq* sq = slot_owner_[slot];
             step_kv_tokens_ += (double)(sq->n_prompt + (int)sq->tokens.size() + (infl_.on ? 1 : 0));
         }
-        stats_.decode_kv_bytes += 8.0 * kHidden * step_kv_tokens_ * cfg_.n_layer;
+        stats_.decode_kv_bytes += (kv_half_ ? 4.0 : 8.0) * kHidden * step_kv_tokens_ * cfg_.n_layer;
         stats_.decode_weight_bytes += 4.0 * ((double)cfg_.n_layer * 12.0 * kHidden * kHidden + (double)kHidden * kMelVocab);
         HIP_CHECK(hipEventRecord(ev_ds_[f.buf], st_));
         if (use_graph) {
@@ -1788,7 +1790,9 @@ private:
     int text_vocab_ = 0, text_positions_ = 0;
     // KV pool
     DevBuf kv_;
-    long n_blocks_ = 0, kv_layer_stride_ = 0;
+    long n_blocks_ = 0, kv_layer_stride_ = 0;   // stride in elements
+    bool kv_half_ = false;                        // aur_config.kv_fp16
+    void* kv_layer(int l) const { return (char*)kv_.p + (size_t)l * kv_layer_stride_ * (kv_half_ ? 2 : 4); }
     std::vector<int> free_blocks_;
     std::vector<int> h_block_tables_;
     // per-slot device state

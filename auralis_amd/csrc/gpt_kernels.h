@@ -106,7 +106,8 @@ struct GemmRowsArgs {
                          // out[m][n] += total + bias;  kEpiQkv: row-major q rows [M][1024]
     int ldo;
     int omt;             // 16-row tiles allocated in a packed `out`
-    float* kv_layer;     // kEpiQkv: paged K/V of this layer, written at (slot = row_slot[m], pos = slot_kvpos[slot])
+    void* kv_layer;      // kEpiQkv: paged K/V of this layer, written at (slot = row_slot[m], pos = slot_kvpos[slot])
+    int kv_half;         // 1: the K/V pool holds fp16 (aur_config.kv_fp16 throughput mode), else fp32
     const int* row_slot;
     const int* slot_kvpos;
     const int* block_tables;
@@ -138,15 +139,17 @@ void launch_rows_ln(const float* P, int S, const float* bias, float* h, const fl
 void launch_bias_gelu(const float* P, int S, const float* bias, float* act, int M, int N, hipStream_t st);
 
 // qkv = sum_s P[s] + bias;  q -> qbuf[m][1024];  k,v -> paged cache of this layer at (slot, pos)
-void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, float* kv_layer,
+// kv_half (here and below): the pool stores fp16 K/V (same [block][K|V][head][16][64] layout, half the bytes); values are
+// rounded to nearest on the way in, scores / softmax / P.V stay fp32
+void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, void* kv_layer,
                          const int* row_slot, const int* row_pos, const int* slot_kvpos,
-                         const int* block_tables, int max_blocks, int M, hipStream_t st);
+                         const int* block_tables, int max_blocks, int M, hipStream_t st, bool kv_half = false);
 
 // causal attention of every row against its sequence's paged K/V (keys 0..pos), 16 heads x 64
 // out_mtt > 0: `out` is written as packed rows with that many 16-row tiles (decode chain, A operand of the proj GEMM)
-void launch_paged_attention(const float* qbuf, const float* kv_layer, const int* row_slot, const int* row_pos,
+void launch_paged_attention(const float* qbuf, const void* kv_layer, const int* row_slot, const int* row_pos,
                             const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
-                            hipStream_t st, int out_mtt = 0);
+                            hipStream_t st, int out_mtt = 0, bool kv_half = false);
 
 // decode rows (one new token per sequence): qkv epilogue + KV page write + attention in one launch, reading the QKV
 // GEMM slabs directly (bitwise the same result as launch_qkv_epilogue + launch_paged_attention)

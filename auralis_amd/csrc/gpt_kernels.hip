@@ -3,6 +3,8 @@
 // Reference arithmetic: src/auralis/models/xttsv2/components/vllm_mm_gpt.py (GPT2Model.forward 787-849,
 // compute_logits 664-688, sample 691-712), components/vllm/hijack.py:49-88 (repetition penalty), and the
 // vLLM 0.6.4.post1 GPT2Block / Sampler semantics restated in SURVEY.md Appendix A2-A5.
+#include <type_traits>
+
 #include "gpt_kernels.h"
 
 namespace aur {
@@ -390,7 +392,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
                 const int slot = a.row_slot[m];
                 const int pos = a.slot_kvpos[slot];
                 const int blk = a.block_tables[(long)slot * a.max_blocks + pos / kKvBlockTokens];
-                a.kv_layer[kv_offset(blk, u - 1, d / kHeadDim, pos % kKvBlockTokens) + d % kHeadDim] = t;
+                const long off = kv_offset(blk, u - 1, d / kHeadDim, pos % kKvBlockTokens) + d % kHeadDim;
+                if (a.kv_half) reinterpret_cast<_Float16*>(a.kv_layer)[off] = (_Float16)t;
+                else reinterpret_cast<float*>(a.kv_layer)[off] = t;
             }
         }
     }
@@ -563,9 +567,13 @@ void launch_bias_gelu(const float* P, int S, const float* bias, float* act, int 
 
 // ------------------------------------------------------------------------------------------------
 
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8g __attribute__((ext_vector_type(8)));
+
+template <bool KVH>
 __global__ __launch_bounds__(256) void qkv_epilogue_kernel(const float* __restrict__ P, int S,
                                                            const float* __restrict__ bias, float* __restrict__ qbuf,
-                                                           float* __restrict__ kv_layer,
+                                                           void* __restrict__ kv_layer,
                                                            const int* __restrict__ row_slot,
                                                            const int* __restrict__ row_pos,
                                                            const int* __restrict__ slot_kvpos,
@@ -586,17 +594,27 @@ __global__ __launch_bounds__(256) void qkv_epilogue_kernel(const float* __restri
         } else {
             const int d = n - u * kHidden;
             const int head = d / kHeadDim, dd = d % kHeadDim;
-            *reinterpret_cast<f32x4*>(kv_layer + kv_offset(blk, u - 1, head, tok) + dd) = t;
+            const long off = kv_offset(blk, u - 1, head, tok) + dd;
+            if (KVH) {
+                const h16x4 hv = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
+                *reinterpret_cast<h16x4*>(reinterpret_cast<_Float16*>(kv_layer) + off) = hv;
+            } else {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(kv_layer) + off) = t;
+            }
         }
     }
 }
 
-void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, float* kv_layer,
+void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, void* kv_layer,
                          const int* row_slot, const int* row_pos, const int* slot_kvpos,
-                         const int* block_tables, int max_blocks, int M, hipStream_t st) {
+                         const int* block_tables, int max_blocks, int M, hipStream_t st, bool kv_half) {
     trace_launch("qkv_epilogue_kernel");
-    hipLaunchKernelGGL(qkv_epilogue_kernel, dim3(M), dim3(256), 0, st, P, S, bias, qbuf, kv_layer, row_slot, row_pos,
-                       slot_kvpos, block_tables, max_blocks, M);
+    if (kv_half)
+        hipLaunchKernelGGL(qkv_epilogue_kernel<true>, dim3(M), dim3(256), 0, st, P, S, bias, qbuf, kv_layer, row_slot, row_pos,
+                           slot_kvpos, block_tables, max_blocks, M);
+    else
+        hipLaunchKernelGGL(qkv_epilogue_kernel<false>, dim3(M), dim3(256), 0, st, P, S, bias, qbuf, kv_layer, row_slot, row_pos,
+                           slot_kvpos, block_tables, max_blocks, M);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -607,74 +625,117 @@ void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, 
 // FUSED (decode rows only): the row's q/k/v come straight from the QKV GEMM slabs (+ bias); the block writes its own
 // k,v into the page and uses them from registers, so the separate qkv_epilogue launch disappears.  Token t is still
 // handled by the same lane group in the same iteration => bitwise the same result as the unfused pair.
-template <bool FUSED>
+template <bool FUSED, bool KVH, bool PF = false>
 __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __restrict__ qbuf,
-                                                              float* __restrict__ kv_layer,
+                                                              void* __restrict__ kv_layer_v,
                                                               const int* __restrict__ row_slot,
                                                               const int* __restrict__ row_pos,
                                                               const int* __restrict__ slot_kvpos,
                                                               const int* __restrict__ block_tables, int max_blocks,
                                                               float* __restrict__ out, const float* __restrict__ P,
                                                               int S, const float* __restrict__ bias, int M, int out_mtt) {
-    __shared__ float part_o[16][kHeadDim];
-    __shared__ float part_m[16], part_l[16];
+    static_assert(!(FUSED && KVH), "the slab-fused decode path keeps fp32 K/V");
+    // every lane moves 16 B per cached token: 16 lanes x 4 floats (fp32 pool) or 8 lanes x 8 halves (fp16 pool) span the 64-wide
+    // head, so one wave instruction covers TPW = 4 or 8 consecutive tokens (1 KiB contiguous either way)
+    constexpr int LPT = KVH ? 8 : 16;        // lanes per token
+    constexpr int EPL = kHeadDim / LPT;      // elements per lane
+    constexpr int TPW = 64 / LPT;            // tokens per wave instruction
+    constexpr int NP = 4 * TPW;              // partial (m, l, o) groups per workgroup
+    using KT = typename std::conditional<KVH, _Float16, float>::type;
+    __shared__ float part_o[NP][kHeadDim];
+    __shared__ float part_m[NP], part_l[NP];
     const int m = blockIdx.x, head = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int g = lane >> 4, d4 = lane & 15;
+    const int g = lane / LPT, dl = lane % LPT;
     const int slot = row_slot[m];
     const int pos = row_pos ? row_pos[m] : slot_kvpos[slot];
     const int n_keys = pos + 1;
     const int* bt = block_tables + (long)slot * max_blocks;
+    const KT* kv_layer = reinterpret_cast<const KT*>(kv_layer_v);
 
-    // 4 tokens per wave per step, 4 steps unrolled: all 8 K/V loads of a lane are issued before the first softmax
-    // update (addresses are clamped instead of predicated so that the loads can be hoisted).  The first batch goes out
-    // before q is assembled from the GEMM slabs: it does not depend on q.
+    // UN steps unrolled: all 2*UN K/V loads of a lane are issued before the first softmax update (addresses are clamped instead
+    // of predicated so that the loads can be hoisted).  The first batch goes out before q is assembled: it does not depend on q.
     constexpr int UN = 4;
-    f32x4 k4[UN], v4[UN];
-    auto load_kv = [&](int t0) {
+    // (the fp16 pool's values stay packed, 4 registers per 8 halves, until they are used: as floats they cost 104 VGPRs)
+    using RawT = typename std::conditional<KVH, h16x8g, f32x4>::type;
+    RawT kraw[UN], vraw[UN], knext[UN], vnext[UN];
+    auto load_kv = [&](int t0, RawT (&kd)[UN], RawT (&vd)[UN]) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int t = min(t0 + 16 * u + wv * 4 + g, n_keys - 1);
+            const int t = min(t0 + 4 * TPW * u + wv * TPW + g, n_keys - 1);
             const int blk = bt[t / kKvBlockTokens];
-            const long off = kv_offset(blk, 0, head, t % kKvBlockTokens) + d4 * 4;
-            k4[u] = *reinterpret_cast<const f32x4*>(kv_layer + off);
-            v4[u] = *reinterpret_cast<const f32x4*>(kv_layer + off + (long)kHeads * kKvBlockTokens * kHeadDim);
+            const long off = kv_offset(blk, 0, head, t % kKvBlockTokens) + dl * EPL;
+            kd[u] = *reinterpret_cast<const RawT*>(kv_layer + off);
+            vd[u] = *reinterpret_cast<const RawT*>(kv_layer + off + (long)kHeads * kKvBlockTokens * kHeadDim);
         }
     };
-    load_kv(0);
-    f32x4 qv, own_k = {0.f, 0.f, 0.f, 0.f}, own_v = {0.f, 0.f, 0.f, 0.f};
-    if (FUSED) {
+    load_kv(0, kraw, vraw);
+    float qv[EPL], own_k[EPL], own_v[EPL];
+#pragma unroll
+    for (int c = 0; c < EPL; ++c) own_k[c] = own_v[c] = 0.f;
+    if constexpr (FUSED) {
         constexpr int N = 3 * kHidden;
-        const int col = head * kHeadDim + d4 * 4;
+        const int col = head * kHeadDim + dl * 4;
         const float* p0 = P + (long)m * N + col;
-        qv = slab_sum(p0, (long)M * N, S, bias + col);
-        own_k = slab_sum(p0 + kHidden, (long)M * N, S, bias + kHidden + col);
-        own_v = slab_sum(p0 + 2 * kHidden, (long)M * N, S, bias + 2 * kHidden + col);
+        const f32x4 q4 = slab_sum(p0, (long)M * N, S, bias + col);
+        const f32x4 k4 = slab_sum(p0 + kHidden, (long)M * N, S, bias + kHidden + col);
+        const f32x4 v4 = slab_sum(p0 + 2 * kHidden, (long)M * N, S, bias + 2 * kHidden + col);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            qv[c] = q4[c];
+            own_k[c] = k4[c];
+            own_v[c] = v4[c];
+        }
         if (wv == 0 && g == 0) {
-            const long off = kv_offset(bt[pos / kKvBlockTokens], 0, head, pos % kKvBlockTokens) + d4 * 4;
-            *reinterpret_cast<f32x4*>(kv_layer + off) = own_k;
-            *reinterpret_cast<f32x4*>(kv_layer + off + (long)kHeads * kKvBlockTokens * kHeadDim) = own_v;
+            float* kvw = reinterpret_cast<float*>(kv_layer_v);
+            const long off = kv_offset(bt[pos / kKvBlockTokens], 0, head, pos % kKvBlockTokens) + dl * 4;
+            *reinterpret_cast<f32x4*>(kvw + off) = k4;
+            *reinterpret_cast<f32x4*>(kvw + off + (long)kHeads * kKvBlockTokens * kHeadDim) = v4;
         }
     } else {
-        qv = *reinterpret_cast<const f32x4*>(qbuf + (long)m * kHidden + head * kHeadDim + d4 * 4);
+        const float* qp = qbuf + (long)m * kHidden + head * kHeadDim + dl * EPL;
+#pragma unroll
+        for (int c4 = 0; c4 < EPL / 4; ++c4) {
+            const f32x4 q4 = *reinterpret_cast<const f32x4*>(qp + 4 * c4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qv[4 * c4 + c] = q4[c];
+        }
     }
     float mi = -INFINITY, li = 0.f;
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    for (int t0 = 0; t0 < n_keys; t0 += 16 * UN) {
-        if (t0 > 0) load_kv(t0);
+    float o[EPL];
+#pragma unroll
+    for (int c = 0; c < EPL; ++c) o[c] = 0.f;
+    constexpr int STEP = 4 * TPW * UN;   // tokens per workgroup iteration
+    for (int t0 = 0; t0 < n_keys; t0 += STEP) {
+        // the next iteration's loads are in flight while this one is reduced (one memory round trip per iteration was
+        // exposed before: the workgroups of a CU only partly covered for each other)
+        const bool more = PF && t0 + STEP < n_keys;
+        if (PF) {
+            if (more) load_kv(t0 + STEP, knext, vnext);
+        } else if (t0 > 0) {
+            load_kv(t0, kraw, vraw);
+        }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int t = t0 + 16 * u + wv * 4 + g;
+            const int t = t0 + 4 * TPW * u + wv * TPW + g;
             const bool valid = t < n_keys;
-            if (FUSED && t == pos) {   // own token: registers (the page write above may not be visible yet)
-                k4[u] = own_k;
-                v4[u] = own_v;
+            float kx[EPL], vx[EPL];
+#pragma unroll
+            for (int c = 0; c < EPL; ++c) {
+                kx[c] = (float)kraw[u][c];
+                vx[c] = (float)vraw[u][c];
             }
-            float sc = (qv[0] * k4[u][0] + qv[1] * k4[u][1]) + (qv[2] * k4[u][2] + qv[3] * k4[u][3]);
-            sc += __shfl_xor(sc, 8, 64);
-            sc += __shfl_xor(sc, 4, 64);
-            sc += __shfl_xor(sc, 2, 64);
-            sc += __shfl_xor(sc, 1, 64);
+            if (FUSED && t == pos) {   // own token: registers (the page write above may not be visible yet)
+#pragma unroll
+                for (int c = 0; c < EPL; ++c) {
+                    kx[c] = own_k[c];
+                    vx[c] = own_v[c];
+                }
+            }
+            float sc = (qv[0] * kx[0] + qv[1] * kx[1]) + (qv[2] * kx[2] + qv[3] * kx[3]);
+            if constexpr (EPL == 8) sc += (qv[4] * kx[4] + qv[5] * kx[5]) + (qv[6] * kx[6] + qv[7] * kx[7]);
+#pragma unroll
+            for (int sh = LPT / 2; sh > 0; sh >>= 1) sc += __shfl_xor(sc, sh, 64);
             sc *= 0.125f;   // 1/sqrt(64)
             if (valid) {
                 const float mn = fmaxf(mi, sc);
@@ -682,14 +743,22 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
                 const float p = expf(sc - mn);
                 li = li * alpha + p;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] = o[c] * alpha + p * v4[u][c];
+                for (int c = 0; c < EPL; ++c) o[c] = o[c] * alpha + p * vx[c];
                 mi = mn;
             }
         }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                kraw[u] = knext[u];
+                vraw[u] = vnext[u];
+            }
+        }
     }
-    const int pidx = wv * 4 + g;
-    *reinterpret_cast<f32x4*>(&part_o[pidx][d4 * 4]) = o;
-    if (d4 == 0) {
+    const int pidx = wv * TPW + g;
+#pragma unroll
+    for (int c = 0; c < EPL; ++c) part_o[pidx][dl * EPL + c] = o[c];
+    if (dl == 0) {
         part_m[pidx] = mi;
         part_l[pidx] = li;
     }
@@ -697,10 +766,10 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
     if (threadIdx.x < kHeadDim) {
         float mx = -INFINITY;
 #pragma unroll
-        for (int p = 0; p < 16; ++p) mx = fmaxf(mx, part_m[p]);
+        for (int p = 0; p < NP; ++p) mx = fmaxf(mx, part_m[p]);
         float L = 0.f, O = 0.f;
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const float w = expf(part_m[p] - mx);
             L += part_l[p] * w;
             O += part_o[p][threadIdx.x] * w;
@@ -710,13 +779,30 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
     }
 }
 
-void launch_paged_attention(const float* qbuf, const float* kv_layer, const int* row_slot, const int* row_pos,
+void launch_paged_attention(const float* qbuf, const void* kv_layer, const int* row_slot, const int* row_pos,
                             const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
-                            hipStream_t st, int out_mtt) {
+                            hipStream_t st, int out_mtt, bool kv_half) {
     trace_launch("paged_attention_kernel");
-    hipLaunchKernelGGL(paged_attention_kernel<false>, dim3(M, kHeads), dim3(256), 0, st, qbuf, const_cast<float*>(kv_layer),
-                       row_slot, row_pos, slot_kvpos, block_tables, max_blocks, out, (const float*)nullptr, 0,
-                       (const float*)nullptr, M, out_mtt);
+    // AUR_ATTN_PREFETCH=1: issue the next iteration's K/V loads before reducing the current one.  Measured (r02, 64 x ctx ~243):
+    // fp32 pool 26.0 vs 25.1 us, fp16 pool 17.7 vs 17.2 us per launch, i.e. the ~40 extra VGPRs cost more residency than the
+    // overlap buys (the 4-7 workgroups of a CU already cover for each other) => off.
+    static const int pf = [] {
+        const char* e = getenv("AUR_ATTN_PREFETCH");
+        return e ? atoi(e) : 0;
+    }();
+    const bool prefetch = pf != 0;
+#define AUR_ATT(KVH_, PF_)                                                                                                      \
+    hipLaunchKernelGGL((paged_attention_kernel<false, KVH_, PF_>), dim3(M, kHeads), dim3(256), 0, st, qbuf,                     \
+                       const_cast<void*>(kv_layer), row_slot, row_pos, slot_kvpos, block_tables, max_blocks, out,               \
+                       (const float*)nullptr, 0, (const float*)nullptr, M, out_mtt)
+    if (kv_half) {
+        if (prefetch) AUR_ATT(true, true);
+        else AUR_ATT(true, false);
+    } else {
+        if (prefetch) AUR_ATT(false, true);
+        else AUR_ATT(false, false);
+    }
+#undef AUR_ATT
     HIP_CHECK(hipGetLastError());
 }
 
@@ -724,7 +810,7 @@ void launch_qkv_attention_fused(const float* P, int S, const float* bias, float*
                                 const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
                                 hipStream_t st) {
     trace_launch("paged_attention_kernel<fused>");
-    hipLaunchKernelGGL(paged_attention_kernel<true>, dim3(M, kHeads), dim3(256), 0, st, (const float*)nullptr, kv_layer,
+    hipLaunchKernelGGL((paged_attention_kernel<true, false>), dim3(M, kHeads), dim3(256), 0, st, (const float*)nullptr, (void*)kv_layer,
                        row_slot, (const int*)nullptr, slot_kvpos, block_tables, max_blocks, out, P, S, bias, M, 0);
     HIP_CHECK(hipGetLastError());
 }

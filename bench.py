@@ -195,7 +195,8 @@ def build_report(args, st, dims, world, samples, dt, audio_s):
         "metric": "audio_samples_per_s (64-way batch; rtf = wall_s / audio_s alongside)",
         "value": samples / dt, "unit": "audio-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.vocoder == "fp32" else "f32 (GPT) + f16-in/f32-acc MFMA (vocoder convs)", "data": "synthetic",
+        "dtype": ("f32" if args.vocoder == "fp32" else "f32 (GPT) + f16-in/f32-acc MFMA (vocoder convs)")
+                 + (" + f16 K/V pool (throughput mode, not the parity configuration)" if args.kv == "fp16" else ""), "data": "synthetic",
         "rtf": dt / audio_s, "audio_sec_per_wall_sec": audio_s / dt,
         "config": {"workload": f"{args.batch} concurrent 200-char utterances per GPU (70 text tokens -> "
                                f"{args.tokens} mel tokens fixed-length -> {dims.voc.samples_for_latents(args.tokens)} "
@@ -203,7 +204,7 @@ def build_report(args, st, dims, world, samples, dt, audio_s):
                                f"continuous batching; BASELINE.json configs[2]"
                                + ("; consecutive steps pipelined (vocoder of batch k overlaps GPT of batch k+1)" if args.pipeline else ""),
                    "utterances_per_gpu": args.batch, "mel_tokens": args.tokens, "gpt_layers": args.layers,
-                   "vocoder_mfma_inputs": args.vocoder,
+                   "vocoder_mfma_inputs": args.vocoder, "kv_cache": args.kv,
                    "parallelism": f"dp{world} (independent utterances, 1 RCCL broadcast of conditioning)"},
         "roofline": dominant,
         "roofline_second_kernel": roof_conv,
@@ -230,6 +231,9 @@ def main():
     ap.add_argument("--layers", type=int, default=30)
     ap.add_argument("--vocoder", choices=["fp32", "fp16"], default="fp16",
                     help="MFMA input type of the HiFi-GAN convs (fp32 accumulate either way; GPT is fp32)")
+    ap.add_argument("--kv", choices=["fp32", "fp16"], default="fp32",
+                    help="paged K/V pool dtype: fp32 = the bit-exact parity mode (default, the reported metric); fp16 = opt-in "
+                         "throughput mode (aur_config.kv_fp16), half the attention bytes, ids may differ after a near-tie")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", action="store_true",
                     help="queue all steps at once so the vocoder of batch k overlaps the GPT of batch k+1 (measured "
@@ -262,7 +266,8 @@ def main():
     gpt_sd = make_synthetic_gpt(dims.gpt, seed=1234, n_layer=args.layers)
     xtts_sd = make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd)
     eng = NativeEngine(n_layer=args.layers, max_seqs=args.batch, device=local_rank, profile=True,
-                       vocoder_fp16=(args.vocoder == "fp16"), return_latents=False)   # audio + tokens, as TTSOutput
+                       vocoder_fp16=(args.vocoder == "fp16"), return_latents=False,   # audio + tokens, as TTSOutput
+                       kv_fp16=(args.kv == "fp16"))
     eng.load_weights(pack_all(gpt_sd, xtts_sd))
     _log("weights resident")
 

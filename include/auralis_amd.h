@@ -47,6 +47,10 @@ typedef struct aur_config {
     int32_t return_latents;   /* 1 = also copy each sequence's vocoder input latents to the host (aur_result.latents; parity
                                  tests).  0 = audio and tokens only, as the reference's TTSOutput (saves ~1.1 MB of D2H
                                  and host copies per 280-token utterance) */
+    int32_t kv_fp16;          /* 1 = throughput mode: the paged K/V pool holds fp16 (rounded to nearest on write; scores, softmax
+                                 and P.V stay fp32), which halves the bytes the decode attention streams.  NOT the parity mode:
+                                 greedy ids can differ from the fp32 reference after a near-tie (measured rate: DESIGN.md §4).
+                                 0 (default) = fp32 K/V, bit-exact contract */
 } aur_config;
 
 /* One named fp32 tensor.  Names are the packed names produced by auralis_amd/weights.py from the
