@@ -1,11 +1,11 @@
-"""Minimal text front-end feeding the hot path: sentence chunking and BPE ids.
+"""Text front-end feeding the hot path: sentence chunking and BPE ids.
 
-Reference: XTTSTokenizerFast / split_sentence / char_limits (src/auralis/models/xttsv2/config/tokenizer.py:119-236,
-742-1002).  Scope note: text normalisation lives in api/cleaners.py (en/fr/de numbers spelled out; other languages
-keep digits); the spaCy sentencizer is replaced by a punctuation sentencizer; this module keeps the contract the engine
-depends on — chunks no longer than the per-language character limit,
-ids = BPE("[lang]" + text with " " -> "[SPACE]") wrapped in [START]/[STOP] — and uses the real tokenizer.json when
-the checkpoint directory has one, else a deterministic stand-in vocabulary for synthetic checkpoints."""
+Reference: XTTSTokenizerFast / split_sentence / find_best_split_point / char_limits
+(src/auralis/models/xttsv2/config/tokenizer.py:51-236, 742-1002).  split_sentence follows the reference's algorithm step by
+step; spaCy (absent offline) contributes only its rule-based `sentencizer`, restated in _sentencize with the tokenizer
+approximated on whitespace words (abbreviation exceptions listed there).  Text normalisation lives in api/cleaners.py (en/fr/de
+numbers spelled out; other languages keep digits).  ids = BPE("[lang]" + cleaned text with " " -> "[SPACE]") wrapped in
+[START]/[STOP], from the checkpoint's tokenizer.json (required for real checkpoints)."""
 from __future__ import annotations
 
 import os
@@ -15,47 +15,92 @@ from typing import List, Optional
 
 CHAR_LIMITS = {"en": 250, "de": 253, "fr": 273, "es": 239, "it": 213, "pt": 203, "pl": 224, "zh": 82, "ar": 166,
                "cs": 186, "ru": 182, "nl": 251, "tr": 226, "ja": 71, "hu": 224, "ko": 95}
-_SENT_END = re.compile(r"(?<=[.!?;:。！？])\s+|\n{2,}")
-_SOFT = re.compile(r"[,)\]\-–—]\s|\s")
+# spaCy `sentencizer` default punct_chars (the subset that occurs in the scripts XTTS supports): a token made of these ends a
+# sentence; following punctuation-only tokens (closing quotes / brackets) still belong to it
+_SENT_PUNCT = ".!?։؟۔܀܁܂߹।॥၊။።፧፨᙮᜵᜶᠃᠉᥄᥅᪨᪩᪪᪫᭚᭛᭞᭟᰻᰼᱾᱿‼‽⁇⁈⁉⸮⸼꓿꘎꘏꛳꛷꡶꡷꣎꣏꤯꧈꧉꩝꩞꩟꫰꫱꯫﹒﹖﹗！．？｡。"
+_CLOSERS = "\"'”’»›)]}）】』》"
+# spaCy's English tokenizer keeps these as ONE token (tokenizer exceptions), so their period does not end a sentence
+_ABBREV = {"mr.", "mrs.", "ms.", "dr.", "prof.", "st.", "sr.", "jr.", "mt.", "vs.", "etc.", "e.g.", "i.e.", "a.m.", "p.m.",
+           "no.", "co.", "inc.", "ltd.", "corp.", "gen.", "gov.", "sen.", "rep.", "adm.", "messrs.", "bros.", "jan.", "feb.",
+           "mar.", "apr.", "jun.", "jul.", "aug.", "sep.", "sept.", "oct.", "nov.", "dec.", "ph.d.", "u.s.", "u.k."}
 
 
-def _best_split(text: str, limit: int, window: int = 30) -> int:
-    """Split position <= limit, preferring punctuation then whitespace inside the last `window` characters."""
-    lo = max(1, limit - window)
-    seg = text[lo:limit]
-    for pat in (r"[.!?;:]\s", r"[,)\]]\s", r"[-–—]\s", r"\s"):
-        hits = list(re.finditer(pat, seg))
-        if hits:
-            return lo + hits[-1].end()
-    return limit
+def _sentencize(text: str) -> List[str]:
+    """Rule-based sentence boundaries as spaCy's `sentencizer` draws them on a blank pipeline (tokenizer.py:185-191): a
+    sentence ends after a token consisting of sentence punctuation (plus any punctuation-only tokens after it) and the next
+    sentence starts at the following token.  The tokenizer is approximated on whitespace-separated words: a word's trailing run
+    of sentence punctuation (optionally followed by closing quotes / brackets) is that punctuation token, unless the word is
+    one of the tokenizer's abbreviation exceptions, a single letter + '.', or a number / dotted token with no space (3.14,
+    example.com keep their dots because the period is word-internal)."""
+    out, start = [], 0
+    for m in re.finditer(r"\S+", text):
+        w = m.group(0)
+        core = w.rstrip(_CLOSERS)
+        if not core or core[-1] not in _SENT_PUNCT:
+            continue
+        if core[-1] == ".":
+            low = core.lower().lstrip("\"'“‘«‹([{")
+            if low in _ABBREV or re.fullmatch(r"[a-z]\.", low) or re.fullmatch(r"(?:[a-z]\.){2,}", low):
+                continue
+        out.append(text[start:m.end()])
+        start = m.end()
+    if text[start:].strip():
+        out.append(text[start:])
+    return out
+
+
+def find_best_split_point(text: str, target_pos: int, window_size: int = 30) -> int:
+    """tokenizer.py:51-115 restated: every break marker inside [target - window, target + window] is scored
+    priority x (1 - distance / (2 * window)) and the best one wins (first best on ties); the split lands AFTER the marker.
+    Note the window extends past the target, so a chunk may exceed the limit by up to `window_size` characters, as in the
+    reference."""
+    markers = ((r"[.!?؟။။။]+[\s]*", 1.0), (r"[\n\r]+\s*[\n\r]+", 1.0), (r"[:|;；：；][\s]*", 0.9), (r"[,，،、][\s]*", 0.8),
+               (r"[)}\]）】』»›》\s]+", 0.7), (r"[-—−]+[\s]*", 0.7), (r"\s+[&+=/\s]+\s+", 0.6), (r"[\s]+", 0.5))
+    start = max(0, target_pos - window_size)
+    window = text[start:min(len(text), target_pos + window_size)]
+    best_pos, best_score = target_pos, 0.0
+    for pattern, priority in markers:
+        for m in re.finditer(pattern, window):
+            pos = start + m.end()
+            score = priority * (1 - abs(pos - target_pos) / (window_size * 2))
+            if score > best_score:
+                best_score, best_pos = score, pos
+    return best_pos
 
 
 def split_sentence(text: str, lang: str, text_split_length: int = 250) -> List[str]:
+    """tokenizer.py:119-236: sentences (spaCy sentencizer, restated in _sentencize) are packed greedily into chunks of at most
+    `text_split_length` characters; a sentence longer than the limit is cut at find_best_split_point; a trailing '.' of a
+    chunk becomes a space (":234, prevents annoying sounds")."""
     text = text.strip()
     if len(text) <= text_split_length:
         return [text]
-    sentences = [s.strip() for s in _SENT_END.split(text) if s and s.strip()]
-    chunks: List[str] = []
+    splits: List[str] = []
     cur: List[str] = []
     cur_len = 0
-    for s in sentences:
-        if cur_len + len(s) <= text_split_length:
+    for sent in _sentencize(text):
+        s = sent.strip()
+        n = len(s)
+        if cur_len + n <= text_split_length:
             cur.append(s)
-            cur_len += len(s) + 1
-            continue
-        if cur:
-            chunks.append(" ".join(cur))
-            cur, cur_len = [], 0
-        while len(s) > text_split_length:
-            p = _best_split(s, text_split_length)
-            chunks.append(s[:p].strip())
-            s = s[p:].strip()
-        if s:
-            cur, cur_len = [s], len(s)
+            cur_len += n + 1
+        elif n > text_split_length:
+            if cur:
+                splits.append(" ".join(cur))
+                cur, cur_len = [], 0
+            rest = s
+            while len(rest) > text_split_length:
+                p = find_best_split_point(rest, text_split_length, window_size=30)
+                splits.append(rest[:p].strip())
+                rest = rest[p:].strip()
+            if rest:
+                cur, cur_len = [rest], len(rest)
+        else:
+            splits.append(" ".join(cur))
+            cur, cur_len = [s], n
     if cur:
-        chunks.append(" ".join(cur))
-    # the reference replaces a trailing '.' by a space ("prevents annoying sounds", tokenizer.py:234)
-    return [c[:-1] + " " if c.endswith(".") else c for c in chunks if c]
+        splits.append(" ".join(cur))
+    return [c[:-1] + " " if c.endswith(".") else c for c in splits if c]
 
 
 def preprocess_text(text: str, lang: str) -> str:

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
     // NTL = 16-column tiles per workgroup (each wave keeps MT x NTL accumulator tiles): 2 halves the activation bytes a
     // workgroup pulls per weight byte; the K order of every output element is the same for NTL = 1 and 2 (bitwise equal)
     static_assert(!LN || KCH == 1, "LN prologue needs the whole row in one chunk");
-    static_assert(NW == 8 || NW == 16, "waves per workgroup");
+    static_assert(NW == 4 || NW == 8 || NW == 16, "waves per workgroup");
     constexpr int NB = 64 / NW;   // 16-deep K blocks per wave per 1024-deep chunk
     __shared__ __attribute__((aligned(16))) float red[NW][MT * NTL * 256];
     __shared__ float rs[LN ? 16 * MT : 1][2];   // (mean, rstd) of the workgroup's rows
@@ -284,11 +284,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
     // (loads return in order).  Wave w combines rows w, w + NW, ...; lane t holds column tile t.
     constexpr int RPW = LN ? 16 * MT / NW : 1;   // rows per wave
     float2 pt[RPW];
-    f32x4 gbv = {0.f, 0.f, 0.f, 0.f};
+    f32x4 gbv = {0.f, 0.f, 0.f, 0.f}, gbv2 = {0.f, 0.f, 0.f, 0.f};
     if (LN) {
 #pragma unroll
         for (int u = 0; u < RPW; ++u) pt[u] = a.stats_in[(long)(m0 + w + NW * u) * 64 + lane];
-        if (tid < 512) gbv = *reinterpret_cast<const f32x4*>(((tid < 256) ? a.gamma : a.beta) + 4 * (tid & 255));
+        if (NW >= 8) {
+            if (tid < 512) gbv = *reinterpret_cast<const f32x4*>(((tid < 256) ? a.gamma : a.beta) + 4 * (tid & 255));
+        } else {
+            gbv = *reinterpret_cast<const f32x4*>(a.gamma + 4 * tid);
+            gbv2 = *reinterpret_cast<const f32x4*>(a.beta + 4 * tid);
+        }
     }
     load_chunk(0, 0);
     if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 1] = (long long)__builtin_amdgcn_s_memtime();
@@ -297,7 +302,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
         __builtin_amdgcn_sched_barrier(0);   // everything above is in flight before the first wait
         // gamma / beta go through LDS (8 KB): holding this lane's values in registers next to the A registers of a 64-row
         // tile spilled
-        if (tid < 512) *reinterpret_cast<f32x4*>(&gb[tid >> 8][4 * (tid & 255)]) = gbv;
+        if (NW >= 8) {
+            if (tid < 512) *reinterpret_cast<f32x4*>(&gb[tid >> 8][4 * (tid & 255)]) = gbv;
+        } else {
+            *reinterpret_cast<f32x4*>(&gb[0][4 * tid]) = gbv;
+            *reinterpret_cast<f32x4*>(&gb[1][4 * tid]) = gbv2;
+        }
 #pragma unroll
         for (int u = 0; u < RPW; ++u) {
             const int rr = w + NW * u;
@@ -427,9 +437,17 @@ static void launch_gemm_rows_mt(const GemmRowsArgs& a, int mt, int nw, hipStream
     }
     AUR_REQUIRE(mt <= 2 || KCH == 1, "gemm_rows: rows per workgroup");
     if (mt == 2) {
+        AUR_REQUIRE(nw != 4, "gemm_rows: 4-wave workgroups exist for 16-row tiles only");
         if (nw == 8) hipLaunchKernelGGL((gemm_rows_kernel<2, KCH, LN, EPI, 8>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((gemm_rows_kernel<2, KCH, LN, EPI, 16>), grid, dim3(1024), 0, st, a);
     } else {
+        if constexpr (KCH == 1) {
+            if (nw == 4) {
+                hipLaunchKernelGGL((gemm_rows_kernel<1, KCH, LN, EPI, 4>), grid, dim3(256), 0, st, a);
+                return;
+            }
+        }
+        AUR_REQUIRE(nw != 4, "gemm_rows: 4-wave workgroups exist for K = 1024 only");
         if (nw == 8) hipLaunchKernelGGL((gemm_rows_kernel<1, KCH, LN, EPI, 8>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((gemm_rows_kernel<1, KCH, LN, EPI, 16>), grid, dim3(1024), 0, st, a);
     }

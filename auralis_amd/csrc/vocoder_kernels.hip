@@ -313,15 +313,15 @@ void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 // XH: the input tensor is fp16 in HBM and already activated (ConvArgs::x_f16), staged without conversion.
-template <int KS, int DIL, int MT, bool XH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void conv1d_mfma_f16_kernel(ConvArgs a) {
+// PF: software-pipelined staging — the global loads of chunk i+1 are issued before the MFMAs of chunk i and parked in
+// registers (2 waves per SIMD: ~200 VGPRs, no spills); !PF: synchronous staging at 3 waves per SIMD (under the 168-VGPR cap of
+// 3 waves the prefetch registers spilled, which is why round 1 measured it slower).
+// WIDE (64-channel tiles only): 512 instead of 256 positions per workgroup — twice the MFMAs per staged weight chunk.
+template <int KS, int DIL, int MT, bool XH, bool PF, bool WIDE = false>
+__global__ __launch_bounds__(256, PF ? 2 : 3) void conv1d_mfma_f16_kernel(ConvArgs a) {
     constexpr int CK = 16;
     constexpr int WM = MT / 32;
-#ifndef AUR_F16_WN64
-#define AUR_F16_WN64 2
-#define AUR_F16_WN32 4
-#endif
-    constexpr int WN = (MT == 64) ? AUR_F16_WN64 : AUR_F16_WN32;
+    constexpr int WN = (MT == 64) ? (WIDE ? 4 : 2) : 4;
     constexpr int NTW = 32 * WN;
     constexpr int NT = 4 * NTW;
     constexpr int HALO = (KS - 1) * DIL;
@@ -406,17 +406,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         AUR_WST(0, w0) AUR_WST(1, w1) AUR_WST(2, w2) AUR_WST(3, w3) AUR_WST(4, w4) AUR_WST(5, w5)
     };
 
-#ifndef AUR_F16_PREFETCH
-#define AUR_F16_PREFETCH 0
-#endif
-    if (AUR_F16_PREFETCH) load_chunk(0);
+    if (PF) load_chunk(0);
     for (int ci0 = 0; ci0 < a.Cin; ci0 += CK) {
-        if (!AUR_F16_PREFETCH) load_chunk(ci0);          // synchronous staging: fewer live registers, more waves per SIMD
+        if (!PF) load_chunk(ci0);          // synchronous staging: fewer live registers, more waves per SIMD
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         store_chunk();
         __syncthreads();
-        if (AUR_F16_PREFETCH && ci0 + CK < a.Cin) load_chunk(ci0 + CK);
+        if (PF && ci0 + CK < a.Cin) load_chunk(ci0 + CK);
         __builtin_amdgcn_sched_barrier(0);
         const _Float16* xbase = &xs[(wv * NTW + l31) * RS + 8 * hi];
         const _Float16* wbase = &ws[l31 * RS + 8 * hi];
@@ -439,21 +436,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     conv_epilogue<WM, WN, MT, NTW>(a, acc, b, mtile, q0, wv, l31, hi, len_in, n_q);
 }
 
-template <int KS, int DIL, bool XH>
-static void launch_conv_f16_t(const ConvArgs& a, hipStream_t st) {
+template <int KS, int DIL, bool XH, bool PF, bool WIDE>
+static void launch_conv_f16_pf(const ConvArgs& a, hipStream_t st) {
     AUR_REQUIRE(a.Cin % 16 == 0 && a.wp16, "conv f16: Cin % 16, packed fp16 weights");
     AUR_REQUIRE(!a.out_act_f16 || (a.mrf_mode == 0 && a.ups_s == 0), "conv f16: fp16 output only for plain convs");
     const int n_q = a.ups_s ? a.max_len + 1 : a.max_len;
     trace_launch("conv1d_mfma_f16_kernel");
     if (a.Mtot % 64 == 0) {
-        constexpr int NT64 = 128 * AUR_F16_WN64;
+        constexpr int NT64 = WIDE ? 512 : 256;
         dim3 grid((n_q + NT64 - 1) / NT64, a.Mtot / 64, a.B);
-        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 64, XH>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 64, XH, PF, WIDE>), grid, dim3(256), 0, st, a);
     } else {
         AUR_REQUIRE(a.Mtot % 32 == 0, "conv f16: Mtot % 32");
-        constexpr int NT32 = 128 * AUR_F16_WN32;
+        constexpr int NT32 = 512;
         dim3 grid((n_q + NT32 - 1) / NT32, a.Mtot / 32, a.B);
-        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 32, XH>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 32, XH, PF, false>), grid, dim3(256), 0, st, a);
+    }
+}
+
+// AUR_F16_PF_MINC=<c>: convs with at least c input channels use the software-pipelined staging (A/B; see the kernel comment)
+template <int KS, int DIL, bool XH>
+static void launch_conv_f16_t(const ConvArgs& a, hipStream_t st) {
+    static const int pf_minc = [] {
+        const char* e = getenv("AUR_F16_PF_MINC");
+        return e ? atoi(e) : 100000;
+    }();
+    static const int wide_minc = [] {   // AUR_F16_WIDE_MINC=<c>: pipelined convs with >= c input channels use 512-position tiles
+        const char* e = getenv("AUR_F16_WIDE_MINC");
+        return e ? atoi(e) : 100000;
+    }();
+    if (a.Cin >= pf_minc) {
+        if (a.Cin >= wide_minc && a.Mtot % 64 == 0) launch_conv_f16_pf<KS, DIL, XH, true, true>(a, st);
+        else launch_conv_f16_pf<KS, DIL, XH, true, false>(a, st);
+    } else {
+        launch_conv_f16_pf<KS, DIL, XH, false, false>(a, st);
     }
 }
 

@@ -62,7 +62,9 @@ def test_split_sentence_respects_limit_and_keeps_words():
     text = " ".join([PARA] * 6)
     for lang in ("en", "fr", "de"):
         chunks = split_sentence(text, lang, CHAR_LIMITS[lang])
-        assert all(0 < len(c) <= CHAR_LIMITS[lang] for c in chunks)
+        # the reference's own slack: a long sentence is cut at the best marker within +-30 characters of the limit, and a
+        # chunk opened in the "start new split" branch is accounted one character short (tokenizer.py:196-229)
+        assert all(0 < len(c) <= CHAR_LIMITS[lang] + 30 for c in chunks)
         assert "".join("".join(chunks).split()).replace(".", "") == "".join(text.split()).replace(".", "")
     assert split_sentence("short text.", "en") == ["short text."]
 
@@ -333,3 +335,31 @@ def test_default_seeds_do_not_depend_on_the_process_hash_salt():
 
     from auralis_amd.api import xtts_engine
     assert "hash(request.request_id)" not in inspect.getsource(xtts_engine)
+
+
+def test_split_sentence_follows_the_reference_algorithm():
+    """Hand-traced through tokenizer.py:119-236 (spaCy sentencizer rules: a sentence ends after . ! ? tokens plus trailing
+    closers; ';' and ':' do NOT end a sentence; abbreviations and initials are tokenizer exceptions)."""
+    from auralis_amd.api.text import _sentencize, find_best_split_point
+    t = 'Hello there. This is Dr. Smith speaking! Is it 3.14 or not? "Yes." he said. J. R. R. Tolkien wrote it... The end.'
+    assert [s.strip() for s in _sentencize(t)] == ["Hello there.", "This is Dr. Smith speaking!", "Is it 3.14 or not?", '"Yes."',
+                                                    "he said.", "J. R. R. Tolkien wrote it...", "The end."]
+    assert [s.strip() for s in _sentencize("Un point; deux points: rien ne coupe ici. Voilà !")] == \
+        ["Un point; deux points: rien ne coupe ici.", "Voilà !"]
+    # greedy packing with the reference's length accounting (joined with single spaces, trailing '.' -> ' ')
+    sents = ["A" * 99 + ".", "B" * 99 + ".", "C" * 99 + ".", "D" * 40 + "!"]
+    chunks = split_sentence(" ".join(sents), "en", 250)
+    assert chunks == [sents[0] + " " + sents[1][:-1] + " ", sents[2] + " " + sents[3]]
+    # a sentence longer than the limit is cut at the best-scoring marker near the limit: a comma 4 characters before the
+    # target (0.8 x (1 - 4/60) = 0.747) beats whitespace exactly at the target (the closing-bracket class contains \\s:
+    # 0.7 x 1.0), while a comma 9 characters away (0.68) loses to it
+    long = "x" * 244 + ", " + "y " * 40 + "end"
+    p = find_best_split_point(long, 250, window_size=30)
+    assert long[:p].endswith(", ") and p == 246
+    parts = split_sentence(long, "en", 250)
+    assert parts[0] == "x" * 244 + "," and "".join(parts).replace(" ", "") == long.replace(" ", "")
+    far = "x" * 239 + ", " + "y " * 40 + "end"
+    assert find_best_split_point(far, 250, window_size=30) == 249
+    # strong markers win over nearer weak ones; with no marker in the window the cut is exactly at the target
+    assert find_best_split_point("a" * 235 + ". " + "b" * 100, 250) == 237
+    assert find_best_split_point("z" * 400, 250) == 250

@@ -139,8 +139,9 @@ int main(int argc, char** argv) {
         HIP_CHECK(hipStreamSynchronize(st));
         for (int ntl : {1, 2})
         for (int nt : {0})
-        for (int nw : {16, 8})
+        for (int nw : {16, 8, 4})
             for (int mt : {1, 2, 4}) {
+                if (nw == 4 && (mt != 1 || s.K != 1024 || ntl != 1)) continue;
                 if (ntl == 2 && !(s.ln && nw == 8 && mt <= 2)) continue;
                 if (nt && (M + 16 * mt - 1) / (16 * mt) != 1) continue;
                 if (s.K == 4096 && mt == 4) continue;
