@@ -101,3 +101,109 @@ def test_wav_roundtrip_and_end_to_end_shapes(tmp_path, cond_sd):
     assert torch.isfinite(cond).all() and abs(spk.norm().item() - 1.0) < 1e-4
     with pytest.raises(ValueError):
         Cn.read_wav(b"not a wav file at all, definitely not....................")
+
+
+# ------------------------------------------------------------------------------------------------ real-speech golden + front-end
+def _golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cond_female_6s.npz"))
+
+
+def _wav_bytes(pcm16: np.ndarray, sr: int = 22050) -> bytes:
+    import io
+    import wave
+    b = io.BytesIO()
+    with wave.open(b, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(sr)
+        w.writeframes(pcm16.astype(np.int16).tobytes())
+    return b.getvalue()
+
+
+def _golden_sd(dims):
+    sd = make_synthetic_conditioning_weights(dims, seed=99)
+    sd["mel_stats"] = torch.ones(80)
+    return sd
+
+
+def test_conditioning_of_real_speech_matches_reference_classes(dims):
+    """6 s of the reference's female.wav (fixture made by oracle/make_golden_cond.py): conditioning.py end to end against the
+    outputs the reference's ConditioningEncoder / PerceiverResampler / ResNetSpeakerEncoder classes gave on the same clip."""
+    g = _golden()
+    cond, spk = Cn.get_conditioning_latents(_golden_sd(dims), [_wav_bytes(g["pcm16"])], max_ref_length=30, gpt_cond_len=6,
+                                            gpt_cond_chunk_len=6)
+    assert cond.shape == (1, 32, 1024) and spk.shape == (1, 512, 1)
+    assert (cond - torch.from_numpy(g["gpt_cond_latent"])).abs().max().item() < 2e-4
+    assert (spk - torch.from_numpy(g["speaker_embedding"])).abs().max().item() < 1e-5
+
+
+@pytest.mark.gpu
+def test_conditioning_on_gpu_matches_reference_classes(dims):
+    """The same clip through conditioning.py on cuda:0 (PyTorch-ROCm: rocFFT STFT, MIOpen convs, rocBLAS attention)."""
+    g = _golden()
+    cond, spk = Cn.get_conditioning_latents(_golden_sd(dims), [_wav_bytes(g["pcm16"])], max_ref_length=30, gpt_cond_len=6,
+                                            gpt_cond_chunk_len=6, device="cuda")
+    assert cond.is_cuda and spk.is_cuda
+    assert (cond.cpu() - torch.from_numpy(g["gpt_cond_latent"])).abs().max().item() < 2e-3
+    assert (spk.cpu() - torch.from_numpy(g["speaker_embedding"])).abs().max().item() < 1e-4
+
+
+def test_mel_front_end_against_an_independent_restatement():
+    """torchaudio is not installed, so the mel front-end cannot be pinned to the reference's MelSpectrogram objects
+    (common/utilities.py:9-71, hifigan_decoder.py:537-548).  Independent cross-check on real speech: scipy's STFT (zero phase
+    reference implementation, own framing) + a filterbank coded from the HTK-mel / Slaney-normalisation definitions."""
+    import scipy.signal as ss
+    g = _golden()
+    x = g["pcm16"].astype(np.float64) / 32767.0
+
+    def mel_ref(x, sr, n_fft, win_len, hop, n_mels, fmin, fmax, window, slaney):
+        win = ss.get_window(window, win_len, fftbins=True)
+        pad = (n_fft - win_len) // 2
+        win = np.pad(win, (pad, n_fft - win_len - pad))
+        xp = np.pad(x, n_fft // 2, mode="reflect")
+        frames = 1 + (len(xp) - n_fft) // hop
+        idx = np.arange(n_fft)[None, :] + hop * np.arange(frames)[:, None]
+        spec = np.fft.rfft(xp[idx] * win[None, :], axis=1)
+        power = (spec.real ** 2 + spec.imag ** 2).T                                  # [freq, frames]
+        hz2mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)
+        mel2hz = lambda m: 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+        pts = mel2hz(np.linspace(hz2mel(fmin), hz2mel(fmax), n_mels + 2))
+        freqs = np.linspace(0, sr // 2, n_fft // 2 + 1)
+        fb = np.zeros((n_mels, len(freqs)))
+        for m in range(n_mels):
+            lo, ce, hi = pts[m], pts[m + 1], pts[m + 2]
+            up = (freqs - lo) / (ce - lo)
+            down = (hi - freqs) / (hi - ce)
+            fb[m] = np.maximum(0.0, np.minimum(up, down))
+            if slaney:
+                fb[m] *= 2.0 / (hi - lo)
+        return fb @ power
+
+    ours = Cn.mel_spectrogram(torch.from_numpy(x).float()[None], 22050, 2048, 1024, 256, 80, 0.0, 8000.0, "hann", slaney_norm=True)[0]
+    ref = mel_ref(x, 22050, 2048, 1024, 256, 80, 0.0, 8000.0, "hann", True)
+    assert ours.shape == ref.shape
+    assert np.abs(ours.numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+    # the fixture's own log-mel (what the reference classes were fed) is this front-end's output
+    logm = torch.log(torch.clamp(ours, min=1e-5)).numpy()
+    assert np.abs(logm - g["mel_gpt"][0].astype(np.float32)).max() < 2e-2           # (fixture stores fp16)
+    a16 = Cn.resample(torch.from_numpy(x).float()[None], 22050, 16000)[0].numpy().astype(np.float64)
+    pre = np.concatenate([[a16[1]], a16])                                             # reflect pad of one sample
+    pre = pre[1:] - 0.97 * pre[:-1]
+    ours16 = Cn.mel_spectrogram(torch.from_numpy(pre).float()[None], 16000, 512, 400, 160, 64, window="hamming")[0]
+    ref16 = mel_ref(pre, 16000, 512, 400, 160, 64, 0.0, 8000.0, "hamming", False)
+    assert np.abs(ours16.numpy() - ref16).max() <= 2e-4 * np.abs(ref16).max()
+
+
+def test_resampler_against_scipy_polyphase():
+    """22 050 -> 16 000 Hz on real speech: the windowed-sinc resampler (torchaudio's default kernel restated) against
+    scipy.signal.resample_poly (Kaiser-windowed polyphase FIR): different filters, so only band-limited agreement is asked."""
+    import scipy.signal as ss
+    g = _golden()
+    x = g["pcm16"].astype(np.float64) / 32767.0
+    ours = Cn.resample(torch.from_numpy(x).float()[None], 22050, 16000)[0].numpy()
+    ref = ss.resample_poly(x, 320, 441)
+    n = min(len(ours), len(ref))
+    assert abs(len(ours) - len(ref)) <= 1
+    err = ours[200:n - 200] - ref[200:n - 200]
+    assert np.sqrt(np.mean(err ** 2)) < 0.05 * np.sqrt(np.mean(ref[200:n - 200] ** 2))
