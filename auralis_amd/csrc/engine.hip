@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void init_slots_kernel(const SlotInit* __restr
 struct RowWs {
     hipStream_t st = nullptr;
     int rows_cap = 0;
-    DevBuf h, xn, qbuf, att, act, P, P2, ybuf, stats;   // stats: LayerNorm partials of the packed residual stream [rows][64] float2
+    DevBuf h, xn, qbuf, att, act, P, P2, ybuf, stats, row_meta;   // row_meta: per-row K/V addressing of the current decode step   // stats: LayerNorm partials of the packed residual stream [rows][64] float2
     DevBuf i_row_slot, i_row_pos, i_desc, i_sample_row, i_sample_slot, i_next_kvpos, i_out_tok;
     PinBuf pin;
     std::vector<int> sample_row, sample_slot;
@@ -942,6 +942,7 @@ private:
         const int cap = (std::max(M, 64) + 63) / 64 * 64;   // whole 64-row groups: the decode chain keeps its rows packed (pk_off)
         w.ybuf.ensure((size_t)cap * kHidden * 4);
         w.stats.ensure((size_t)cap * 64 * sizeof(float2));
+        w.row_meta.ensure((size_t)cap * kRowMetaStride * sizeof(int));
         w.h.ensure((size_t)cap * kHidden * 4);
         w.xn.ensure((size_t)cap * kHidden * 4);
         w.qbuf.ensure((size_t)cap * kHidden * 4);
@@ -1015,15 +1016,15 @@ private:
             a.M = M; a.eps = 1e-5f;
             a.X = h; a.xmt = mtt; a.Wt = L.tqkv; a.N = 3 * kHidden; a.K = kHidden; a.bias = L.bqkv;
             a.gamma = L.ln1w; a.beta = L.ln1b; a.stats_in = w.stats.as<float2>(); a.out = w.qbuf.as<float>(); a.ldo = kHidden;
-            a.kv_layer = kvl; a.kv_half = kv_half_ ? 1 : 0; a.row_slot = d_row_slot; a.slot_kvpos = kvpos; a.block_tables = bt; a.max_blocks = kMaxBlocks;
+            a.kv_layer = kvl; a.kv_half = kv_half_ ? 1 : 0; a.row_meta = w.row_meta.as<int>(); a.row_slot = d_row_slot; a.slot_kvpos = kvpos; a.block_tables = bt; a.max_blocks = kMaxBlocks;
             gemm_rows(w, a, true, kEpiQkv, 0);
             if (gemm_prof_now_) {
                 ConvEvent& ev = prof_event(5, 4.0 * kHidden * step_kv_tokens_, (kv_half_ ? 4.0 : 8.0) * kHidden * step_kv_tokens_ + 8.0 * kHidden * M);
                 HIP_CHECK(hipEventRecord(ev.a, w.st));
-                launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, nullptr, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, mtt, kv_half_);
+                launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, nullptr, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, mtt, kv_half_, w.row_meta.as<int>());
                 HIP_CHECK(hipEventRecord(ev.b, w.st));
             } else {
-                launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, nullptr, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, mtt, kv_half_);
+                launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, nullptr, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, mtt, kv_half_, w.row_meta.as<int>());
             }
             a = GemmRowsArgs{};
             a.M = M; a.X = w.att.as<float>(); a.xmt = mtt; a.Wt = L.tproj; a.N = kHidden; a.K = kHidden; a.bias = L.bproj;
@@ -1333,7 +1334,8 @@ private:
     // GEMMs are latency bound, the attention is bandwidth bound: the chains fill each other's gaps).
     void decode_kernels(RowWs& w, int Mk) {
         launch_embed_decode(w.i_row_slot.as<int>(), slot_tok_.as<int>(), slot_pos_.as<int>(), wte_, wpe_, w.h.as<float>(), Mk, w.st,
-                            rows_gemm_ ? w.rows_cap / 16 : 0, rows_gemm_ ? w.stats.as<float2>() : nullptr);
+                            rows_gemm_ ? w.rows_cap / 16 : 0, rows_gemm_ ? w.stats.as<float2>() : nullptr,
+                            rows_gemm_ ? w.row_meta.as<int>() : nullptr, slot_kvpos_.as<int>(), block_tables_.as<int>(), kMaxBlocks);
         if (rows_gemm_) {
             forward_decode(w, Mk, w.i_row_slot.as<int>());
             sample_kernels_decode(w, Mk);

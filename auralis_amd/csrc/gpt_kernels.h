@@ -112,6 +112,8 @@ struct GemmRowsArgs {
     const int* slot_kvpos;
     const int* block_tables;
     int max_blocks;
+    const int* row_meta; // optional dense per-row copy {pos, slot, .., block table at +kRowMetaBt} (embed_decode_kernel): one memory
+                         // round trip instead of the row_slot -> slot_kvpos -> block_tables chain at the end of the kernel
     // LayerNorm statistics travel as per-column-tile partials (mean_t, M2_t = sum (x - mean_t)^2 over the tile's 16 columns):
     // the kernels that WRITE the residual stream (embed_decode, the kEpiResidual epilogue) emit stats[row][tile] for the 64
     // tiles of a 1024-wide row, the LN prologue combines them (Chan's parallel variance, fixed order) instead of reducing the
@@ -149,7 +151,7 @@ void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, 
 // out_mtt > 0: `out` is written as packed rows with that many 16-row tiles (decode chain, A operand of the proj GEMM)
 void launch_paged_attention(const float* qbuf, const void* kv_layer, const int* row_slot, const int* row_pos,
                             const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
-                            hipStream_t st, int out_mtt = 0, bool kv_half = false);
+                            hipStream_t st, int out_mtt = 0, bool kv_half = false, const int* row_meta = nullptr);
 
 // decode rows (one new token per sequence): qkv epilogue + KV page write + attention in one launch, reading the QKV
 // GEMM slabs directly (bitwise the same result as launch_qkv_epilogue + launch_paged_attention)
@@ -161,9 +163,15 @@ void launch_qkv_attention_fused(const float* P, int S, const float* bias, float*
 void launch_embed_prompt(const int4* desc, const float* spk_cond, const float* text_emb, const float* text_pos,
                          const float* wte, const float* wpe, float* h, int M, hipStream_t st);
 // decode rows: h[m] = wte[tok[slot]] + wpe[pos[slot]]
-// h_mtt > 0: h is written as packed rows and stats[row][64] receives the LayerNorm partials of each row (GemmRowsArgs)
+// h_mtt > 0: h is written as packed rows and stats[row][64] receives the LayerNorm partials of each row (GemmRowsArgs).
+// row_meta (optional, [M][kRowMetaStride] ints): the step's per-row K/V addressing, gathered once per step for the 30
+// attention launches and QKV epilogues: [0] = K/V position of the new token (slot_kvpos), [1] = slot,
+// [kRowMetaBt ..] = the slot's block table.
+constexpr int kRowMetaStride = 80, kRowMetaBt = 8;
 void launch_embed_decode(const int* row_slot, const int* slot_tok, const int* slot_pos, const float* wte,
-                         const float* wpe, float* h, int M, hipStream_t st, int h_mtt = 0, float2* stats = nullptr);
+                         const float* wpe, float* h, int M, hipStream_t st, int h_mtt = 0, float2* stats = nullptr,
+                         int* row_meta = nullptr, const int* slot_kvpos = nullptr, const int* block_tables = nullptr,
+                         int max_blocks = 0);
 
 // y[j] = final_norm(xn[sample_row[j]]);  latents[slot][lat_idx[slot]] = final_norm(y[j])   (double final_norm,
 // XTTSv2.py:685-687 on top of vllm_mm_gpt.py:671)

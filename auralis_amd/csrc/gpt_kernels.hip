@@ -399,9 +399,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
             if (u == 0) {
                 a.out[(long)m * kHidden + d] = t;
             } else {
-                const int slot = a.row_slot[m];
-                const int pos = a.slot_kvpos[slot];
-                const int blk = a.block_tables[(long)slot * a.max_blocks + pos / kKvBlockTokens];
+                int pos, blk;
+                if (a.row_meta) {
+                    pos = a.row_meta[(long)m * kRowMetaStride];
+                    blk = a.row_meta[(long)m * kRowMetaStride + kRowMetaBt + pos / kKvBlockTokens];
+                } else {
+                    const int slot = a.row_slot[m];
+                    pos = a.slot_kvpos[slot];
+                    blk = a.block_tables[(long)slot * a.max_blocks + pos / kKvBlockTokens];
+                }
                 const long off = kv_offset(blk, u - 1, d / kHeadDim, pos % kKvBlockTokens) + d % kHeadDim;
                 if (a.kv_half) reinterpret_cast<_Float16*>(a.kv_layer)[off] = (_Float16)t;
                 else reinterpret_cast<float*>(a.kv_layer)[off] = t;
@@ -643,7 +649,7 @@ void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, 
 // FUSED (decode rows only): the row's q/k/v come straight from the QKV GEMM slabs (+ bias); the block writes its own
 // k,v into the page and uses them from registers, so the separate qkv_epilogue launch disappears.  Token t is still
 // handled by the same lane group in the same iteration => bitwise the same result as the unfused pair.
-template <bool FUSED, bool KVH, bool PF = false>
+template <bool FUSED, bool KVH, bool PF = false, int UN = 4>
 __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __restrict__ qbuf,
                                                               void* __restrict__ kv_layer_v,
                                                               const int* __restrict__ row_slot,
@@ -651,7 +657,8 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
                                                               const int* __restrict__ slot_kvpos,
                                                               const int* __restrict__ block_tables, int max_blocks,
                                                               float* __restrict__ out, const float* __restrict__ P,
-                                                              int S, const float* __restrict__ bias, int M, int out_mtt) {
+                                                              int S, const float* __restrict__ bias, int M, int out_mtt,
+                                                              const int* __restrict__ row_meta) {
     static_assert(!(FUSED && KVH), "the slab-fused decode path keeps fp32 K/V");
     // every lane moves 16 B per cached token: 16 lanes x 4 floats (fp32 pool) or 8 lanes x 8 halves (fp16 pool) span the 64-wide
     // head, so one wave instruction covers TPW = 4 or 8 consecutive tokens (1 KiB contiguous either way)
@@ -665,15 +672,21 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
     const int m = blockIdx.x, head = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int g = lane / LPT, dl = lane % LPT;
-    const int slot = row_slot[m];
-    const int pos = row_pos ? row_pos[m] : slot_kvpos[slot];
+    int pos;
+    const int* bt;
+    if (row_meta) {   // dense per-row copy made once per decode step: one round trip instead of three dependent ones
+        pos = row_meta[(long)m * kRowMetaStride];
+        bt = row_meta + (long)m * kRowMetaStride + kRowMetaBt;
+    } else {
+        const int slot = row_slot[m];
+        pos = row_pos ? row_pos[m] : slot_kvpos[slot];
+        bt = block_tables + (long)slot * max_blocks;
+    }
     const int n_keys = pos + 1;
-    const int* bt = block_tables + (long)slot * max_blocks;
     const KT* kv_layer = reinterpret_cast<const KT*>(kv_layer_v);
 
     // UN steps unrolled: all 2*UN K/V loads of a lane are issued before the first softmax update (addresses are clamped instead
     // of predicated so that the loads can be hoisted).  The first batch goes out before q is assembled: it does not depend on q.
-    constexpr int UN = 4;
     // (the fp16 pool's values stay packed, 4 registers per 8 halves, until they are used: as floats they cost 104 VGPRs)
     using RawT = typename std::conditional<KVH, h16x8g, f32x4>::type;
     RawT kraw[UN], vraw[UN], knext[UN], vnext[UN];
@@ -799,7 +812,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
 
 void launch_paged_attention(const float* qbuf, const void* kv_layer, const int* row_slot, const int* row_pos,
                             const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
-                            hipStream_t st, int out_mtt, bool kv_half) {
+                            hipStream_t st, int out_mtt, bool kv_half, const int* row_meta) {
     trace_launch("paged_attention_kernel");
     // AUR_ATTN_PREFETCH=1: issue the next iteration's K/V loads before reducing the current one.  Measured (r02, 64 x ctx ~243):
     // fp32 pool 26.0 vs 25.1 us, fp16 pool 17.7 vs 17.2 us per launch, i.e. the ~40 extra VGPRs cost more residency than the
@@ -809,10 +822,28 @@ void launch_paged_attention(const float* qbuf, const void* kv_layer, const int* 
         return e ? atoi(e) : 0;
     }();
     const bool prefetch = pf != 0;
+    // AUR_ATTN_UN=8: 8 instead of 4 token steps (2 x 8 K/V loads per lane) in flight per workgroup iteration: half the
+    // serialized memory round trips per row at the cost of registers the 4 workgroups per CU do not need anyway
+    static const int un = [] {
+        const char* e = getenv("AUR_ATTN_UN");
+        return e ? atoi(e) : 4;
+    }();
+    if (un == 8 && !prefetch) {
+        if (kv_half)
+            hipLaunchKernelGGL((paged_attention_kernel<false, true, false, 8>), dim3(M, kHeads), dim3(256), 0, st, qbuf,
+                               const_cast<void*>(kv_layer), row_slot, row_pos, slot_kvpos, block_tables, max_blocks, out,
+                               (const float*)nullptr, 0, (const float*)nullptr, M, out_mtt, row_meta);
+        else
+            hipLaunchKernelGGL((paged_attention_kernel<false, false, false, 8>), dim3(M, kHeads), dim3(256), 0, st, qbuf,
+                               const_cast<void*>(kv_layer), row_slot, row_pos, slot_kvpos, block_tables, max_blocks, out,
+                               (const float*)nullptr, 0, (const float*)nullptr, M, out_mtt, row_meta);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
 #define AUR_ATT(KVH_, PF_)                                                                                                      \
     hipLaunchKernelGGL((paged_attention_kernel<false, KVH_, PF_>), dim3(M, kHeads), dim3(256), 0, st, qbuf,                     \
                        const_cast<void*>(kv_layer), row_slot, row_pos, slot_kvpos, block_tables, max_blocks, out,               \
-                       (const float*)nullptr, 0, (const float*)nullptr, M, out_mtt)
+                       (const float*)nullptr, 0, (const float*)nullptr, M, out_mtt, row_meta)
     if (kv_half) {
         if (prefetch) AUR_ATT(true, true);
         else AUR_ATT(true, false);
@@ -829,7 +860,7 @@ void launch_qkv_attention_fused(const float* P, int S, const float* bias, float*
                                 hipStream_t st) {
     trace_launch("paged_attention_kernel<fused>");
     hipLaunchKernelGGL((paged_attention_kernel<true, false>), dim3(M, kHeads), dim3(256), 0, st, (const float*)nullptr, (void*)kv_layer,
-                       row_slot, (const int*)nullptr, slot_kvpos, block_tables, max_blocks, out, P, S, bias, M, 0);
+                       row_slot, (const int*)nullptr, slot_kvpos, block_tables, max_blocks, out, P, S, bias, M, 0, (const int*)nullptr);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -866,10 +897,20 @@ __global__ __launch_bounds__(256) void embed_decode_kernel(const int* __restrict
                                                            const int* __restrict__ slot_pos,
                                                            const float* __restrict__ wte,
                                                            const float* __restrict__ wpe, float* __restrict__ h, int h_mtt,
-                                                           float2* __restrict__ stats) {
+                                                           float2* __restrict__ stats, int* __restrict__ row_meta,
+                                                           const int* __restrict__ slot_kvpos,
+                                                           const int* __restrict__ block_tables, int max_blocks) {
     const int m = blockIdx.x;
     const int slot = row_slot[m];
     const int n = 4 * threadIdx.x;
+    if (row_meta) {   // the step's K/V addressing of this row, dense (kRowMetaStride ints)
+        int* rm = row_meta + (long)m * kRowMetaStride;
+        if (threadIdx.x == 0) {
+            rm[0] = slot_kvpos[slot];
+            rm[1] = slot;
+        }
+        if ((int)threadIdx.x < max_blocks) rm[kRowMetaBt + threadIdx.x] = block_tables[(long)slot * max_blocks + threadIdx.x];
+    }
     const f32x4 v = *reinterpret_cast<const f32x4*>(wte + (long)slot_tok[slot] * kHidden + n) +
                     *reinterpret_cast<const f32x4*>(wpe + (long)slot_pos[slot] * kHidden + n);
     *reinterpret_cast<f32x4*>(h + (h_mtt > 0 ? pk_off(m, n, h_mtt) : (long)m * kHidden + n)) = v;
@@ -891,9 +932,12 @@ __global__ __launch_bounds__(256) void embed_decode_kernel(const int* __restrict
 }
 
 void launch_embed_decode(const int* row_slot, const int* slot_tok, const int* slot_pos, const float* wte,
-                         const float* wpe, float* h, int M, hipStream_t st, int h_mtt, float2* stats) {
+                         const float* wpe, float* h, int M, hipStream_t st, int h_mtt, float2* stats, int* row_meta,
+                         const int* slot_kvpos, const int* block_tables, int max_blocks) {
+    AUR_REQUIRE(!row_meta || (slot_kvpos && block_tables && max_blocks + kRowMetaBt <= kRowMetaStride), "embed_decode: row meta");
     trace_launch("embed_decode_kernel");
-    hipLaunchKernelGGL(embed_decode_kernel, dim3(M), dim3(256), 0, st, row_slot, slot_tok, slot_pos, wte, wpe, h, h_mtt, stats);
+    hipLaunchKernelGGL(embed_decode_kernel, dim3(M), dim3(256), 0, st, row_slot, slot_tok, slot_pos, wte, wpe, h, h_mtt, stats,
+                       row_meta, slot_kvpos, block_tables, max_blocks);
     HIP_CHECK(hipGetLastError());
 }
 
