@@ -210,6 +210,7 @@ public:
         if (const char* e = getenv("AUR_SAMPLER_FULL_SORT")) sampler_full_sort_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_FUSE_GELU")) fuse_gelu_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_DECODE_GEMM")) rows_gemm_ = std::string(e) != "splitk";
+        if (const char* e = getenv("AUR_PREFILL_GEMM")) tile_gemm_ = std::string(e) != "splitk";   // A/B: round-1 prefill GEMM
         AUR_REQUIRE(rows_gemm_ || !kv_half_, "kv_fp16 needs the gemm_rows decode chain (AUR_DECODE_GEMM=splitk keeps fp32 K/V)");
         if (const char* e = getenv("AUR_TEST_FAIL_STEP")) fail_at_step_ = atoi(e);
 
@@ -665,6 +666,9 @@ public:
         } else if (kw == 2) {
             pl.fused = true; pl.slabs = 1;
         }
+        if (kw == 3) {   // kw == 3: the prefill-regime LDS-tiled kernel
+            pl.tile = true; pl.slabs = 1;
+        }
         const int S = pl.slabs;
         DevBuf dx, dw, dp, dout;
         dx.ensure((size_t)M * K * 4);
@@ -672,7 +676,8 @@ public:
         dp.ensure((size_t)S * M * N * 4);
         HIP_CHECK(hipMemcpy(dx.p, X, (size_t)M * K * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(dw.p, Wm, (size_t)K * N * 4, hipMemcpyHostToDevice));
-        launch_gemm_splitk(dx.as<float>(), K, dw.as<float>(), dp.as<float>(), M, N, K, pl, st_);
+        if (pl.tile) launch_gemm_tile(dx.as<float>(), K, dw.as<float>(), dp.as<float>(), M, N, K, st_);
+        else launch_gemm_splitk(dx.as<float>(), K, dw.as<float>(), dp.as<float>(), M, N, K, pl, st_);
         HIP_CHECK(hipStreamSynchronize(st_));
         std::vector<float> hp((size_t)S * M * N);
         HIP_CHECK(hipMemcpy(hp.data(), dp.p, hp.size() * 4, hipMemcpyDeviceToHost));
@@ -959,6 +964,10 @@ private:
     // profile mode: HIP-event pairs around the GEMM launches of every 16th decode step (sampled: 121 per step)
     bool gemm(RowWs& w, const float* X, int ldx, const float* Wm, float* P, int M, int N, int K, const GemmPlan& pl,
               const GemmGelu* gelu = nullptr) {
+        if (pl.tile) {
+            launch_gemm_tile(X, ldx, Wm, P, M, N, K, w.st, gelu);
+            return gelu != nullptr;
+        }
         if (!gemm_prof_now_) return launch_gemm_splitk(X, ldx, Wm, P, M, N, K, pl, w.st, gelu);
         if (n_gemm_events_ == gemm_events_.size()) {
             ConvEvent e{};
@@ -1095,7 +1104,15 @@ private:
         const int* bt = block_tables_.as<int>();
         const int* kvpos = slot_kvpos_.as<int>();
         launch_rows_ln(nullptr, 0, nullptr, h, layers_[0].ln1w, layers_[0].ln1b, xn, M, 1e-5f, w.st);
-        const GemmPlan p1 = gemm_plan(M, kHidden), p4 = gemm_plan(M, 4 * kHidden);
+        GemmPlan p1 = gemm_plan(M, kHidden), p4 = gemm_plan(M, 4 * kHidden);
+        // prefill-type calls (explicit row positions: prompt prefill, speaker prefix, literal second pass) run on the LDS-tiled
+        // GEMM whatever M is (one slab, k ascending for every M => a prompt's rows do not depend on what else was admitted);
+        // the round-1 decode chain (d_row_pos == nullptr, AUR_DECODE_GEMM=splitk) keeps the split-K kernel
+        const bool tile = tile_gemm_ && d_row_pos != nullptr;
+        if (tile) {
+            p1.tile = p4.tile = true;
+            p1.slabs = p4.slabs = 1;
+        }
         const int S1 = p1.slabs, S4 = p4.slabs;
         for (int l = 0; l < cfg_.n_layer; ++l) {
             const LayerW& L = layers_[l];
@@ -1786,6 +1803,7 @@ private:
     std::vector<std::unique_ptr<DevBuf>> packed_;   // pack_wt16 copies (decode GEMM layout)
     const float* thead_ = nullptr;
     int fail_at_step_ = 0;              // AUR_TEST_FAIL_STEP=n: throw inside the n-th aur_step (recovery test)
+    bool tile_gemm_ = true;             // AUR_PREFILL_GEMM=splitk selects the round-1 fused-slice kernel for prefill-type GEMMs
     bool rows_gemm_ = true;             // AUR_DECODE_GEMM=splitk selects the round-1 decode chain
     const float *wte_ = nullptr, *wpe_ = nullptr, *lnfw_ = nullptr, *lnfb_ = nullptr, *fnw_ = nullptr, *fnb_ = nullptr,
                 *headT_ = nullptr, *headb_ = nullptr, *text_emb_ = nullptr, *text_pos_ = nullptr;

@@ -18,6 +18,7 @@ struct GemmPlan {
     int slices;  // K / (4*kw)
     bool fused;  // slice loop inside the kernel (one output slab) instead of one slab per slice
     int slabs;   // slabs the epilogue has to sum
+    bool tile = false;   // prefill-regime LDS-tiled kernel (launch_gemm_tile) instead of the split-K kernel; slabs == 1
 };
 GemmPlan gemm_plan(int M, int K);
 
@@ -132,6 +133,14 @@ void launch_pack_wt16(const float* W, int ldw, float* Wt, int K, int N, hipStrea
 void launch_final_rows(const float* h, int mtt, const int* sample_slot, const float* lnf_w, const float* lnf_b, const float* fn_w,
                        const float* fn_b, float* ybuf, float* latents, long lat_slot_stride, const int* slot_ngen,
                        int max_lat_rows, int Ms, float eps, hipStream_t st);
+
+// Prefill-regime GEMM (M = sum of prompt rows, hundreds to thousands): P[m][n] = sum_k X[m][k] * W[k][n] as ONE slab, or
+// act[m][n] = gelu_new(that + bias[n]) when `gelu` is given.  128 x 128 output tile per workgroup, K in steps of 16 through a
+// double-buffered LDS stage, exact-f32 v_mfma_f32_32x32x2_f32 (each wave a 64 x 64 sub-tile); W in the file's [K][N] layout.
+// Every output element sums k in ascending order whatever M is, so prefill results do not depend on what else was admitted
+// in the same step (all prefill-type calls use this kernel, small M included).  N % 128 == 0, K % 16 == 0.
+void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, int N, int K, hipStream_t st,
+                      const GemmGelu* gelu = nullptr);
 
 // h[m] += sum_s P[s][m] + bias (if S > 0); out[m] = LayerNorm(h[m]; gamma, beta, eps).  Rows of 1024.
 void launch_rows_ln(const float* P, int S, const float* bias, float* h, const float* gamma, const float* beta,

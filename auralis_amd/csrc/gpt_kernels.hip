@@ -200,6 +200,141 @@ bool launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M
 }
 
 // ------------------------------------------------------------------------------------------------
+// Prefill-regime GEMM: see gpt_kernels.h.  LDS stage per K step of 16: A tile stored k-major ([k][128 rows], so that the MFMA A
+// operand — lane = row, two k per instruction — is a conflict-free ds_read_b32), B tile [k][128 columns] as loaded.  The global
+// loads of step i+1 are issued before the 32 MFMAs of step i and written to the other buffer after them: one barrier per step.
+template <int BM, int BN, bool GELU>
+__global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W,
+                                                           float* __restrict__ P, int M, int N, int K, GemmGelu ep) {
+    static_assert((BM == 128 || BM == 64) && (BN == 128 || BN == 64), "tile shapes");
+    constexpr int BK = 16, PA = BM + 4, PB = BN + 4;
+    constexpr int MI = BM / 64, NI = BN / 64;   // 32 x 32 MFMA tiles per wave (waves form a 2 x 2 grid over the tile)
+    constexpr int LA = BM / 64, LB = BN / 64;   // float4 loads per thread and K step for the A / B tile
+    __shared__ __attribute__((aligned(16))) float As[2][BK][PA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][PB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5, wm = wv >> 1, wn = wv & 1;
+    // XCD-aware order: the row tiles of one column tile get ids 8 apart, so the weight panel of a column tile stays in one
+    // XCD's L2 while the activation panels stream past it
+    const int n_nt = N / BN, n_mt = (M + BM - 1) / BM;
+    int ntile, mtile;
+    {
+        const int L = blockIdx.x;
+        if ((n_nt & 7) == 0) {
+            const int xcd = L & 7, slot = L >> 3;
+            mtile = slot % n_mt;
+            ntile = (slot / n_mt) * 8 + xcd;
+        } else {
+            mtile = L % n_mt;
+            ntile = L / n_mt;
+        }
+    }
+    const int m0 = mtile * BM, n0 = ntile * BN;
+    // staging roles: A = float4 of 4 consecutive k for row tid/4 (+64), B = float4 of 4 columns for k row tid/(BN/4) (+256/(BN/4))
+    constexpr int BT = BN / 4;                  // threads per B row
+    const int a_row = tid >> 2, a_kq = tid & 3, b_kr = tid / BT, b_n4 = tid % BT;
+    const float* ap[LA];
+    const float* bp[LB];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int r = m0 + a_row + 64 * i;
+        ap[i] = X + (long)(r < M ? r : M - 1) * ldx + 4 * a_kq;   // rows >= M alias the last row: never stored
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) bp[i] = W + (long)(b_kr + (256 / BT) * i) * N + n0 + 4 * b_n4;
+    f32x4 ga[LA], gb[LB];
+    auto g_load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) ga[i] = *reinterpret_cast<const f32x4*>(ap[i] + k0);
+#pragma unroll
+        for (int i = 0; i < LB; ++i) gb[i] = *reinterpret_cast<const f32x4*>(bp[i] + (long)k0 * N);
+    };
+    auto s_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) As[buf][4 * a_kq + c][a_row + 64 * i] = ga[i][c];
+#pragma unroll
+        for (int i = 0; i < LB; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][b_kr + (256 / BT) * i][4 * b_n4]) = gb[i];
+    };
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    g_load(0);
+    s_store(0);
+    __syncthreads();
+    const int n_steps = K / BK;
+    for (int st = 0; st < n_steps; ++st) {
+        const int cur = st & 1;
+        const bool more = st + 1 < n_steps;
+        if (more) g_load((st + 1) * BK);
+        __builtin_amdgcn_sched_barrier(0);   // the next step's loads are in flight before this step's MFMAs
+        const float* arow = &As[cur][hi][wm * (BM / 2) + l31];
+        const float* brow = &Bs[cur][hi][wn * (BN / 2) + l31];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float av[MI], bv[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) av[mi] = arow[2 * kk * PA + 32 * mi];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bv[ni] = brow[2 * kk * PB + 32 * ni];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (more) s_store(cur ^ 1);
+        __syncthreads();
+    }
+    // D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = n0 + wn * (BN / 2) + ni * 32 + l31;
+            float bv = 0.f;
+            if (GELU) bv = ep.bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row < M) {
+                    if (GELU) ep.act[(long)row * N + col] = gelu_new(acc[mi][ni][r] + bv);
+                    else P[(long)row * N + col] = acc[mi][ni][r];
+                }
+            }
+        }
+}
+
+void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, int N, int K, hipStream_t st,
+                      const GemmGelu* gelu) {
+    AUR_REQUIRE(N % 128 == 0 && K % 16 == 0 && ldx % 4 == 0 && M >= 1, "gemm_tile: shape");
+    trace_launch("gemm_tile_kernel");
+    const GemmGelu none{nullptr, nullptr};
+    // N = 1024 GEMMs (attention and MLP projections): 128 x 128 tiles give 8 x ceil(M/128) workgroups — 288 for a 64-prompt
+    // prefill, 1.1 per CU, half the chip idle in the second round — so they run on 64 x 64 tiles (1136 workgroups).  The k order
+    // of every output element is the same for both shapes.
+    static const int small_env = [] {
+        const char* e = getenv("AUR_GEMM_TILE_SMALL_N");
+        return e ? atoi(e) : 1024;
+    }();
+    if (N <= small_env) {
+        const dim3 grid((unsigned)((N / 64) * ((M + 63) / 64)));
+        if (gelu) hipLaunchKernelGGL((gemm_tile_kernel<64, 64, true>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, K, *gelu);
+        else hipLaunchKernelGGL((gemm_tile_kernel<64, 64, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, K, none);
+    } else {
+        const dim3 grid((unsigned)((N / 128) * ((M + 127) / 128)));
+        if (gelu) hipLaunchKernelGGL((gemm_tile_kernel<128, 128, true>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, K, *gelu);
+        else hipLaunchKernelGGL((gemm_tile_kernel<128, 128, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, K, none);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
 // Decode-regime GEMM: see gpt_kernels.h.  Reduction order of one output element: the MFMA k-chain of wave w over its
 // 64-wide slice of every chunk (chunks in order), then waves 0..15 in order — independent of M and of the other rows, so
 // continuous batching stays bitwise batch-invariant.

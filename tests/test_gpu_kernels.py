@@ -32,6 +32,29 @@ def test_gemm_splitk(eng, M, N, K, kw):
     assert err < 2e-4 * max(1.0, np.abs(ref).max()), err
 
 
+# kw = 3: the prefill-regime LDS-tiled kernel (128 x 128 tiles, one slab) that every prefill-type GEMM runs on
+@pytest.mark.parametrize("M,N,K", [(103, 3072, 1024), (71, 1024, 1024), (4544, 1024, 4096), (300, 4096, 1024), (1, 1024, 1024),
+                                   (129, 1024, 1024), (1000, 3072, 1024)])
+def test_gemm_tile(eng, M, N, K):
+    g = torch.Generator().manual_seed(M * 5 + N + K)
+    X = torch.randn(M, K, generator=g)
+    W = torch.randn(K, N, generator=g) * 0.05
+    ref = (X.double() @ W.double()).float().numpy()
+    got = eng.dbg_gemm(X.numpy(), W.numpy(), 3)
+    err = np.abs(got - ref).max()
+    assert err < 2e-4 * max(1.0, np.abs(ref).max()), err
+
+
+def test_gemm_tile_is_batch_invariant_bitwise(eng):
+    """A prompt's rows must not depend on how many other rows were admitted in the same prefill step."""
+    g = torch.Generator().manual_seed(9)
+    X = torch.randn(500, 1024, generator=g)
+    W = torch.randn(1024, 3072, generator=g) * 0.05
+    big = eng.dbg_gemm(X.numpy(), W.numpy(), 3)
+    for m in (1, 71, 128, 129, 300):
+        assert np.array_equal(big[:m], eng.dbg_gemm(X[:m].numpy(), W.numpy(), 3)), m
+
+
 def test_gemm_is_batch_invariant_bitwise(eng):
     """Fused-slice form (M > 128) and split form (M <= 128) add the K-slices in the same order."""
     g = torch.Generator().manual_seed(3)
