@@ -205,6 +205,7 @@ public:
         ws_[1].st = st2_;
         xt_f16_ = cfg_.vocoder_fp16 != 0;   // fp16 storage of the ResBlock c1 -> c2 intermediate (bit-identical, see ConvArgs)
         if (const char* e = getenv("AUR_XT_F16")) xt_f16_ = xt_f16_ && atoi(e) != 0;
+        if (const char* e = getenv("AUR_VOC_ACT2")) act2_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_DECODE_STREAMS")) decode_streams_ = atoi(e);
         if (const char* e = getenv("AUR_DECODE_PIPELINE")) pipeline_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_SAMPLER_FULL_SORT")) sampler_full_sort_ = atoi(e) != 0;
@@ -1594,7 +1595,8 @@ private:
             ev->flops = 2.0 * a.Cin * KS * a.Mtot * tot_in;
             // bytes in the dtype each tensor is actually stored in (the c1 -> c2 intermediate may be fp16)
             ev->bytes = (a.x_f16 ? 2.0 : 4.0) * a.Cin * tot_in +
-                        a.Cout * tot_out * ((a.out_act_f16 ? 2.0 : 4.0) + 4.0 * ((a.res ? 1.0 : 0.0) + (a.mrf_mode >= 2 ? 1.0 : 0.0)));
+                        a.Cout * tot_out * ((a.out_act_f16 ? 2.0 : 4.0) + (a.act2 ? 2.0 : 0.0) +
+                                            4.0 * ((a.res ? 1.0 : 0.0) + (a.mrf_mode >= 2 ? 1.0 : 0.0)));
             HIP_CHECK(hipEventRecord(ev->a, st_voc_));
         }
         if (cfg_.vocoder_fp16)
@@ -1650,6 +1652,7 @@ private:
         v_z_.ensure(Bz * 1024 * T * 4);
         v_s0_.ensure(Bz * 512 * T * 4);
         for (auto* b : {&v_A_, &v_B_, &v_C_, &v_D_, &v_E_}) b->ensure(Bz * 8192 * T * 4);
+        v_Ch_.ensure(Bz * 8192 * T * 2);
         HIP_CHECK(hipEventRecord(ev_va_, st_voc_));
         launch_interp2(d_lat, lat_bstride, d_latrow, d_nlat, d_len, v_z_.as<float>(), (long)T, (long)(1024 * T), 1024, B, maxT, st_voc_);
         const float* condt = voc_cond_.as<float>();
@@ -1666,6 +1669,7 @@ private:
         const float* in = v_s0_.as<float>();
         int Cin = 512, mul = 1, cond_off = 512;
         float *A = v_A_.as<float>(), *Bb = v_B_.as<float>(), *Cb = v_C_.as<float>(), *D = v_D_.as<float>(), *E = v_E_.as<float>();
+        void* Ch = v_Ch_.p;   // fp16(lrelu(Cb)), interleaved: written by the second conv of rounds 0 / 1, read by the next first conv
         for (int i = 0; i < 4; ++i) {
             const int s = rates[i], C = chans[i], mul_out = mul * s;
             const long Lin = (long)T * mul, Lout = (long)T * mul_out;
@@ -1681,9 +1685,11 @@ private:
             for (int j = 0; j < 3; ++j)
                 for (int c = 0; c < 3; ++c) {
                     const float* r = (c == 0) ? A : Cb;
+                    // rounds 1 and 2: the first conv reads the fp16 activated copy the previous round's second conv left in Ch
+                    const bool c1_h = xt_f16_ && act2_ && c > 0;
                     ConvArgs b1{};
                     b1.base_len = d_len; b1.B = B;
-                    b1.x = r; b1.wp = v_c1_[i][j][c].wp; b1.wp16 = v_c1_[i][j][c].wp16; b1.bias = v_c1_[i][j][c].bias; b1.out = Bb;
+                    b1.x = c1_h ? reinterpret_cast<const float*>(Ch) : r; b1.x_f16 = c1_h ? 1 : 0; b1.wp = v_c1_[i][j][c].wp; b1.wp16 = v_c1_[i][j][c].wp16; b1.bias = v_c1_[i][j][c].bias; b1.out = Bb;
                     b1.len_mul = mul_out; b1.Cin = C; b1.Mtot = C; b1.Cout = C;
                     b1.x_stride = Lout; b1.o_stride = Lout; b1.x_bstride = (long)C * Lout; b1.o_bstride = (long)C * Lout;
                     b1.padl = (rk[j] - 1) / 2 * rd[c]; b1.slope = 0.1f; b1.max_len = maxT * mul_out;
@@ -1691,6 +1697,7 @@ private:
                     conv(b1, rk[j], rd[c], totT * mul_out, totT * mul_out);
                     ConvArgs b2 = b1;
                     b2.out_act_f16 = 0; b2.x_f16 = xt_f16_ ? 1 : 0;
+                    if (xt_f16_ && act2_ && c < 2) { b2.act2 = Ch; b2.act2_slope = 0.1f; }
                     b2.x = Bb; b2.wp = v_c2_[i][j][c].wp; b2.wp16 = v_c2_[i][j][c].wp16; b2.bias = v_c2_[i][j][c].bias; b2.res = r;
                     b2.padl = (rk[j] - 1) / 2;
                     if (c < 2) {
@@ -1870,7 +1877,8 @@ private:
     // vocoder
     ConvLayer v_pre_, v_ups_[4], v_c1_[4][3][3], v_c2_[4][3][3];
     const float* v_post_ = nullptr;
-    DevBuf v_meta_, v_z_, v_s0_, v_A_, v_B_, v_C_, v_D_, v_E_, tmp_lat_, tmp_wav_;
+    DevBuf v_meta_, v_z_, v_s0_, v_A_, v_B_, v_C_, v_D_, v_E_, v_Ch_, tmp_lat_, tmp_wav_;
+    bool act2_ = true;                  // AUR_VOC_ACT2=0: first convs of rounds 1, 2 read the fp32 residual stream (A/B)
     std::vector<ConvEvent> conv_events_;
     std::vector<ConvEvent> gemm_events_;
     size_t n_gemm_events_ = 0;

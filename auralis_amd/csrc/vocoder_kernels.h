@@ -36,8 +36,16 @@ struct ConvArgs {
     // stores (_Float16)lrelu(value, out_slope) -- exactly what the consumer's staging would have produced from the fp32
     // value -- and the consumer sets x_f16 (input rows are halves, already activated; its `slope` is ignored).
     // Strides stay in elements.  Bit-identical results, half the bytes for that tensor.
+    // The fp16 activated tensors are CHANNEL-CHUNK INTERLEAVED: [B][C/16][stride positions][16 channels] halves, i.e. the 16
+    // input channels a staging chunk needs for one position are 32 contiguous bytes (two 16-byte loads per position instead
+    // of 16 two-byte ones; the producer stores 4 channels = 8 bytes at a time instead of single halves).
     int x_f16, out_act_f16;
     float out_slope;
+    // Second output of a residual conv: act2 = fp16(lrelu(out, act2_slope)) of the fp32 value it stores in `out`, in the same
+    // interleaved layout (strides o_stride / o_bstride), consumed by the next round's first conv with x_f16 — that conv then
+    // stages 2 B per element without conversion instead of 4 B + lrelu + cvt.  nullptr = off.
+    void* act2;
+    float act2_slope;
 };
 
 void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st);

@@ -45,6 +45,8 @@ __device__ __forceinline__ void conv_row_adds(const ConvArgs& a, float (&add)[16
     }
 }
 
+typedef _Float16 h16x4v __attribute__((ext_vector_type(4)));
+
 // plain conv (ups_s == 0): t == q, len_out == n_q
 template <int WM, int WN, int MT, int NTW, int MODE>
 __device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, f32x16 (&acc)[WM][WN], int b, int mtile, int q0, int wv,
@@ -73,16 +75,34 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, f32x16 (&
             }
             __builtin_amdgcn_sched_barrier(0);   // all loads of this 32x32 tile are in flight before the first use
             if (ok) {
+                float val[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long off = base + (long)((r & 3) + 8 * (r >> 2)) * a.o_stride;
-                    const float val = acc[m][n][r] + add[r] + rv[r];
-                    if (MODE == 0) {
-                        if (a.out_act_f16) reinterpret_cast<_Float16*>(a.out)[off] = (_Float16)lrelu(val, a.out_slope);
-                        else a.out[off] = val;
-                    } else if (MODE == 1) a.mrf[off] = val;
-                    else if (MODE == 2) a.mrf[off] = mv[r] + val;
-                    else a.out[off] = (mv[r] + val) / 3.0f;
+                for (int r = 0; r < 16; ++r) val[r] = acc[m][n][r] + add[r] + rv[r];
+                // interleaved fp16 tensors: this lane's registers 4g .. 4g+3 are channels c0 + 8g .. +3 of position q, i.e. 8
+                // contiguous bytes at [chunk (c0 + 8g)/16][q][(c0 + 8g) % 16]
+                const int c0 = mtile * MT + m * 32 + 4 * hi;
+                auto store_h = [&](void* dst, float sl) {
+                    _Float16* hb = reinterpret_cast<_Float16*>(dst) + ob;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = c0 + 8 * g;
+                        const h16x4v hv = {(_Float16)lrelu(val[4 * g], sl), (_Float16)lrelu(val[4 * g + 1], sl),
+                                           (_Float16)lrelu(val[4 * g + 2], sl), (_Float16)lrelu(val[4 * g + 3], sl)};
+                        *reinterpret_cast<h16x4v*>(hb + ((long)(c >> 4) * a.o_stride + q) * 16 + (c & 15)) = hv;
+                    }
+                };
+                if (MODE == 0 && a.out_act_f16) {
+                    store_h(a.out, a.out_slope);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long off = base + (long)((r & 3) + 8 * (r >> 2)) * a.o_stride;
+                        if (MODE == 0) a.out[off] = val[r];
+                        else if (MODE == 1) a.mrf[off] = val[r];
+                        else if (MODE == 2) a.mrf[off] = mv[r] + val[r];
+                        else a.out[off] = (mv[r] + val[r]) / 3.0f;
+                    }
+                    if (MODE == 0 && a.act2) store_h(a.act2, a.act2_slope);
                 }
             }
         }
@@ -318,7 +338,7 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 // 3 waves the prefetch registers spilled, which is why round 1 measured it slower).
 // WIDE (64-channel tiles only): 512 instead of 256 positions per workgroup — twice the MFMAs per staged weight chunk.
 template <int KS, int DIL, int MT, bool XH, bool PF, bool WIDE = false>
-__global__ __launch_bounds__(256, PF ? 2 : 3) void conv1d_mfma_f16_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, ((PF && !XH) || WIDE) ? 2 : 3) void conv1d_mfma_f16_kernel(ConvArgs a) {
     constexpr int CK = 16;
     constexpr int WM = MT / 32;
     constexpr int WN = (MT == 64) ? (WIDE ? 4 : 2) : 4;
@@ -357,7 +377,7 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv1d_mfma_f16_kernel(ConvAr
     const uint4* wsrc_tile = reinterpret_cast<const uint4*>(a.wp16) + (long)mtile * (a.Cin / CK) * NW;
 
     float xv[XH ? 1 : XI][XH ? 1 : CK];
-    _Float16 xhv[XH ? XI : 1][XH ? CK : 1];
+    h16x8 xlo[XH ? XI : 1], xhh[XH ? XI : 1];   // XH: the 16 channels of one position = 32 contiguous bytes (interleaved layout)
     uint4 w0, w1, w2, w3, w4, w5;
     w0 = w1 = w2 = w3 = w4 = w5 = uint4{0, 0, 0, 0};
 #define AUR_WLD(i, reg) \
@@ -373,10 +393,13 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv1d_mfma_f16_kernel(ConvAr
         for (int it = 0; it < XI; ++it) {
             const int t = q0 - a.padl + tid + it * 256;
             const int tc = min(max(t, 0), len_in - 1);
+            if constexpr (XH) {
+                const _Float16* p = xhb + ((long)(ci0 >> 4) * a.x_stride + tc) * 16;
+                xlo[it] = *reinterpret_cast<const h16x8*>(p);
+                xhh[it] = *reinterpret_cast<const h16x8*>(p + 8);
+            } else {
 #pragma unroll
-            for (int c = 0; c < CK; ++c) {
-                if constexpr (XH) xhv[it][c] = xhb[(long)(ci0 + c) * a.x_stride + tc];
-                else xv[it][c] = xb[(long)(ci0 + c) * a.x_stride + tc];
+                for (int c = 0; c < CK; ++c) xv[it][c] = xb[(long)(ci0 + c) * a.x_stride + tc];
             }
         }
         AUR_WLD(0, w0) AUR_WLD(1, w1) AUR_WLD(2, w2) AUR_WLD(3, w3) AUR_WLD(4, w4) AUR_WLD(5, w5)
@@ -388,12 +411,13 @@ __global__ __launch_bounds__(256, PF ? 2 : 3) void conv1d_mfma_f16_kernel(ConvAr
             const int t = q0 - a.padl + i;
             const bool ok = (t >= 0 && t < len_in);
             h16x8 lo, hh;
+            if constexpr (XH) {
+                const h16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                lo = ok ? xlo[it] : zero;
+                hh = ok ? xhh[it] : zero;
+            } else {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                if constexpr (XH) {
-                    lo[c] = ok ? xhv[it][c] : (_Float16)0.f;
-                    hh[c] = ok ? xhv[it][c + 8] : (_Float16)0.f;
-                } else {
+                for (int c = 0; c < 8; ++c) {
                     lo[c] = (_Float16)(ok ? lrelu(xv[it][c], slope) : 0.f);
                     hh[c] = (_Float16)(ok ? lrelu(xv[it][c + 8], slope) : 0.f);
                 }
@@ -440,6 +464,8 @@ template <int KS, int DIL, bool XH, bool PF, bool WIDE>
 static void launch_conv_f16_pf(const ConvArgs& a, hipStream_t st) {
     AUR_REQUIRE(a.Cin % 16 == 0 && a.wp16, "conv f16: Cin % 16, packed fp16 weights");
     AUR_REQUIRE(!a.out_act_f16 || (a.mrf_mode == 0 && a.ups_s == 0), "conv f16: fp16 output only for plain convs");
+    AUR_REQUIRE(!a.act2 || (a.mrf_mode == 0 && a.ups_s == 0 && !a.out_act_f16), "conv f16: act2 only next to a plain fp32 output");
+    AUR_REQUIRE((!a.x_f16 && !a.out_act_f16 && !a.act2) || (a.Cin % 16 == 0 && a.Cout % 16 == 0), "conv f16: interleaved tensors need 16-channel chunks");
     const int n_q = a.ups_s ? a.max_len + 1 : a.max_len;
     trace_launch("conv1d_mfma_f16_kernel");
     if (a.Mtot % 64 == 0) {
@@ -454,32 +480,32 @@ static void launch_conv_f16_pf(const ConvArgs& a, hipStream_t st) {
     }
 }
 
-// AUR_F16_PF_MINC=<c>: convs with at least c input channels use the software-pipelined staging (A/B; see the kernel comment)
+// The software-pipelined (PF) and 512-position (WIDE) forms of the kernel were measured in round 2 and are NOT instantiated:
+//  * fp32-input staging (32 registers per chunk), 2 waves per SIMD, by input-channel threshold: convs 105.4-111.0 ms per
+//    64-utterance batch against 103.5 ms synchronous; 512-position tiles on top (spills at 256 VGPRs): 125.7-177.6 ms;
+//  * with the interleaved fp16 activated inputs (16 staging registers, no spills at 3 waves per SIMD): pipelined 92.4-94.8 ms,
+//    512-position tiles 93.3-93.7 ms, synchronous 94.1 ms — all within run-to-run noise.
+// PMC of the heavy kernels (k = 7 / 11 at 128 / 256 channels): waves spend 50-58 % of their cycles in SQ_WAIT_INST_ANY (issue
+// stalls) and 28-34 % parked on waitcnt / barriers, LDS bank conflicts are ~2 % — the limiter is inside the MFMA / LDS-read
+// issue stream, not the staging latency these variants attack.
 template <int KS, int DIL, bool XH>
 static void launch_conv_f16_t(const ConvArgs& a, hipStream_t st) {
-    static const int pf_minc = [] {
-        const char* e = getenv("AUR_F16_PF_MINC");
-        return e ? atoi(e) : 100000;
-    }();
-    static const int wide_minc = [] {   // AUR_F16_WIDE_MINC=<c>: pipelined convs with >= c input channels use 512-position tiles
-        const char* e = getenv("AUR_F16_WIDE_MINC");
-        return e ? atoi(e) : 100000;
-    }();
-    if (a.Cin >= pf_minc) {
-        if (a.Cin >= wide_minc && a.Mtot % 64 == 0) launch_conv_f16_pf<KS, DIL, XH, true, true>(a, st);
-        else launch_conv_f16_pf<KS, DIL, XH, true, false>(a, st);
-    } else {
-        launch_conv_f16_pf<KS, DIL, XH, false, false>(a, st);
-    }
+    launch_conv_f16_pf<KS, DIL, XH, false, false>(a, st);
 }
 
 void launch_conv1d_f16(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
-    if (a.x_f16) {   // fp16 inputs exist only for the second conv of a ResBlock pair (dilation 1)
+    if (a.x_f16) {   // fp16 activated inputs: the second conv of every ResBlock pair, and the first conv of rounds 1 and 2
         switch (KS * 16 + DIL) {
             case 3 * 16 + 1: launch_conv_f16_t<3, 1, true>(a, st); break;
+            case 3 * 16 + 3: launch_conv_f16_t<3, 3, true>(a, st); break;
+            case 3 * 16 + 5: launch_conv_f16_t<3, 5, true>(a, st); break;
             case 7 * 16 + 1: launch_conv_f16_t<7, 1, true>(a, st); break;
+            case 7 * 16 + 3: launch_conv_f16_t<7, 3, true>(a, st); break;
+            case 7 * 16 + 5: launch_conv_f16_t<7, 5, true>(a, st); break;
             case 11 * 16 + 1: launch_conv_f16_t<11, 1, true>(a, st); break;
-            default: throw InvalidArgument("launch_conv1d_f16: fp16 input only for k in {3,7,11}, dilation 1");
+            case 11 * 16 + 3: launch_conv_f16_t<11, 3, true>(a, st); break;
+            case 11 * 16 + 5: launch_conv_f16_t<11, 5, true>(a, st); break;
+            default: throw InvalidArgument("launch_conv1d_f16: fp16 input only for k in {3,7,11}, dilation in {1,3,5}");
         }
         HIP_CHECK(hipGetLastError());
         return;
