@@ -161,8 +161,8 @@ def build_report(args, st, dims, world, samples, dt, audio_s):
     if st["conv_ms"] > 0:
         g = 21301.0 * samples / world / (st["conv_ms"] * 1e-3) / 1e9
         roof_conv["survey_8d_fp32_bytes"] = {"bytes_per_sample": 21301, "achieved": g, "frac": g / HBM_PEAK_GBPS}
-    roof_attn = roof("paged_attention_kernel<false> (decode: one query row per sequence against its paged fp32 K/V)",
-                     st["attn_ms"], st["attn_launches"], st["attn_bytes"], 0.0, 1.0, r"paged_attention_kernel<false>", "attention",
+    roof_attn = roof("paged_attention_kernel<false, KVH, ..> (decode: one query row per sequence against its paged K/V)",
+                     st["attn_ms"], st["attn_launches"], st["attn_bytes"], 0.0, 1.0, r"paged_attention_kernel<false, (false|true), ", "attention",
                      "algorithmic bytes = K and V rows of every live sequence's context (8 KiB per token per layer) + q + out")
     gemms = []
     for k in range(5):

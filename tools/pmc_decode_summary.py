@@ -16,7 +16,7 @@ import os
 import re
 import sys
 
-KERNELS = [("attention", r"paged_attention_kernel<false>", None),
+KERNELS = [("attention", r"paged_attention_kernel<false(>|, )", None),
            ("gemm_qkv", r"gemm_rows_kernel<\d, 1, true, 3", 4.0 * (1024 * 3072 + 64 * 1024 + 64 * 3072)),
            ("gemm_proj", r"gemm_rows_kernel<\d, 1, false, 2", 4.0 * (1024 * 1024 + 64 * 1024 + 2 * 64 * 1024)),
            ("gemm_fc", r"gemm_rows_kernel<\d, 1, true, 1", 4.0 * (1024 * 4096 + 64 * 1024 + 64 * 4096)),
