@@ -1,12 +1,10 @@
 """TTSOutput — container for synthesized audio, API-compatible with the reference on the path's surface
 (src/auralis/common/definitions/output.py:16-329: array, sample_rate, start_time, token_length, combine_outputs,
 to_tensor, to_bytes, save, resample, get_info, from_tensor, from_file, change_speed).  Codec back-ends differ:
-the reference goes through torchaudio/librosa/sounddevice (absent offline); wav / raw PCM are written natively,
-other formats raise."""
+the reference goes through torchaudio/librosa/sounddevice (absent offline); wav, raw PCM and FLAC are written and read
+natively (api/codecs.py, api/flac.py), mp3 / opus / aac go to torchaudio or an ffmpeg executable when one is present."""
 from __future__ import annotations
 
-import io
-import wave
 from dataclasses import dataclass
 from pathlib import Path
 from typing import List, Optional, Tuple, Union
@@ -47,17 +45,8 @@ class TTSOutput:
 
     @classmethod
     def from_file(cls, filename: Union[str, Path]) -> "TTSOutput":
-        with wave.open(str(filename), "rb") as w:
-            n, sw, ch, sr = w.getnframes(), w.getsampwidth(), w.getnchannels(), w.getframerate()
-            raw = w.readframes(n)
-        if sw == 2:
-            a = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
-        elif sw == 4:
-            a = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
-        else:
-            raise ValueError(f"unsupported sample width {sw}")
-        if ch > 1:
-            a = a.reshape(-1, ch).mean(axis=1)
+        from . import codecs
+        a, sr = codecs.decode(str(filename))
         return cls(array=a, sample_rate=sr)
 
     # -- views ----------------------------------------------------------------------------------------
@@ -70,25 +59,10 @@ class TTSOutput:
         return n, self.sample_rate, n / float(self.sample_rate)
 
     def to_bytes(self, format: str = "wav", sample_width: int = 2) -> bytes:
-        fmt = format.lower()
-        pcm = np.clip(np.asarray(self.array, dtype=np.float32), -1.0, 1.0)
-        if sample_width == 2:
-            data = (pcm * 32767.0).astype("<i2").tobytes()
-        elif sample_width == 4:
-            data = (pcm.astype(np.float64) * 2147483647.0).astype("<i4").tobytes()
-        else:
-            raise ValueError("sample_width must be 2 or 4")
-        if fmt in ("pcm", "raw"):
-            return data
-        if fmt == "wav":
-            buf = io.BytesIO()
-            with wave.open(buf, "wb") as w:
-                w.setnchannels(1)
-                w.setsampwidth(sample_width)
-                w.setframerate(self.sample_rate)
-                w.writeframes(data)
-            return buf.getvalue()
-        raise ValueError(f"format '{format}' needs an external codec (reference uses torchaudio); wav/pcm are built in")
+        """output.py:119-187: 'mp3', 'opus', 'aac', 'flac', 'wav', 'pcm'; samples clamped to [-1, 1]."""
+        from . import codecs
+        return codecs.encode(np.asarray(self.array, dtype=np.float32), self.sample_rate, format, sample_width,
+                             bit_rate=self.bit_rate, compression=self.compression)
 
     def save(self, filename: Union[str, Path], sample_rate: Optional[int] = None, format: Optional[str] = None) -> None:
         out = self if sample_rate in (None, self.sample_rate) else self.resample(sample_rate)

@@ -53,5 +53,10 @@ class TTSRequest:
             self.language = get_language(self.text)
         validate_language(self.language)
 
+    def infer_language(self) -> None:
+        """Detect the language of `text` when it is "auto" (the reference's requests.py method of the same name)."""
+        if self.language == "auto" and isinstance(self.text, str) and len(self.text) > 0:
+            self.language = get_language(self.text)
+
     def copy(self) -> "TTSRequest":
         return _copy.copy(self)

@@ -28,34 +28,12 @@ Tensor = torch.Tensor
 
 # ----------------------------------------------------------------------------------------------- audio front-end
 def read_wav(src: Union[str, bytes]) -> Tuple[Tensor, int]:
-    """PCM wav (8/16/24/32-bit int or 32-bit float) -> mono float32 [1, n], sample rate."""
-    fh = io.BytesIO(src) if isinstance(src, (bytes, bytearray)) else open(src, "rb")
-    try:
-        data = fh.read()
-    finally:
-        fh.close()
-    if len(data) < 44 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
-        raise ValueError("reference audio must be a RIFF/WAVE file (other containers need an external decoder)")
-    fmt_tag = int.from_bytes(data[20:22], "little")
-    with wave.open(io.BytesIO(data if fmt_tag == 1 else data[:20] + (1).to_bytes(2, "little") + data[22:]), "rb") as w:
-        n, sw, ch, sr = w.getnframes(), w.getsampwidth(), w.getnchannels(), w.getframerate()
-        raw = w.readframes(n)
-    if fmt_tag == 3 and sw == 4:
-        a = np.frombuffer(raw, dtype="<f4").astype(np.float32)
-    elif sw == 2:
-        a = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
-    elif sw == 4:
-        a = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
-    elif sw == 3:
-        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
-        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
-        a = (np.where(v >= 1 << 23, v - (1 << 24), v)).astype(np.float32) / 8388608.0
-    elif sw == 1:
-        a = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
-    else:
-        raise ValueError(f"unsupported wav sample width {sw}")
-    a = a.reshape(-1, ch).mean(axis=1) if ch > 1 else a
-    return torch.from_numpy(np.ascontiguousarray(a)).unsqueeze(0), sr
+    """Reference audio (path or bytes) -> mono float32 [1, n], sample rate.  RIFF/WAVE (8/16/24/32-bit int, 32-bit float) and
+    FLAC are decoded natively; other containers through torchaudio / ffmpeg when present (api/codecs.py) - the reference uses
+    torchaudio.load (utilities.py:74-98)."""
+    from .api import codecs
+    a, sr = codecs.decode(src)
+    return torch.from_numpy(a).unsqueeze(0), sr
 
 
 def resample(x: Tensor, orig: int, new: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> Tensor:

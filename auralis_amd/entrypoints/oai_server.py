@@ -4,17 +4,24 @@ src/auralis/common/definitions/openai.py:111-164).  No arithmetic lives here.
 
     python -m auralis_amd.entrypoints.oai_server --model /path/to/checkpoint_dir --port 8000
 
-`voice` carries base64 files exactly like the reference: RIFF/WAVE reference audio, or an .npz with precomputed
-conditioning.  `/v1/chat/completions` (a proxy that TTS-es an upstream LLM stream, oai_server.py:95-222) is outside the
-synthesis path and answers 501."""
+`voice` carries base64 files exactly like the reference: reference audio (RIFF/WAVE or FLAC natively, other containers
+through torchaudio / ffmpeg when present), or an .npz with precomputed conditioning.  `response_format`: wav, pcm, flac are
+built in; mp3 / opus / aac need torchaudio or an ffmpeg executable (api/codecs.py) and otherwise answer the reference's
+500 envelope naming the missing back-end.  The default here is wav (the reference's is mp3).  `/v1/chat/completions` is the reference's voice-chat proxy (oai_server.py:95-222, request model
+common/definitions/openai.py:16-108): the request is forwarded to an upstream OpenAI-compatible `openai_api_url` with the caller's
+Bearer key, the streamed text deltas are passed through (modality "text") and vocalised every `vocalize_at_every_n_words`
+words (modality "audio": `audio.chunk` events carrying base64 WAV), then the remainder, a stop chunk and `[DONE]`."""
 from __future__ import annotations
 
 import argparse
+import asyncio
 import base64
-from typing import List, Literal, Optional
+import json
+import uuid
+from typing import Any, Dict, List, Literal, Optional
 
-from fastapi import FastAPI, HTTPException
-from fastapi.responses import JSONResponse, Response
+from fastapi import FastAPI, Header, HTTPException
+from fastapi.responses import JSONResponse, Response, StreamingResponse
 from pydantic import BaseModel, Field, field_validator
 
 from ..api.requests import TTSRequest
@@ -65,6 +72,75 @@ class AudioSpeechGenerationRequest(BaseModel):
                           length_penalty=self.length_penalty, do_sample=self.do_sample, seed=self.seed)
 
 
+class ChatCompletionMessage(BaseModel):
+    role: Literal["system", "user", "assistant"]
+    content: str
+
+
+_TTS_FIELDS = ("enhance_speech", "language", "max_ref_length", "gpt_cond_len", "gpt_cond_chunk_len", "temperature", "top_p",
+               "top_k", "repetition_penalty", "length_penalty", "do_sample")
+
+
+class VoiceChatCompletionRequest(BaseModel):
+    """Field for field the reference's model (openai.py:16-108); extra OpenAI fields (max_tokens, ...) are forwarded."""
+    model_config = {"extra": "allow"}
+    model: str
+    messages: List[ChatCompletionMessage]
+    speaker_files: List[str] = Field(..., description="List of base64-encoded audio files")
+    modalities: List[str] = Field(default=["text", "audio"])   # validated in the route: the reference answers 400, not 422
+    openai_api_url: Optional[str] = Field(default=None, validate_default=True)
+    vocalize_at_every_n_words: int = Field(default=100, ge=1)
+    stream: bool = True
+    enhance_speech: bool = False
+    language: str = "auto"
+    max_ref_length: int = 60
+    gpt_cond_len: int = 30
+    gpt_cond_chunk_len: int = 4
+    temperature: float = 0.75
+    top_p: float = 0.85
+    top_k: int = 50
+    repetition_penalty: float = 5.0
+    length_penalty: float = 1.0
+    do_sample: bool = True
+
+    @field_validator("openai_api_url")
+    @classmethod
+    def _url_required(cls, v):
+        if v is None:
+            raise ValueError("You should always give a url for the text generation")
+        return v
+
+    @field_validator("stream")
+    @classmethod
+    def _stream_only(cls, v):
+        if not v:
+            raise ValueError("Streaming should be enabled! For non-streaming conversion use the audio endpoint")
+        return v
+
+    @field_validator("speaker_files")
+    @classmethod
+    def _speakers_are_base64(cls, v):
+        if not v:
+            raise ValueError("At least one speaker file is required")
+        for f in v:
+            try:
+                base64.b64decode(f, validate=True)
+            except Exception:
+                raise ValueError("Invalid base64 encoding in speaker file")
+        return v
+
+    def to_tts_request(self, text: str = "") -> TTSRequest:
+        return TTSRequest(text=text, stream=False, speaker_files=[base64.b64decode(f) for f in self.speaker_files],
+                          **{k: getattr(self, k) for k in _TTS_FIELDS})
+
+    def to_openai_request(self) -> Dict[str, Any]:
+        """What goes upstream: everything except the speech-side fields, always streamed (openai.py:99-108)."""
+        drop = {"speaker_files", "openai_api_url", "vocalize_at_every_n_words", "modalities", *_TTS_FIELDS}
+        d = {k: v for k, v in self.model_dump().items() if k not in drop}
+        d["stream"] = True
+        return d
+
+
 def create_app(tts: Optional[TTS]) -> FastAPI:
     app = FastAPI(title="auralis_amd TTS server")
     app.state.tts = tts
@@ -86,9 +162,76 @@ def create_app(tts: Optional[TTS]) -> FastAPI:
         except Exception as e:  # same envelope as the reference (oai_server.py:92-93)
             return JSONResponse(status_code=500, content={"error": f"Error generating audio: {e}"})
 
+    async def _speak(engine: TTS, req: TTSRequest):
+        fut = asyncio.run_coroutine_threadsafe(engine.generate_speech_async(req), engine._loop)
+        return await asyncio.wrap_future(fut)
+
     @app.post("/v1/chat/completions")
-    async def chat_completions():
-        return JSONResponse(status_code=501, content={"error": "chat-completions proxy is outside the synthesis path"})
+    async def chat_completions(request: VoiceChatCompletionRequest, authorization: Optional[str] = Header(None)):
+        engine: Optional[TTS] = app.state.tts
+        if engine is None or engine.tts_engine is None:
+            raise HTTPException(status_code=500, detail="TTS engine not initialized")
+        if not authorization or not authorization.startswith("Bearer "):
+            return JSONResponse(status_code=400, content={"error": "Authorization header with Bearer token is required"})
+        valid = ["text", "audio"]
+        if not all(m in valid for m in request.modalities):
+            return JSONResponse(status_code=400, content={"error": f"Invalid modalities. Must be one or more of {valid}"})
+        try:
+            import aiohttp
+            modalities, every_n = request.modalities, request.vocalize_at_every_n_words
+            upstream_body = request.to_openai_request()
+            headers = {"Content-Type": "application/json", "Authorization": authorization}
+            request_id = uuid.uuid4().hex
+
+            async def audio_event(text: str) -> str:
+                req = request.to_tts_request(text=text)   # (language "auto" is resolved from this piece of text)
+                out = await _speak(engine, req)
+                b64 = base64.b64encode(out.to_bytes()).decode("utf-8")
+                return f"data: {json.dumps({'id': request_id, 'object': 'audio.chunk', 'data': b64})}\n\n"
+
+            async def stream_generator():
+                pending = ""
+                try:
+                    async with aiohttp.ClientSession() as session:
+                        async with session.post(request.openai_api_url, json=upstream_body, headers=headers) as resp:
+                            if resp.status != 200:
+                                raise HTTPException(status_code=resp.status, detail=await resp.text())
+                            async for raw in resp.content:
+                                line = raw.decode("utf-8").strip() if raw else ""
+                                if not line.startswith("data:"):
+                                    continue
+                                payload = line[5:].strip()
+                                if payload == "[DONE]":
+                                    break
+                                try:
+                                    data = json.loads(payload)
+                                except json.JSONDecodeError:
+                                    continue
+                                content = (data.get("choices") or [{}])[0].get("delta", {}).get("content", "")
+                                if content:
+                                    pending += content
+                                    if "text" in modalities:
+                                        yield f"data: {json.dumps(data)}\n\n"
+                                    if len(pending.split()) >= every_n:
+                                        if "audio" in modalities:
+                                            yield await audio_event(pending)
+                                        pending = ""
+                                elif "text" in modalities:
+                                    yield f"data: {json.dumps(data)}\n\n"
+                    if pending and "audio" in modalities:
+                        yield await audio_event(pending)
+                    if "text" in modalities:
+                        stop = {"id": request_id, "object": "chat.completion.chunk",
+                                "choices": [{"delta": {}, "index": 0, "finish_reason": "stop"}]}
+                        yield f"data: {json.dumps(stop)}\n\n"
+                    yield "data: [DONE]\n\n"
+                except Exception as e:   # same envelope as the reference: the error travels inside the event stream
+                    detail = getattr(e, "detail", None) or str(e)
+                    yield f"data: {json.dumps({'error': str(detail)})}\n\n"
+
+            return StreamingResponse(stream_generator(), media_type="text/event-stream")
+        except Exception as e:
+            return JSONResponse(status_code=500, content={"error": f"Error in chat completions: {e}"})
 
     @app.get("/health")
     async def health():

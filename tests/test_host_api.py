@@ -55,7 +55,7 @@ def test_output_roundtrip_and_transforms(tmp_path):
     both = TTSOutput.combine_outputs([o, o])
     assert len(both.array) == 48000
     with pytest.raises(ValueError):
-        o.to_bytes("mp3")
+        o.to_bytes("ogg-vorbis")          # not in the reference's format list (mp3 / opus / aac / flac: tests/test_codecs.py)
 
 
 def test_split_sentence_respects_limit_and_keeps_words():

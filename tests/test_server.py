@@ -34,9 +34,15 @@ def test_speech_endpoint_roundtrip(tmp_path):
         r = client.post("/v1/audio/speech", json={"input": "x", "model": "xtts", "voice": ["@@not-base64@@"]})
         assert r.status_code == 422
         r = client.post("/v1/audio/speech", json={"input": "hi", "model": "xtts", "voice": [_npz_voice()],
+                                                    "response_format": "flac", "language": "en"})
+        assert r.status_code == 200 and r.headers["content-type"] == "audio/flac" and r.content[:4] == b"fLaC"
+        from auralis_amd.api import codecs
+        r = client.post("/v1/audio/speech", json={"input": "hi", "model": "xtts", "voice": [_npz_voice()],
                                                     "response_format": "mp3", "language": "en"})
-        assert r.status_code == 500 and "error" in r.json()
-        assert client.post("/v1/chat/completions", json={}).status_code == 501
+        if codecs.external_backend() is None:   # lossy codecs need the reference's own back-end (torchaudio / ffmpeg)
+            assert r.status_code == 500 and "ffmpeg" in r.json()["error"]
+        else:
+            assert r.status_code == 200
         assert client.get("/health").json()["status"] == "ok"
     finally:
         tts.close()
@@ -46,3 +52,99 @@ def test_speech_endpoint_without_engine():
     client = fastapi_testclient.TestClient(create_app(None))
     r = client.post("/v1/audio/speech", json={"input": "hi", "model": "xtts", "voice": [_npz_voice()]})
     assert r.status_code == 500
+
+
+def _upstream_app(deltas):
+    """A stand-in for the upstream OpenAI-compatible endpoint: checks the forwarded request, streams `deltas` as SSE."""
+    from aiohttp import web
+    seen = {}
+
+    async def handler(request):
+        seen["auth"] = request.headers.get("Authorization")
+        seen["body"] = await request.json()
+        resp = web.StreamResponse(status=200, headers={"Content-Type": "text/event-stream"})
+        await resp.prepare(request)
+        await resp.write(b": keep-alive comment\n\n")
+        await resp.write(b'data: {"choices": [{"delta": {"role": "assistant"}}]}\n\n')
+        for d in deltas:
+            import json
+            await resp.write(("data: " + json.dumps({"choices": [{"delta": {"content": d}, "index": 0}]}) + "\n\n").encode())
+        await resp.write(b"data: not-json\n\n")
+        await resp.write(b"data: [DONE]\n\n")
+        await resp.write_eof()
+        return resp
+
+    async def refuse(request):
+        return web.Response(status=401, text="bad key")
+
+    app = web.Application()
+    app.router.add_post("/v1/chat/completions", handler)
+    app.router.add_post("/refuse", refuse)
+    return app, seen
+
+
+def test_chat_completions_proxy_streams_text_and_audio():
+    """The voice-chat proxy (reference oai_server.py:95-222): text deltas passed through, audio every n words + remainder,
+    stop chunk and [DONE]; Bearer key and the non-speech fields forwarded upstream; speech-side fields kept out of it."""
+    import asyncio
+    import json
+    import threading
+
+    from aiohttp import web
+    deltas = ["Hello there, ", "this is the first ", "part of the answer. ", "And here ", "comes the rest."]
+    up, seen = _upstream_app(deltas)
+    loop = asyncio.new_event_loop()
+    runner = web.AppRunner(up)
+    loop.run_until_complete(runner.setup())
+    site = web.TCPSite(runner, "127.0.0.1", 0)
+    loop.run_until_complete(site.start())
+    port = runner.addresses[0][1]
+    th = threading.Thread(target=loop.run_forever, daemon=True)
+    th.start()
+    fake = FakeNativeEngine(max_seqs=2)
+    tts = TTS(scheduler_max_concurrency=2).with_engine(XTTSv2Engine(fake, XTTSTokenizer(None, synthetic=True)))
+    try:
+        client = fastapi_testclient.TestClient(create_app(tts))
+        body = {"model": "some-llm", "messages": [{"role": "user", "content": "hi"}], "speaker_files": [_npz_voice()],
+                "openai_api_url": f"http://127.0.0.1:{port}/v1/chat/completions", "vocalize_at_every_n_words": 6,
+                "language": "en", "max_tokens": 64}
+        assert client.post("/v1/chat/completions", json=body).status_code == 400            # no Bearer token
+        hdr = {"Authorization": "Bearer sk-test"}
+        assert client.post("/v1/chat/completions", json={**body, "modalities": ["video"]}, headers=hdr).status_code == 400
+        assert client.post("/v1/chat/completions", json={**body, "stream": False}, headers=hdr).status_code == 422
+        no_url = {k: v for k, v in body.items() if k != "openai_api_url"}
+        assert client.post("/v1/chat/completions", json=no_url, headers=hdr).status_code == 422
+
+        r = client.post("/v1/chat/completions", json=body, headers=hdr)
+        assert r.status_code == 200 and r.headers["content-type"].startswith("text/event-stream")
+        events = [ln[5:].strip() for ln in r.text.splitlines() if ln.startswith("data:")]
+        assert events[-1] == "[DONE]"
+        objs = [json.loads(e) for e in events[:-1]]
+        text = "".join(o["choices"][0]["delta"].get("content", "") for o in objs if "choices" in o)
+        assert text == "".join(deltas)
+        audio = [o for o in objs if o.get("object") == "audio.chunk"]
+        # 6-word threshold: after delta 2 (6 words), after delta 4 (7 words since), and the remainder -> three audio events
+        assert len(audio) == 3 and len(fake.submitted) == 3
+        for o in audio:
+            wav = base64.b64decode(o["data"])
+            assert wav[:4] == b"RIFF" and len(wav) > 44
+        assert objs[-1]["choices"][0]["finish_reason"] == "stop"
+        # an audio event follows the text delta that crossed the threshold
+        kinds = ["a" if o.get("object") == "audio.chunk" else "t" for o in objs]
+        assert kinds.index("a") > 0 and kinds[kinds.index("a") - 1] == "t"
+        # what went upstream
+        assert seen["auth"] == "Bearer sk-test" and seen["body"]["stream"] is True and seen["body"]["max_tokens"] == 64
+        assert seen["body"]["model"] == "some-llm" and seen["body"]["messages"][0]["content"] == "hi"
+        for k in ("speaker_files", "openai_api_url", "vocalize_at_every_n_words", "modalities", "temperature", "language"):
+            assert k not in seen["body"]
+
+        r = client.post("/v1/chat/completions", json={**body, "modalities": ["audio"]}, headers=hdr)
+        objs = [json.loads(ln[5:]) for ln in r.text.splitlines() if ln.startswith("data:") and "[DONE]" not in ln]
+        assert objs and all(o.get("object") == "audio.chunk" for o in objs)                  # audio only: no text, no stop chunk
+
+        r = client.post("/v1/chat/completions", json={**body, "openai_api_url": f"http://127.0.0.1:{port}/refuse"}, headers=hdr)
+        assert r.status_code == 200 and "bad key" in r.text and "[DONE]" not in r.text       # upstream error inside the stream
+    finally:
+        tts.close()
+        loop.call_soon_threadsafe(loop.stop)
+        th.join(timeout=5)
