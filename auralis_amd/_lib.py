@@ -31,6 +31,11 @@ class aur_tensor_desc(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("numel", C.c_int64)]
 
 
+class aur_cond_params(C.Structure):
+    _fields_ = [("max_ref_length", C.c_int32), ("gpt_cond_len", C.c_int32), ("gpt_cond_chunk_len", C.c_int32),
+                ("sound_norm_refs", C.c_int32)]
+
+
 class aur_seq_desc(C.Structure):
     _fields_ = [("text_ids", C.POINTER(C.c_int32)), ("n_text", C.c_int32), ("speaker_key", C.c_uint64),
                 ("temperature", C.c_float), ("top_p", C.c_float), ("top_k", C.c_int32),
@@ -68,7 +73,7 @@ class aur_stats(C.Structure):
 # every symbol include/auralis_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "aur_last_error", "aur_version", "aur_engine_create", "aur_engine_destroy", "aur_load_weights",
-    "aur_set_conditioning", "aur_set_conditioning_device", "aur_has_conditioning", "aur_submit", "aur_step", "aur_poll_finished",
+    "aur_set_conditioning", "aur_set_conditioning_device", "aur_has_conditioning", "aur_compute_conditioning", "aur_submit", "aur_step", "aur_poll_finished",
     "aur_release", "aur_vocode", "aur_sync", "aur_get_stats", "aur_reset_stats", "aur_dbg_gemm", "aur_dbg_gemm_rows",
     "aur_dbg_gemm_tile_map", "aur_dbg_layernorm", "aur_dbg_conv1d", "aur_dbg_conv1d_f16", "aur_dbg_prefill", "aur_dbg_sample",
 ]
@@ -102,6 +107,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "aur_set_conditioning": [eng, C.c_uint64, fp, fp],
         "aur_set_conditioning_device": [eng, C.c_uint64, C.c_void_p, C.c_void_p],
         "aur_has_conditioning": [eng, C.c_uint64, ip],
+        "aur_compute_conditioning": [eng, C.POINTER(fp), ip, C.c_int32, C.POINTER(aur_cond_params), fp, fp],
         "aur_submit": [eng, C.POINTER(aur_seq_desc), C.POINTER(C.c_uint64)],
         "aur_step": [eng, ip, ip],
         "aur_poll_finished": [eng, C.POINTER(aur_result), C.c_size_t, C.POINTER(C.c_size_t)],
@@ -200,6 +206,19 @@ class NativeEngine:
         out = C.c_int32()
         self._check(self.lib.aur_has_conditioning(self.h, key, C.byref(out)))
         return bool(out.value)
+
+    def compute_conditioning(self, references, max_ref_length: int = 30, gpt_cond_len: int = 6, gpt_cond_chunk_len: int = 6,
+                             sound_norm_refs: bool = False):
+        """Reference audio (list of mono float32 arrays at 22 050 Hz) -> (gpt_cond_latent [1,32,1024], speaker_embedding
+        [1,512,1]) computed by the HIP kernels (needs weights.pack_conditioning in load_weights)."""
+        arrs = [_f32(np.asarray(r).reshape(-1)) for r in references]
+        ptrs = (C.POINTER(C.c_float) * len(arrs))(*[_fp(a) for a in arrs])
+        ns = _i32([a.size for a in arrs])
+        p = aur_cond_params(int(max_ref_length), int(gpt_cond_len), int(gpt_cond_chunk_len), int(bool(sound_norm_refs)))
+        g = np.empty((1, 32, 1024), np.float32)
+        s = np.empty((1, 512, 1), np.float32)
+        self._check(self.lib.aur_compute_conditioning(self.h, ptrs, _ip(ns), len(arrs), C.byref(p), _fp(g), _fp(s)))
+        return g, s
 
     def set_conditioning_device(self, key: int, d_gpt_cond_ptr: int, d_spk_ptr: int):
         self._check(self.lib.aur_set_conditioning_device(self.h, key, C.c_void_p(d_gpt_cond_ptr), C.c_void_p(d_spk_ptr)))

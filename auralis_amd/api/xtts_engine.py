@@ -2,8 +2,9 @@
 library: same public methods, same return shapes; vLLM, the second GPT pass and the torch HiFi-GAN are replaced by
 aur_submit / aur_step / aur_poll_finished.
 
-`speaker_files` may be reference audio (RIFF/WAVE paths or bytes: conditioning is computed once per speaker by
-auralis_amd/conditioning.py, SURVEY §8f #1, on the GPU through PyTorch-ROCm), a path/bytes of an .npz holding
+`speaker_files` may be reference audio (paths or bytes; RIFF/WAVE and FLAC natively, api/codecs.py): conditioning is computed
+once per speaker on the GPU by the HIP kernels behind aur_compute_conditioning (csrc/cond_net.h, SURVEY §8f #1;
+auralis_amd/conditioning.py is the PyTorch restatement the tests compare it with), a path/bytes of an .npz holding
 `gpt_cond_latent` [1,32,1024] and `speaker_embedding` [1,512,1], or a dict / tuple with those arrays."""
 from __future__ import annotations
 
@@ -68,6 +69,9 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
         native = NativeEngine(n_layer=n_layer, max_seqs=max(1, max_concurrency), device=device,
                               vocoder_fp16=(vocoder == "fp16"), return_latents=False)
         native.load_weights(pack_all(gpt_sd, xtts_sd))
+        if any(k.startswith("conditioning_encoder.") for k in xtts_sd):
+            from ..weights import pack_conditioning
+            native.load_weights(pack_conditioning(xtts_sd))
         tok_file = None
         for cand in ("tokenizer.json", os.path.join("gpt", "tokenizer.json")):
             p = os.path.join(pretrained_model_name_or_path, cand)
@@ -143,11 +147,25 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
             if key in self._cond_cache:
                 self._cond_cache.move_to_end(key)
             else:
-                dev = "cuda" if torch.cuda.is_available() else "cpu"
-                g_t, s_t = await asyncio.to_thread(Cn.get_conditioning_latents, self.conditioning_weights, refs,
-                                                   max_ref_length, gpt_cond_len, gpt_cond_chunk_len, sound_norm_refs,
-                                                   load_sr, dev)
-                self._cond_cache[key] = (g_t.float().cpu().numpy(), s_t.float().cpu().numpy())
+                hip = getattr(self.native, "compute_conditioning", None)
+                if hip is not None:
+                    # loader on the host (decode, mono, resample to 22 050 Hz, clip: utilities.py:74-98), networks in HIP
+                    def _run():
+                        pcm = []
+                        for r in refs:
+                            a = Cn.load_audio(r, load_sr)
+                            if load_sr != 22050:
+                                a = Cn.resample(a, load_sr, 22050)
+                            pcm.append(a[0].numpy())
+                        return hip(pcm, max_ref_length=max_ref_length, gpt_cond_len=gpt_cond_len,
+                                   gpt_cond_chunk_len=gpt_cond_chunk_len, sound_norm_refs=sound_norm_refs)
+                    self._cond_cache[key] = await asyncio.to_thread(_run)
+                else:   # engines without the entry point (CPU test doubles): the PyTorch restatement
+                    dev = "cuda" if torch.cuda.is_available() else "cpu"
+                    g_t, s_t = await asyncio.to_thread(Cn.get_conditioning_latents, self.conditioning_weights, refs,
+                                                       max_ref_length, gpt_cond_len, gpt_cond_chunk_len, sound_norm_refs,
+                                                       load_sr, dev)
+                    self._cond_cache[key] = (g_t.float().cpu().numpy(), s_t.float().cpu().numpy())
                 while len(self._cond_cache) > self._cond_cache_max:
                     self._cond_cache.popitem(last=False)
             g, s = self._cond_cache[key]

@@ -10,8 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_C")
 LIB = os.path.join(OUT_DIR, "libauralis_amd.so")
-SOURCES = ["vocoder_kernels.hip", "gpt_kernels.hip", "engine.hip"]
-HEADERS = ["common.h", "vocoder_kernels.h", "gpt_kernels.h", os.path.join("..", "..", "include", "auralis_amd.h")]
+SOURCES = ["vocoder_kernels.hip", "gpt_kernels.hip", "cond_kernels.hip", "engine.hip"]
+HEADERS = ["common.h", "vocoder_kernels.h", "gpt_kernels.h", "cond_kernels.h", "cond_net.h", os.path.join("..", "..", "include", "auralis_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 

@@ -67,6 +67,10 @@ struct PinBuf {
     }
 };
 
+}  // namespace aur
+#include "cond_net.h"   // (uses DevBuf)
+namespace aur {
+
 // Pinned result block of one vocoder batch: the D2H copies land here and aur_result.wav / .latents point straight into
 // it (no second host copy); the block returns to the pool when the last sequence of the batch is released.
 struct PinBlock {
@@ -316,6 +320,26 @@ public:
     bool has_conditioning(uint64_t key) {
         std::lock_guard<std::mutex> lk(mu_);
         return speaker_row(key, false) >= 0;
+    }
+    // Reference audio (mono float32, 22 050 Hz, host memory) -> gpt_cond_latent [32][1024], speaker_embedding [512] on the GPU
+    // (cond_net.h).  Needs the "cond.*" tensors of weights.py: pack_conditioning.
+    void compute_conditioning(const float* const* pcm, const int32_t* n_samples, int n_refs, const aur_cond_params& cp, float* out_cond,
+                              float* out_spk) {
+        std::lock_guard<std::mutex> gl(gpu_mu_);   // shares the GPT stream; not while a step is running
+        use();
+        if (!cond_net_) {
+            cond_net_.reset(new CondNet([this](const std::string& n, int64_t numel) { return W(n, numel); },
+                                        [this](const std::string& n) { return w_.find(n) != w_.end(); }, st_));
+        }
+        AUR_REQUIRE(w_.find("cond.enc.init.w") != w_.end(), "conditioning weights not loaded (pack_conditioning)");
+        CondParams p;
+        p.max_ref_length = cp.max_ref_length;
+        p.gpt_cond_len = cp.gpt_cond_len;
+        p.gpt_cond_chunk_len = cp.gpt_cond_chunk_len;
+        p.sound_norm_refs = cp.sound_norm_refs;
+        AUR_REQUIRE(p.max_ref_length > 0 && p.gpt_cond_chunk_len > 0, "conditioning: lengths must be positive");
+        std::vector<int> n(n_samples, n_samples + n_refs);
+        cond_net_->run(pcm, n.data(), n_refs, p, out_cond, out_spk);
     }
     void set_conditioning(uint64_t key, const float* gpt_cond, const float* spk, bool device_ptrs) {
         std::lock_guard<std::mutex> gl(gpu_mu_);   // may be called while the driver thread is inside aur_step
@@ -1838,6 +1862,7 @@ private:
     bool share_prefix_ = true;        // AUR_SHARE_PREFIX=0 disables
     bool share_prefix_now_ = true;    // dbg_prefill turns it off to return every prompt row
     std::mutex gpu_mu_;
+    std::unique_ptr<CondNet> cond_net_;
     // row workspace
     RowWs ws_[2];
     // vocoder stage
@@ -1977,6 +2002,16 @@ int aur_has_conditioning(aur_engine* e, uint64_t key, int32_t* out) {
     CHECK_PTR(e);
     CHECK_PTR(out);
     return guarded([&] { *out = e->impl.has_conditioning(key) ? 1 : 0; });
+}
+int aur_compute_conditioning(aur_engine* e, const float* const* pcm, const int32_t* n_samples, int32_t n_refs, const aur_cond_params* p,
+                             float* out_gpt_cond, float* out_spk_emb) {
+    CHECK_PTR(e);
+    CHECK_PTR(pcm);
+    CHECK_PTR(n_samples);
+    CHECK_PTR(p);
+    CHECK_PTR(out_gpt_cond);
+    CHECK_PTR(out_spk_emb);
+    return guarded([&] { e->impl.compute_conditioning(pcm, n_samples, n_refs, *p, out_gpt_cond, out_spk_emb); });
 }
 int aur_submit(aur_engine* e, const aur_seq_desc* seq, uint64_t* seq_id) {
     CHECK_PTR(e);

@@ -138,7 +138,7 @@ void launch_final_rows(const float* h, int mtt, const int* sample_slot, const fl
 // act[m][n] = gelu_new(that + bias[n]) when `gelu` is given.  128 x 128 output tile per workgroup, K in steps of 16 through a
 // double-buffered LDS stage, exact-f32 v_mfma_f32_32x32x2_f32 (each wave a 64 x 64 sub-tile); W in the file's [K][N] layout.
 // Every output element sums k in ascending order whatever M is, so prefill results do not depend on what else was admitted
-// in the same step (all prefill-type calls use this kernel, small M included).  N % 128 == 0, K % 16 == 0.
+// in the same step (all prefill-type calls use this kernel, small M included).  N % 64 == 0, K % 16 == 0.
 void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, int N, int K, hipStream_t st,
                       const GemmGelu* gelu = nullptr);
 

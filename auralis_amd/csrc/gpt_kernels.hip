@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const float* __restri
 
 void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, int N, int K, hipStream_t st,
                       const GemmGelu* gelu) {
-    AUR_REQUIRE(N % 128 == 0 && K % 16 == 0 && ldx % 4 == 0 && M >= 1, "gemm_tile: shape");
+    AUR_REQUIRE(N % 64 == 0 && K % 16 == 0 && ldx % 4 == 0 && M >= 1, "gemm_tile: shape");
     trace_launch("gemm_tile_kernel");
     const GemmGelu none{nullptr, nullptr};
     // N = 1024 GEMMs (attention and MLP projections): 128 x 128 tiles give 8 x ceil(M/128) workgroups — 288 for a 64-prompt
@@ -322,7 +322,7 @@ void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, 
         const char* e = getenv("AUR_GEMM_TILE_SMALL_N");
         return e ? atoi(e) : 1024;
     }();
-    if (N <= small_env) {
+    if (N <= small_env || N % 128 != 0) {
         const dim3 grid((unsigned)((N / 64) * ((M + 63) / 64)));
         if (gelu) hipLaunchKernelGGL((gemm_tile_kernel<64, 64, true>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, K, *gelu);
         else hipLaunchKernelGGL((gemm_tile_kernel<64, 64, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, K, none);

@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from typing import Dict
 
+import math
+
 import numpy as np
 import torch
 
@@ -142,6 +144,152 @@ def pack_all(gpt_sd, xtts_sd) -> Dict[str, np.ndarray]:
     d = pack_vocoder(xtts_sd)
     d.update(pack_gpt(gpt_sd, xtts_sd))
     return d
+
+
+# ---- speaker conditioning (cond_net.h / cond_kernels.h) ----------------------------------------------------------------------
+def _pad2(a: np.ndarray, rows: int, cols: int) -> np.ndarray:
+    out = np.zeros((rows, cols), np.float32)
+    out[: a.shape[0], : a.shape[1]] = a
+    return out
+
+
+def _pad1(a: np.ndarray, n: int, fill: float = 0.0) -> np.ndarray:
+    out = np.full((n,), fill, np.float32)
+    out[: a.shape[0]] = a
+    return out
+
+
+def _ceil(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def _dft_matrix(n_fft: int) -> np.ndarray:
+    """[n_fft][pad128(2 * bins)]: column 2k = cos(2 pi k n / N), 2k + 1 = -sin (float64 -> float32)."""
+    bins = n_fft // 2 + 1
+    k = np.arange(bins, dtype=np.float64)[None, :]
+    n = np.arange(n_fft, dtype=np.float64)[:, None]
+    ang = 2.0 * np.pi * ((k * n) % n_fft) / n_fft
+    m = np.zeros((n_fft, _ceil(2 * bins, 128)), np.float32)
+    m[:, 0: 2 * bins: 2] = np.cos(ang)
+    m[:, 1: 2 * bins: 2] = -np.sin(ang)
+    return m
+
+
+def _window(kind: str, win_length: int, n_fft: int) -> np.ndarray:
+    w = (torch.hann_window if kind == "hann" else torch.hamming_window)(win_length, periodic=True, dtype=torch.float64).numpy()
+    out = np.zeros(n_fft, np.float32)
+    left = (n_fft - win_length) // 2          # torch.stft centres a short window inside n_fft
+    out[left: left + win_length] = w
+    return out
+
+
+def _resample_table(orig: int, new: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> np.ndarray:
+    """[new][2 * width + orig] kernel of torchaudio.functional.resample (same formulas as conditioning.resample)."""
+    g = math.gcd(orig, new)
+    orig, new = orig // g, new // g
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = np.arange(-width, width + orig, dtype=np.float64)[None, :] / orig
+    t = np.arange(0, -new, -1, dtype=np.float64)[:, None] / new + idx
+    t = np.clip(t * base, -lowpass_filter_width, lowpass_filter_width)
+    window = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kern = np.where(t == 0, 1.0, np.sin(t) / np.where(t == 0, 1.0, t)) * window * (base / orig)
+    return kern.astype(np.float32)
+
+
+def pack_conditioning(xtts_sd) -> Dict[str, np.ndarray]:
+    """Once-per-speaker modules of xtts-v2.safetensors -> the "cond.*" tensors the HIP conditioning path reads: every linear
+    map as [K][N] (K padded to 16, N to 64 / 128 with zeros), BatchNorm folded to (scale, shift), the ResNet's 32-channel
+    stage padded to 64 channels, plus the fixed tables of the mel front-ends (windows, DFT matrices, mel filterbanks, the
+    22 050 -> 16 000 Hz resampling kernel)."""
+    from . import conditioning as Cn
+
+    def f(name):
+        return xtts_sd[name].detach().to(torch.float32).cpu().numpy()
+    d: Dict[str, np.ndarray] = {}
+    d["cond.mel_stats"] = f("mel_stats").reshape(80) if "mel_stats" in xtts_sd else np.ones(80, np.float32)
+    d["cond.win_gpt"] = _window("hann", 1024, 2048)
+    d["cond.win_spk"] = _window("hamming", 400, 512)
+    d["cond.dft_gpt"] = _dft_matrix(2048)
+    d["cond.dft_spk"] = _dft_matrix(512)
+    d["cond.fb_gpt"] = _pad2(Cn.mel_filterbank(1025, 0.0, 8000.0, 80, 22050, True).numpy(), _ceil(1025, 16), 128)
+    d["cond.fb_spk"] = _pad2(Cn.mel_filterbank(257, 0.0, 8000.0, 64, 16000, False).numpy(), _ceil(257, 16), 128)
+    d["cond.rs_22050_16000"] = _resample_table(22050, 16000)
+    # ConditioningEncoder
+    e = "conditioning_encoder."
+    d["cond.enc.init.w"] = np.ascontiguousarray(f(e + "init.weight")[:, :, 0].T)
+    d["cond.enc.init.b"] = f(e + "init.bias")
+    i = 0
+    while e + f"attn.{i}.norm.weight" in xtts_sd:
+        p, q = e + f"attn.{i}.", f"cond.enc.{i}."
+        d[q + "gn.w"], d[q + "gn.b"] = f(p + "norm.weight"), f(p + "norm.bias")
+        d[q + "qkv.w"] = np.ascontiguousarray(f(p + "qkv.weight")[:, :, 0].T)
+        d[q + "qkv.b"] = f(p + "qkv.bias")
+        d[q + "proj.w"] = np.ascontiguousarray(f(p + "proj_out.weight")[:, :, 0].T)
+        d[q + "proj.b"] = f(p + "proj_out.bias")
+        i += 1
+    # PerceiverResampler
+    e = "conditioning_perceiver."
+    d["cond.per.latents"] = f(e + "latents")
+    d["cond.per.norm.g"] = f(e + "norm.gamma")
+    i = 0
+    while e + f"layers.{i}.0.to_q.weight" in xtts_sd:
+        p, q = e + f"layers.{i}.", f"cond.per.{i}."
+        d[q + "q.w"] = np.ascontiguousarray(f(p + "0.to_q.weight").T)
+        d[q + "kv.w"] = np.ascontiguousarray(f(p + "0.to_kv.weight").T)
+        d[q + "out.w"] = np.ascontiguousarray(f(p + "0.to_out.weight").T)
+        w1, w2 = f(p + "1.0.weight"), f(p + "1.2.weight")           # [2*inner][1024], [1024][inner]
+        inner = w2.shape[1]
+        d[q + "ff1.w"] = _pad2(w1.T, 1024, _ceil(2 * inner, 128))
+        d[q + "ff1.b"] = _pad1(f(p + "1.0.bias"), _ceil(2 * inner, 128))
+        d[q + "ff2.w"] = _pad2(w2.T, _ceil(inner, 16), 1024)
+        d[q + "ff2.b"] = f(p + "1.2.bias")
+        i += 1
+    # ResNet-SE speaker encoder (NHWC, im2col row = (ky, kx, cin))
+    s, o = "hifigan_decoder.speaker_encoder.", "cond.spk."
+
+    def conv3(name, cin_pad, cout_pad):
+        w = f(name)                                  # [Cout][Cin][3][3]
+        co, ci = w.shape[:2]
+        m = np.zeros((9, cin_pad, cout_pad), np.float32)
+        m[:, :ci, :co] = w.transpose(2, 3, 1, 0).reshape(9, ci, co)
+        return _pad2(m.reshape(9 * cin_pad, cout_pad), _ceil(9 * cin_pad, 16), cout_pad)
+
+    def bn(prefix, out_prefix, cpad):
+        sc = f(prefix + "weight") / np.sqrt(f(prefix + "running_var") + 1e-5)
+        d[out_prefix + "scale"] = _pad1(sc, cpad)
+        d[out_prefix + "shift"] = _pad1(f(prefix + "bias") - f(prefix + "running_mean") * sc, cpad)
+    d[o + "conv1.w"] = conv3(s + "conv1.weight", 1, 64)
+    d[o + "conv1.b"] = _pad1(f(s + "conv1.bias"), 64)
+    bn(s + "bn1.", o + "bn1.", 64)
+    cin = 64
+    for li, (planes, blocks) in enumerate(zip((32, 64, 128, 256), (3, 4, 6, 3)), start=1):
+        cp = max(planes, 64)
+        for bi in range(blocks):
+            p, q = s + f"layer{li}.{bi}.", o + f"layer{li}.{bi}."
+            d[q + "conv1.w"] = conv3(p + "conv1.weight", cin, cp)
+            bn(p + "bn1.", q + "bn1.", cp)
+            d[q + "conv2.w"] = conv3(p + "conv2.weight", cp, cp)
+            bn(p + "bn2.", q + "bn2.", cp)
+            w1, w2 = f(p + "se.fc.0.weight"), f(p + "se.fc.2.weight")    # [Cr][C], [C][Cr]
+            d[q + "se1.w"] = _pad2(w1, w1.shape[0], cp)
+            d[q + "se1.b"] = f(p + "se.fc.0.bias")
+            d[q + "se2.w"] = _pad2(w2, cp, w2.shape[1])
+            d[q + "se2.b"] = _pad1(f(p + "se.fc.2.bias"), cp)
+            if p + "downsample.0.weight" in xtts_sd:
+                wd = f(p + "downsample.0.weight")[:, :, 0, 0]            # [Cout][Cin]
+                d[q + "down.w"] = _pad2(wd.T, cin, cp)
+                bn(p + "downsample.1.", q + "down.", cp)
+            cin = cp
+    d[o + "att0.w"] = np.ascontiguousarray(f(s + "attention.0.weight")[:, :, 0].T)     # [2048][128]
+    d[o + "att0.b"] = f(s + "attention.0.bias")
+    bn(s + "attention.2.", o + "att2.", 128)
+    d[o + "att3.w"] = np.ascontiguousarray(f(s + "attention.3.weight")[:, :, 0].T)     # [128][2048]
+    d[o + "att3.b"] = f(s + "attention.3.bias")
+    d[o + "fc.w"] = np.ascontiguousarray(f(s + "fc.weight").T)                         # [4096][512]
+    d[o + "fc.b"] = f(s + "fc.bias")
+    return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in d.items()}
 
 
 # ---- CPU emulation of what conv1d_mfma_kernel computes from packed weights (host-logic tests only) -------

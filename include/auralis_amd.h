@@ -154,6 +154,21 @@ int aur_set_conditioning_device(aur_engine* e, uint64_t speaker_key, const float
  * re-register an evicted voice). */
 int aur_has_conditioning(aur_engine* e, uint64_t speaker_key, int32_t* out);
 
+/* Speaker conditioning from reference audio on the GPU (replaces XTTSv2Engine.get_conditioning_latents,
+ * models/xttsv2/XTTSv2.py:409-468, with get_speaker_embedding :312-328 and get_gpt_cond_latents :349-407 underneath:
+ * ResNet-SE speaker encoder, ConditioningEncoder, PerceiverResampler and their mel front-ends).
+ * pcm[r]: n_samples[r] mono float32 samples of reference r at 22 050 Hz in HOST memory (decoding / resampling of the files is
+ * the loader's job, as in the reference's load_audio).  Outputs (host): gpt_cond_latent [32][1024], speaker embedding [512],
+ * ready for aur_set_conditioning.  Needs the "cond.*" tensors (auralis_amd/weights.py: pack_conditioning). */
+typedef struct aur_cond_params {
+    int32_t max_ref_length;      /* seconds of each reference that are used (reference default 30) */
+    int32_t gpt_cond_len;        /* seconds of the concatenated references that feed the latents (default 6) */
+    int32_t gpt_cond_chunk_len;  /* seconds per chunk (default 6) */
+    int32_t sound_norm_refs;     /* 1: each reference scaled to 0.75 of its peak */
+} aur_cond_params;
+int aur_compute_conditioning(aur_engine* e, const float* const* pcm, const int32_t* n_samples, int32_t n_refs,
+                             const aur_cond_params* params, float* out_gpt_cond, float* out_spk_emb);
+
 /* Queue a sequence (replaces llm_engine.generate, XTTSv2.py:752). */
 int aur_submit(aur_engine* e, const aur_seq_desc* seq, uint64_t* seq_id);
 

@@ -121,6 +121,15 @@ def _wav_bytes(pcm16: np.ndarray, sr: int = 22050) -> bytes:
     return b.getvalue()
 
 
+def _wav_bytes_f32(x: np.ndarray, sr: int = 22050) -> bytes:
+    """IEEE-float WAV: the decoder hands back exactly these float32 samples."""
+    import struct
+    data = np.asarray(x, dtype="<f4").tobytes()
+    fmt = struct.pack("<HHIIHH", 3, 1, sr, sr * 4, 4, 32)
+    return b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + len(data)) + b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + \
+        b"data" + struct.pack("<I", len(data)) + data
+
+
 def _golden_sd(dims):
     sd = make_synthetic_conditioning_weights(dims, seed=99)
     sd["mel_stats"] = torch.ones(80)
@@ -207,3 +216,66 @@ def test_resampler_against_scipy_polyphase():
     assert abs(len(ours) - len(ref)) <= 1
     err = ours[200:n - 200] - ref[200:n - 200]
     assert np.sqrt(np.mean(err ** 2)) < 0.05 * np.sqrt(np.mean(ref[200:n - 200] ** 2))
+
+
+# ------------------------------------------------------------------------------------------------ HIP path (aur_compute_conditioning)
+def _hip_engine(dims, sd):
+    from auralis_amd._lib import NativeEngine
+    from auralis_amd.weights import pack_conditioning
+    eng = NativeEngine(n_layer=1, max_seqs=1)
+    eng.load_weights(pack_conditioning(sd))
+    return eng
+
+
+@pytest.mark.gpu
+def test_hip_conditioning_matches_reference_classes_on_real_speech(dims):
+    """aur_compute_conditioning (hand-written HIP: DFT-as-GEMM mel front-ends, ConditioningEncoder, PerceiverResampler,
+    ResNet-SE speaker encoder on exact-f32 MFMA GEMMs) on the golden clip, against the outputs of the reference's own module
+    classes (tests/golden/cond_female_6s.npz, oracle/make_golden_cond.py)."""
+    g = _golden()
+    eng = _hip_engine(dims, _golden_sd(dims))
+    try:
+        pcm = g["pcm16"].astype(np.float32) / 32767.0
+        cond, spk = eng.compute_conditioning([pcm], max_ref_length=30, gpt_cond_len=6, gpt_cond_chunk_len=6)
+        assert cond.shape == (1, 32, 1024) and spk.shape == (1, 512, 1)
+        e_c = float(np.abs(cond - g["gpt_cond_latent"]).max())
+        e_s = float(np.abs(spk - g["speaker_embedding"]).max())
+        print(f"HIP conditioning vs reference classes: latent max |err| {e_c:.3e} (rows are O(1)), embedding {e_s:.3e} (unit norm)")
+        assert e_c < 2e-4 and e_s < 1e-5
+        again = eng.compute_conditioning([pcm], max_ref_length=30, gpt_cond_len=6, gpt_cond_chunk_len=6)
+        assert np.array_equal(again[0], cond) and np.array_equal(again[1], spk)          # deterministic, workspaces reused
+        import time
+        t0 = time.perf_counter()
+        for _ in range(5):
+            eng.compute_conditioning([pcm], max_ref_length=30, gpt_cond_len=6, gpt_cond_chunk_len=6)
+        t_hip = (time.perf_counter() - t0) / 5
+        t0 = time.perf_counter()
+        Cn.get_conditioning_latents(_golden_sd(dims), [_wav_bytes(g["pcm16"])], max_ref_length=30, gpt_cond_len=6, gpt_cond_chunk_len=6)
+        t_cpu = time.perf_counter() - t0
+        print(f"6 s reference clip: HIP path {1e3 * t_hip:.1f} ms per call (host copies included), PyTorch CPU fp32 {1e3 * t_cpu:.0f} ms")
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_hip_conditioning_chunks_references_and_normalisation_equal_the_torch_path(dims):
+    """Several references, several chunks (the last one shorter), clipping and sound_norm_refs: HIP path vs conditioning.py
+    (PyTorch, CPU fp32) on the same inputs (XTTSv2.py:409-468 semantics: embeddings averaged over references, latents over
+    the chunks of the concatenated audio)."""
+    g = _golden()
+    sd = _golden_sd(dims)
+    eng = _hip_engine(dims, sd)
+    try:
+        x = g["pcm16"].astype(np.float32) / 32767.0
+        refs = [x[: 22050 * 4 + 1234], 0.5 * x[22050 * 2:]]
+        for kw in (dict(max_ref_length=3, gpt_cond_len=5, gpt_cond_chunk_len=2, sound_norm_refs=False),
+                   dict(max_ref_length=30, gpt_cond_len=30, gpt_cond_chunk_len=3, sound_norm_refs=True)):
+            cond, spk = eng.compute_conditioning(refs, **kw)
+            rc, rs = Cn.get_conditioning_latents(sd, [_wav_bytes_f32(r) for r in refs], device="cpu", **kw)
+            e_c, e_s = float(np.abs(cond - rc.numpy()).max()), float(np.abs(spk - rs.numpy()).max())
+            print(kw, f"latent {e_c:.3e} embedding {e_s:.3e}")
+            assert e_c < 2e-4 and e_s < 1e-5
+        with pytest.raises(Exception, match="0.33"):
+            eng.compute_conditioning([x[:5000]], max_ref_length=30, gpt_cond_len=6, gpt_cond_chunk_len=6)
+    finally:
+        eng.close()
