@@ -963,29 +963,25 @@ void launch_paged_attention(const float* qbuf, const void* kv_layer, const int* 
         const char* e = getenv("AUR_ATTN_UN");
         return e ? atoi(e) : 4;
     }();
-    if (un == 8 && !prefetch) {
-        if (kv_half)
-            hipLaunchKernelGGL((paged_attention_kernel<false, true, false, 8>), dim3(M, kHeads), dim3(256), 0, st, qbuf,
-                               const_cast<void*>(kv_layer), row_slot, row_pos, slot_kvpos, block_tables, max_blocks, out,
-                               (const float*)nullptr, 0, (const float*)nullptr, M, out_mtt, row_meta);
-        else
-            hipLaunchKernelGGL((paged_attention_kernel<false, false, false, 8>), dim3(M, kHeads), dim3(256), 0, st, qbuf,
-                               const_cast<void*>(kv_layer), row_slot, row_pos, slot_kvpos, block_tables, max_blocks, out,
-                               (const float*)nullptr, 0, (const float*)nullptr, M, out_mtt, row_meta);
-        HIP_CHECK(hipGetLastError());
-        return;
-    }
-#define AUR_ATT(KVH_, PF_)                                                                                                      \
-    hipLaunchKernelGGL((paged_attention_kernel<false, KVH_, PF_>), dim3(M, kHeads), dim3(256), 0, st, qbuf,                     \
+    // every (UN, PF) variant visits the tokens of a (wave, lane group) partial in ascending order, so they are bitwise equal
+#define AUR_ATT(KVH_, PF_, UN_)                                                                                                 \
+    hipLaunchKernelGGL((paged_attention_kernel<false, KVH_, PF_, UN_>), dim3(M, kHeads), dim3(256), 0, st, qbuf,                \
                        const_cast<void*>(kv_layer), row_slot, row_pos, slot_kvpos, block_tables, max_blocks, out,               \
                        (const float*)nullptr, 0, (const float*)nullptr, M, out_mtt, row_meta)
+#define AUR_ATT_UN(KVH_, PF_)              \
+    do {                                   \
+        if (un == 2) AUR_ATT(KVH_, PF_, 2); \
+        else if (un == 8) AUR_ATT(KVH_, PF_, 8); \
+        else AUR_ATT(KVH_, PF_, 4);        \
+    } while (0)
     if (kv_half) {
-        if (prefetch) AUR_ATT(true, true);
-        else AUR_ATT(true, false);
+        if (prefetch) AUR_ATT_UN(true, true);
+        else AUR_ATT_UN(true, false);
     } else {
-        if (prefetch) AUR_ATT(false, true);
-        else AUR_ATT(false, false);
+        if (prefetch) AUR_ATT_UN(false, true);
+        else AUR_ATT_UN(false, false);
     }
+#undef AUR_ATT_UN
 #undef AUR_ATT
     HIP_CHECK(hipGetLastError());
 }

@@ -221,6 +221,14 @@ def build_report(args, st, dims, world, samples, dt, audio_s):
     }
 
 
+def _f32_wav(x, sr: int = 22050) -> bytes:
+    import struct
+    data = np.asarray(x, dtype="<f4").tobytes()
+    fmt = struct.pack("<HHIIHH", 3, 1, sr, sr * 4, 4, 32)
+    return (b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + len(data)) + b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt +
+            b"data" + struct.pack("<I", len(data)) + data)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -332,6 +340,29 @@ def main():
             line["cpu_baseline"] = cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, args.cpu_tokens)
         else:
             line["cpu_baseline"] = None
+    # Once-per-speaker path, outside the timed region: reference audio -> conditioning on the HIP kernels
+    if rank == 0 and world == 1:
+        try:
+            from auralis_amd.weights import pack_conditioning
+            eng.load_weights(pack_conditioning(xtts_sd))
+            rng = np.random.default_rng(5)
+            tt = np.arange(22050 * 6) / 22050.0
+            clip = (0.3 * np.sin(2 * np.pi * 150 * tt) * (1 + 0.5 * np.sin(2 * np.pi * 3 * tt)) + 0.02 * rng.standard_normal(tt.size)).astype(np.float32)
+            eng.compute_conditioning([clip])
+            t0 = time.perf_counter()
+            for _ in range(5):
+                eng.compute_conditioning([clip])
+            sc = {"ms_per_6s_reference": (time.perf_counter() - t0) / 5 * 1e3, "what": "aur_compute_conditioning: mel front-ends, "
+                  "ConditioningEncoder, PerceiverResampler, ResNet-SE speaker encoder (fp32, host copies included)"}
+            if not args.no_cpu_baseline:
+                from auralis_amd import conditioning as Cn
+                sd_c = {k: v for k, v in xtts_sd.items() if k.startswith(("conditioning_", "hifigan_decoder.speaker_encoder.", "mel_stats"))}
+                t0 = time.perf_counter()
+                Cn.get_conditioning_latents(sd_c, [_f32_wav(clip)], max_ref_length=30, gpt_cond_len=6, gpt_cond_chunk_len=6)
+                sc["cpu_ms"] = (time.perf_counter() - t0) * 1e3
+            line["speaker_conditioning"] = sc
+        except Exception as e:   # never lose the headline line over the side measurement
+            line["speaker_conditioning"] = {"error": str(e)[:200]}
     # Not the reported metric: the same workload once more with the opt-in fp16 K/V pool (aur_config.kv_fp16; fp32 arithmetic,
     # 0 id mismatches on the C2 / C3 goldens, tests/test_gpu_baseline_size.py), so that both numbers come from one driver run.
     if world == 1 and args.kv == "fp32" and not args.no_throughput_mode:
