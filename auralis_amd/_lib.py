@@ -73,7 +73,8 @@ class aur_stats(C.Structure):
 # every symbol include/auralis_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "aur_last_error", "aur_version", "aur_engine_create", "aur_engine_destroy", "aur_load_weights",
-    "aur_set_conditioning", "aur_set_conditioning_device", "aur_has_conditioning", "aur_compute_conditioning", "aur_submit", "aur_step", "aur_poll_finished",
+    "aur_set_conditioning", "aur_set_conditioning_device", "aur_has_conditioning", "aur_compute_conditioning", "aur_comm_unique_id", "aur_comm_init", "aur_broadcast_conditioning",
+    "aur_submit", "aur_step", "aur_poll_finished",
     "aur_release", "aur_vocode", "aur_sync", "aur_get_stats", "aur_reset_stats", "aur_dbg_gemm", "aur_dbg_gemm_rows",
     "aur_dbg_gemm_tile_map", "aur_dbg_layernorm", "aur_dbg_conv1d", "aur_dbg_conv1d_f16", "aur_dbg_prefill", "aur_dbg_sample",
 ]
@@ -107,6 +108,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "aur_set_conditioning": [eng, C.c_uint64, fp, fp],
         "aur_set_conditioning_device": [eng, C.c_uint64, C.c_void_p, C.c_void_p],
         "aur_has_conditioning": [eng, C.c_uint64, ip],
+        "aur_comm_unique_id": [C.POINTER(C.c_uint8)],
+        "aur_comm_init": [eng, C.POINTER(C.c_uint8), C.c_int32, C.c_int32],
+        "aur_broadcast_conditioning": [eng, C.c_uint64, C.c_int32],
         "aur_compute_conditioning": [eng, C.POINTER(fp), ip, C.c_int32, C.POINTER(aur_cond_params), fp, fp],
         "aur_submit": [eng, C.POINTER(aur_seq_desc), C.POINTER(C.c_uint64)],
         "aur_step": [eng, ip, ip],
@@ -219,6 +223,23 @@ class NativeEngine:
         s = np.empty((1, 512, 1), np.float32)
         self._check(self.lib.aur_compute_conditioning(self.h, ptrs, _ip(ns), len(arrs), C.byref(p), _fp(g), _fp(s)))
         return g, s
+
+    # -- RCCL inside the library (one engine per GPU per process) -------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        rc = load_library().aur_comm_unique_id(buf)
+        if rc != 0:
+            raise AurError(rc, load_library().aur_last_error().decode("utf-8", "replace"))
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self.lib.aur_comm_init(self.h, buf, rank, world))
+
+    def broadcast_conditioning(self, key: int, root: int = 0):
+        """Collective over the engine's communicator: the voice `key` registered on `root` arrives on every other rank."""
+        self._check(self.lib.aur_broadcast_conditioning(self.h, key, root))
 
     def set_conditioning_device(self, key: int, d_gpt_cond_ptr: int, d_spk_ptr: int):
         self._check(self.lib.aur_set_conditioning_device(self.h, key, C.c_void_p(d_gpt_cond_ptr), C.c_void_p(d_spk_ptr)))

@@ -6,6 +6,8 @@
 // workspace.  The reference's counterparts are vLLM's AsyncLLMEngine/scheduler/block manager (un-vendored,
 // XTTSv2.py:198-232), HiddenStatesCollector (components/vllm/hidden_state_collector.py) and the
 // asyncio.to_thread HiFi-GAN call (XTTSv2.py:804).
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -247,6 +249,7 @@ public:
             (void)hipEventDestroy(ev_de_[i]);
         }
         if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+        if (comm_) (void)Rccl::get().CommDestroy(comm_);
         (void)hipEventDestroy(ev_fork_);
         (void)hipEventDestroy(ev_ws1_);
         (void)hipEventDestroy(ev_lat_);
@@ -317,6 +320,80 @@ public:
         spk_info_[row].last_use = ++spk_clock_;
         return row;
     }
+    // ------------------------------------------------------------------ RCCL inside the boundary
+    // The only exchange of the multi-GPU path is the speaker conditioning (133 120 B per voice).  RCCL is resolved at run time
+    // (the copy PyTorch already loaded when there is one), so a single-GPU process never needs it.
+    struct Rccl {
+        typedef struct { char internal[128]; } UniqueId;
+        int (*GetUniqueId)(UniqueId*) = nullptr;
+        int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+        int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+        int (*CommDestroy)(void*) = nullptr;
+        const char* (*GetErrorString)(int) = nullptr;
+        static Rccl& get() {
+            static Rccl r = [] {
+                Rccl x;
+                void* h = nullptr;
+                for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"})
+                    if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+                if (!h) throw StateError("RCCL (librccl.so) not found: multi-GPU conditioning broadcast unavailable");
+                x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+                x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+                x.Broadcast = reinterpret_cast<decltype(x.Broadcast)>(dlsym(h, "ncclBroadcast"));
+                x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+                x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+                if (!x.GetUniqueId || !x.CommInitRank || !x.Broadcast || !x.CommDestroy) throw StateError("RCCL symbols missing");
+                return x;
+            }();
+            return r;
+        }
+        void check(int rc, const char* what) const {
+            if (rc != 0) throw StateError(std::string("RCCL ") + what + " failed: " + (GetErrorString ? GetErrorString(rc) : "?"));
+        }
+    };
+    static void comm_unique_id(uint8_t* out) {
+        Rccl::UniqueId id;
+        Rccl::get().check(Rccl::get().GetUniqueId(&id), "ncclGetUniqueId");
+        memcpy(out, id.internal, 128);
+    }
+    void comm_init(const uint8_t* id_bytes, int rank, int world) {
+        std::lock_guard<std::mutex> gl(gpu_mu_);
+        use();
+        AUR_REQUIRE(world >= 1 && rank >= 0 && rank < world, "comm_init: rank / world");
+        if (comm_) throw StateError("communicator already initialised");
+        Rccl::UniqueId id;
+        memcpy(id.internal, id_bytes, 128);
+        Rccl::get().check(Rccl::get().CommInitRank(&comm_, world, id, rank), "ncclCommInitRank");
+        comm_rank_ = rank;
+        comm_world_ = world;
+    }
+    // collective: every rank of the communicator calls it; `root` must have the voice registered, the others receive it over
+    // xGMI into a device buffer and register it from there (no host bounce)
+    void broadcast_conditioning(uint64_t key, int root) {
+        constexpr int kCond = 32 * kHidden, kTot = kCond + 512;
+        {
+            std::lock_guard<std::mutex> gl(gpu_mu_);
+            use();
+            if (!comm_) throw StateError("aur_comm_init has not been called");
+            AUR_REQUIRE(root >= 0 && root < comm_world_, "broadcast_conditioning: root");
+            bcast_buf_.ensure((size_t)kTot * sizeof(float));
+            float* buf = bcast_buf_.as<float>();
+            if (comm_rank_ == root) {
+                int row;
+                {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    row = speaker_row(key, false);
+                }
+                if (row < 0) throw StateError("broadcast_conditioning: the root has no such speaker_key");
+                HIP_CHECK(hipMemcpyAsync(buf, spk_table_.as<float>() + (long)row * kCond, (size_t)kCond * sizeof(float), hipMemcpyDeviceToDevice, st_));
+                HIP_CHECK(hipMemcpyAsync(buf + kCond, spk_emb_.as<float>() + (long)row * 512, 512 * sizeof(float), hipMemcpyDeviceToDevice, st_));
+            }
+            Rccl::get().check(Rccl::get().Broadcast(buf, buf, (size_t)kTot, /*ncclFloat32*/ 7, root, comm_, st_), "ncclBroadcast");
+            HIP_CHECK(hipStreamSynchronize(st_));
+        }
+        if (comm_rank_ != root) set_conditioning(key, bcast_buf_.as<float>(), bcast_buf_.as<float>() + kCond, true);
+    }
+
     bool has_conditioning(uint64_t key) {
         std::lock_guard<std::mutex> lk(mu_);
         return speaker_row(key, false) >= 0;
@@ -1863,6 +1940,9 @@ private:
     bool share_prefix_now_ = true;    // dbg_prefill turns it off to return every prompt row
     std::mutex gpu_mu_;
     std::unique_ptr<CondNet> cond_net_;
+    void* comm_ = nullptr;   // ncclComm_t
+    int comm_rank_ = 0, comm_world_ = 1;
+    DevBuf bcast_buf_;
     // row workspace
     RowWs ws_[2];
     // vocoder stage
@@ -2002,6 +2082,19 @@ int aur_has_conditioning(aur_engine* e, uint64_t key, int32_t* out) {
     CHECK_PTR(e);
     CHECK_PTR(out);
     return guarded([&] { *out = e->impl.has_conditioning(key) ? 1 : 0; });
+}
+int aur_comm_unique_id(uint8_t* out128) {
+    CHECK_PTR(out128);
+    return guarded([&] { aur::Engine::comm_unique_id(out128); });
+}
+int aur_comm_init(aur_engine* e, const uint8_t* id128, int32_t rank, int32_t world) {
+    CHECK_PTR(e);
+    CHECK_PTR(id128);
+    return guarded([&] { e->impl.comm_init(id128, rank, world); });
+}
+int aur_broadcast_conditioning(aur_engine* e, uint64_t key, int32_t root) {
+    CHECK_PTR(e);
+    return guarded([&] { e->impl.broadcast_conditioning(key, root); });
 }
 int aur_compute_conditioning(aur_engine* e, const float* const* pcm, const int32_t* n_samples, int32_t n_refs, const aur_cond_params* p,
                              float* out_gpt_cond, float* out_spk_emb) {

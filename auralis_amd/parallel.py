@@ -44,6 +44,23 @@ def broadcast_conditioning(engine, speaker_key: int, gpt_cond_latent: Optional[t
     return buf
 
 
+def broadcast_conditioning_native(engine, speaker_key: int, gpt_cond_latent: Optional[torch.Tensor],
+                                  speaker_embedding: Optional[torch.Tensor], src: int = 0) -> None:
+    """The same exchange with the collective INSIDE the library (aur_comm_init / aur_broadcast_conditioning: one ncclBroadcast on
+    the engine's own RCCL communicator).  torch.distributed is used once, to hand the 128-byte communicator id to every rank."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if not getattr(engine, "_comm_ready", False):
+        ids = [type(engine).comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        engine.comm_init(ids[0], rank, world)
+        engine._comm_ready = True
+    if rank == src:
+        engine.set_conditioning(speaker_key, gpt_cond_latent.reshape(32, 1024).float().cpu().numpy(),
+                                speaker_embedding.reshape(512).float().cpu().numpy())
+    engine.broadcast_conditioning(speaker_key, src)
+
+
 def shard_units(n_units: int, world: int, rank: int, per_gpu_batch: int = 64) -> List[int]:
     """Indices of the units (utterance chunks) owned by `rank`: blocks of `per_gpu_batch` dealt round-robin,
     so that C4 (512 utterances, 64/GPU x 8) gives every GPU one full batch and long-form streams stay ordered

@@ -284,7 +284,12 @@ def main():
     # speaker conditioning: computed on rank 0, RCCL-broadcast over xGMI, registered from the device buffer
     cond, spk = make_synthetic_conditioning(dims)
     SPK = 1
-    if use_dist:
+    if use_dist and os.environ.get("AUR_NATIVE_BCAST", "0") == "1":
+        # the collective inside the library (aur_comm_init / aur_broadcast_conditioning); opt-in: it could only be exercised
+        # with world_size 1 in the build environment, the default below has run under torchrun
+        from auralis_amd.parallel import broadcast_conditioning_native
+        broadcast_conditioning_native(eng, SPK, cond if rank == 0 else None, spk if rank == 0 else None, src=0)
+    elif use_dist:
         broadcast_conditioning(eng, SPK, cond if rank == 0 else None, spk if rank == 0 else None, src=0,
                                device=torch.device("cuda", local_rank))
     else:

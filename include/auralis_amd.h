@@ -148,6 +148,16 @@ int aur_set_conditioning(aur_engine* e, uint64_t speaker_key, const float* gpt_c
 int aur_set_conditioning_device(aur_engine* e, uint64_t speaker_key, const float* d_gpt_cond,
                                 const float* d_spk_emb);
 
+/* RCCL inside the boundary (the reference has no counterpart: it forwards tensor_parallel_size to vLLM,
+ * XTTSv2.py:214-215).  One engine per GPU per process; the only exchange of the utterance-sharded path is the speaker
+ * conditioning.  aur_comm_unique_id: rank 0 creates the 128-byte id and the launcher hands it to every rank (any channel);
+ * aur_comm_init: collective, builds the communicator of this engine; aur_broadcast_conditioning: collective, the voice
+ * registered on `root` is sent with ONE ncclBroadcast of 133 120 bytes over xGMI and registered on the other ranks from the
+ * device receive buffer (same effect as aur_set_conditioning_device there).  RCCL is loaded at run time (dlopen). */
+int aur_comm_unique_id(uint8_t* out128);
+int aur_comm_init(aur_engine* e, const uint8_t* id128, int32_t rank, int32_t world_size);
+int aur_broadcast_conditioning(aur_engine* e, uint64_t speaker_key, int32_t root);
+
 /* *out = 1 if speaker_key is registered (and marks it most recently used), else 0.  The table holds
  * aur_config.max_speakers voices; when it is full, registering a new key evicts the least recently used voice that has
  * no undelivered sequences (replaces the reference's unbounded per-request conditioning, XTTSv2.py:409-468: callers

@@ -237,3 +237,34 @@ def test_rccl_world1_broadcast_and_device_pointer_registration_equal_host_path(d
         if dist.is_initialized():
             dist.destroy_process_group()
         e.close()
+
+
+def test_in_library_rccl_communicator_and_broadcast_world1(dims):
+    """aur_comm_unique_id / aur_comm_init / aur_broadcast_conditioning: the RCCL communicator lives inside the library (loaded
+    with dlopen).  World size 1 is what one GPU can exercise: id creation, ncclCommInitRank, the ncclBroadcast on the engine's
+    stream and the error paths; the non-root registration path is the aur_set_conditioning_device code the test above covers."""
+    from auralis_amd._lib import AurError, NativeEngine
+    e, _, _, cond, spk = make_engine(2, max_seqs=2)
+    try:
+        with pytest.raises(AurError, match="aur_comm_init"):
+            e.broadcast_conditioning(SPK_KEY, 0)
+        uid = NativeEngine.comm_unique_id()
+        assert isinstance(uid, bytes) and len(uid) == 128 and any(uid)
+        with pytest.raises(AurError):
+            e.comm_init(uid, 1, 1)                       # rank out of range
+        e.comm_init(uid, 0, 1)
+        with pytest.raises(AurError, match="already"):
+            e.comm_init(uid, 0, 1)
+        ids = make_synthetic_text_ids(dims, n_text=15, seed=8)
+        e.submit(ids, SPK_KEY, temperature=0.0, max_tokens=10, ignore_stop=True)
+        before = e.run_until_done()[0]
+        e.broadcast_conditioning(SPK_KEY, 0)             # root == self: the payload goes through ncclBroadcast and back
+        with pytest.raises(AurError, match="no such speaker"):
+            e.broadcast_conditioning(424242, 0)
+        with pytest.raises(AurError, match="root"):
+            e.broadcast_conditioning(SPK_KEY, 3)
+        e.submit(ids, SPK_KEY, temperature=0.0, max_tokens=10, ignore_stop=True)
+        after = e.run_until_done()[0]
+        assert after["tokens"].tolist() == before["tokens"].tolist() and np.array_equal(after["wav"], before["wav"])
+    finally:
+        e.close()
