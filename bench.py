@@ -250,6 +250,12 @@ def main():
     ap.add_argument("--cpu-tokens", type=int, default=280, help="mel tokens of the CPU-baseline utterance (280 = C2 in full)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON record: everything native libraries print to file descriptor 1 (RCCL's version
+    # banner at communicator creation, for one) is sent to stderr instead, and the record goes to the saved descriptor
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -387,7 +393,7 @@ def main():
             "note": "opt-in mode, NOT the headline configuration: paged K/V stored in fp16 (the reference GPU path's KV dtype), "
                     "everything else as above; greedy and sampled ids equal the fp32 CPU oracle on all committed goldens"}
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
     eng.close()
     if use_dist:
         torch.distributed.destroy_process_group()
