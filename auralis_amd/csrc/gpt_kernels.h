@@ -123,7 +123,7 @@ struct GemmRowsArgs {
     float2* stats_out;        // kEpiResidual (N == 1024): [rows][64], may be nullptr
     int nt_w;            // 1: non-temporal loads on the weight stream (read once per step by exactly one CU when there is a
                          // single row group); launch_gemm_rows sets it from AUR_GEMM_NT
-    long long* prof;     // optional (tools/gemm_bench): 8 s_memtime stamps per workgroup, written by wave 0
+    long long* prof;     // optional (tools/gemm_bench): 8 wall_clock64 stamps (100 MHz, device-wide) per workgroup, written by wave 0
 };
 void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream_t st);
 // Wt = pack_wt16(W), W row-major [K][ldw], N % 16 == 0, K % 16 == 0

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) af[buf][mt][b] = xp[((long)(kb0 + b) * a.xmt + mt) * 64];
     };
-    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 0] = (long long)__builtin_amdgcn_s_memtime();
+    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 0] = (long long)wall_clock64();
     f32x4 acc[MT][NTL];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
         }
     }
     load_chunk(0, 0);
-    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 1] = (long long)__builtin_amdgcn_s_memtime();
+    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 1] = (long long)wall_clock64();
     float mean[MT], rstd[MT];
     if (LN) {
         __builtin_amdgcn_sched_barrier(0);   // everything above is in flight before the first wait
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
             rstd[mt] = rs[16 * mt + j][1];
         }
     }
-    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 2] = (long long)__builtin_amdgcn_s_memtime();
+    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 2] = (long long)wall_clock64();
     if (NBUF == 3) load_chunk(1, 1);
 #pragma unroll
     for (int c = 0; c < KCH; ++c) {
@@ -495,9 +495,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[w][(t * MT + mt) * 256 + r * 64 + lane] = acc[mt][t][r];
-    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 3] = (long long)__builtin_amdgcn_s_memtime();
+    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 3] = (long long)wall_clock64();
     __syncthreads();
-    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 4] = (long long)__builtin_amdgcn_s_memtime();
+    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 4] = (long long)wall_clock64();
     for (int e = tid; e < MT * NTL * 256; e += 64 * NW) {
         float t = red[0][e];
 #pragma unroll
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
             }
         }
     }
-    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 5] = (long long)__builtin_amdgcn_s_memtime();
+    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 5] = (long long)wall_clock64();
 }
 
 // Workgroup shapes in use.  16 waves (K-slice 64 per wave, <= 128 VGPRs per lane) everywhere except the 64-row tiles with

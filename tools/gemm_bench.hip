@@ -165,15 +165,29 @@ int main(int argc, char** argv) {
                 HIP_CHECK(hipStreamSynchronize(st));
                 std::vector<long long> hp((size_t)nwg * 8);
                 HIP_CHECK(hipMemcpy(hp.data(), dprof, hp.size() * 8, hipMemcpyDeviceToHost));
-                long long t_min = hp[0], t_max = hp[5];
+                long long t_min = -1, t_max = 0;
                 double ph[5] = {0, 0, 0, 0, 0};
+                int live = 0;
+                std::vector<double> st_us, en_us;
                 for (int g = 0; g < nwg; ++g) {
-                    t_min = std::min(t_min, hp[g * 8]);
+                    if (hp[g * 8] == 0) continue;   // surplus workgroups of a padded grid exit before the first stamp
+                    ++live;
+                    t_min = t_min < 0 ? hp[g * 8] : std::min(t_min, hp[g * 8]);
                     t_max = std::max(t_max, hp[g * 8 + 5]);
-                    for (int k = 0; k < 5; ++k) ph[k] += (double)(hp[g * 8 + k + 1] - hp[g * 8 + k]) / nwg;
                 }
+                for (int g = 0; g < nwg; ++g) {
+                    if (hp[g * 8] == 0) continue;
+                    for (int k = 0; k < 5; ++k) ph[k] += (double)(hp[g * 8 + k + 1] - hp[g * 8 + k]) / live;
+                    st_us.push_back((double)(hp[g * 8] - t_min) / 100.0);
+                    en_us.push_back((double)(hp[g * 8 + 5] - t_min) / 100.0);
+                }
+                std::sort(st_us.begin(), st_us.end());
+                std::sort(en_us.begin(), en_us.end());
+                printf("    workgroup starts (us after the first): p50 %.2f p90 %.2f max %.2f | ends: p10 %.2f p50 %.2f p90 %.2f max %.2f\n",
+                       st_us[st_us.size() / 2], st_us[st_us.size() * 9 / 10], st_us.back(), en_us[en_us.size() / 10], en_us[en_us.size() / 2],
+                       en_us[en_us.size() * 9 / 10], en_us.back());
                 const double mb = 4.0 * ((double)s.K * s.N + (double)M * s.K + (double)M * s.N) / 1e6;
-                printf("%s M=%d cols/wg=%d rows/wg=%2d waves=%2d wgs=%4d : %6.2f us/launch  %5.2f TB/s | cycles: span %6lld issue %5.0f ln+wait %6.0f mfma %6.0f bar %5.0f epi %5.0f\n",
+                printf("%s M=%d cols/wg=%d rows/wg=%2d waves=%2d wgs=%4d : %6.2f us/launch  %5.2f TB/s | 10-ns ticks: span %6lld issue %5.0f ln+wait %6.0f mfma %6.0f bar %5.0f epi %5.0f\n",
                        s.name, M, 16 * ntl, 16 * mt, nw, nwg, us, mb / us, t_max - t_min, ph[0], ph[1], ph[2], ph[3], ph[4]);
             }
         // reference: the round-1 split-K kernel on the same shape (slab sums not included)
