@@ -625,10 +625,19 @@ void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream
         const char* e = getenv("AUR_GEMM_ROWS_NTL");
         return e ? atoi(e) : 0;
     }();
+    // N = 4096 (FC): 32 rows x 16 columns per workgroup (512 workgroups).  tools/gemm_bench, two runs at the end of round 2:
+    // 11.9-12.0 us against 13.3 us for 16 rows x 32 columns and 12.1-12.3 us for 16 x 16; AUR_GEMM_FC_TILE=1x2 restores 16 x 32
+    static const bool fc_1x2 = [] {
+        const char* e = getenv("AUR_GEMM_FC_TILE");
+        return e && e[0] == '1';
+    }();
     int ntl = 1;
     if (ln) {
         mt = 1;
-        ntl = (a.N >= 4096 && nw == 8) ? 2 : 1;
+        if (a.N >= 4096 && nw == 8) {
+            if (fc_1x2) ntl = 2;
+            else mt = 2;
+        }
         if (ntl_env == 1 || (ntl_env == 2 && nw == 8 && a.N % 32 == 0)) ntl = ntl_env;
     }
     while (mt > 1 && a.M <= 16 * (mt / 2)) mt >>= 1;
