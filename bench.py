@@ -266,6 +266,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world > 1:   # N ranks build the synthetic checkpoint at the same time on one host: share the cores instead of N x all of them
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
 
