@@ -4,7 +4,8 @@
 
 `checkpoint_dir` is the reference's on-disk format (config.json + gpt/gpt2_model.safetensors + core_xttsv2/xtts-v2.safetensors,
 e.g. written by `python -m auralis_amd.tools.convert_checkpoint model.pth out_dir`); `voice.wav` is a few seconds of
-reference speech (RIFF/WAVE) or a precomputed-conditioning .npz."""
+reference speech (RIFF/WAVE or FLAC; the conditioning networks run on the GPU through aur_compute_conditioning) or a
+precomputed-conditioning .npz."""
 import sys
 
 from auralis_amd import TTS, TTSRequest
