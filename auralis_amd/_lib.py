@@ -24,7 +24,8 @@ class AurError(RuntimeError):
 class aur_config(C.Structure):
     _fields_ = [("n_layer", C.c_int32), ("max_seqs", C.c_int32), ("max_prefill_rows", C.c_int32),
                 ("max_speakers", C.c_int32), ("vocoder_min_batch", C.c_int32), ("profile", C.c_int32),
-                ("vocoder_fp16", C.c_int32), ("second_pass", C.c_int32), ("return_latents", C.c_int32), ("kv_fp16", C.c_int32)]
+                ("vocoder_fp16", C.c_int32), ("second_pass", C.c_int32), ("return_latents", C.c_int32), ("kv_fp16", C.c_int32),
+                ("gemm_f32_exact", C.c_int32)]
 
 
 class aur_tensor_desc(C.Structure):
@@ -162,10 +163,11 @@ class NativeEngine:
 
     def __init__(self, n_layer: int = 30, max_seqs: int = 64, device: int = 0, max_prefill_rows: int = 0,
                  max_speakers: int = 0, vocoder_min_batch: int = 0, profile: bool = False, vocoder_fp16: bool = False,
-                 second_pass: bool = False, return_latents: bool = True, kv_fp16: bool = False):
+                 second_pass: bool = False, return_latents: bool = True, kv_fp16: bool = False,
+                 gemm_f32_exact: bool = False):
         self.lib = load_library()
         cfg = aur_config(n_layer, max_seqs, max_prefill_rows, max_speakers, vocoder_min_batch, int(profile),
-                         int(vocoder_fp16), int(second_pass), int(return_latents), int(kv_fp16))
+                         int(vocoder_fp16), int(second_pass), int(return_latents), int(kv_fp16), int(gemm_f32_exact))
         h = C.c_void_p()
         self._check(self.lib.aur_engine_create(C.byref(cfg), device, C.byref(h)))
         self.h = h

@@ -2,10 +2,13 @@
 whitespace, the order of the reference's `multilingual_cleaners` (src/auralis/models/xttsv2/config/tokenizer.py:
 708-719; number handling 603-700, abbreviation / symbol tables 241-600).
 
-The reference delegates number spelling to `num2words` (absent offline).  en / fr / de — the languages of BASELINE
-config 5 — are spelled out here following num2words' conventions ("one thousand, two hundred and thirty-four",
-"quatre-vingt-un", "einundzwanzig"); other languages keep their digits.  This module is CPU text plumbing in front of
-the hot path and is "parity unpinned": no num2words output can be generated in this environment.
+Everything except the spelling of a number is pinned to the reference's own functions by tests/golden/text_frontend.json
+(oracle/make_golden_text.py runs them unmodified): the tables, the regexes and their order, the separator removal, the
+integer-amount tail drop of currencies.  The reference delegates the spelling itself to `num2words`; when that package is
+importable it is used exactly as the reference uses it, otherwise en / fr / de — the languages of BASELINE config 5 — are
+spelled out here following num2words' conventions ("one thousand, two hundred and thirty-four", "quatre-vingt-un",
+"einundzwanzig") and other languages keep their digits.  zh numbers (the reference's vendored zh_num2words.TextNorm) are
+not restated.  CPU text plumbing in front of the hot path.
 """
 from __future__ import annotations
 
@@ -15,35 +18,63 @@ from typing import Callable, Dict, List, Tuple
 _WS = re.compile(r"\s+")
 
 # ------------------------------------------------------------------------------------------------ tables
-_ABBREV = {
+_ABBREV = {   # tokenizer.py:241-399
     "en": [("mrs", "misess"), ("mr", "mister"), ("dr", "doctor"), ("st", "saint"), ("co", "company"), ("jr", "junior"),
            ("maj", "major"), ("gen", "general"), ("drs", "doctors"), ("rev", "reverend"), ("lt", "lieutenant"),
            ("hon", "honorable"), ("sgt", "sergeant"), ("capt", "captain"), ("esq", "esquire"), ("ltd", "limited"),
            ("col", "colonel"), ("ft", "fort")],
+    "es": [("sra", "señora"), ("sr", "señor"), ("dr", "doctor"), ("dra", "doctora"), ("st", "santo"), ("co", "compañía"),
+           ("jr", "junior"), ("ltd", "limitada")],
     "fr": [("mme", "madame"), ("mr", "monsieur"), ("dr", "docteur"), ("st", "saint"), ("co", "compagnie"), ("jr", "junior"),
            ("ltd", "limitée")],
     "de": [("fr", "frau"), ("dr", "doktor"), ("st", "sankt"), ("co", "firma"), ("jr", "junior")],
-    "es": [("sra", "señora"), ("sr", "señor"), ("dr", "doctor"), ("dra", "doctora"), ("st", "santo"), ("co", "compañía"),
-           ("jr", "junior"), ("ltd", "limitada")],
-    "it": [("sig", "signore"), ("dr", "dottore"), ("st", "santo"), ("co", "compagnia"), ("jr", "junior"), ("ltd", "limitata")],
     "pt": [("sra", "senhora"), ("sr", "senhor"), ("dr", "doutor"), ("dra", "doutora"), ("st", "santo"), ("co", "companhia"),
            ("jr", "júnior"), ("ltd", "limitada")],
+    "it": [("sig", "signore"), ("dr", "dottore"), ("st", "santo"), ("co", "compagnia"), ("jr", "junior"), ("ltd", "limitata")],
+    "pl": [("p", "pani"), ("m", "pan"), ("dr", "doktor"), ("sw", "święty"), ("jr", "junior")],
+    "cs": [("dr", "doktor"), ("ing", "inženýr"), ("p", "pan")],
+    "nl": [("dhr", "de heer"), ("mevr", "mevrouw"), ("dr", "dokter"), ("jhr", "jonkheer")],
+    "tr": [("b", "bay"), ("byk", "büyük"), ("dr", "doktor")],
+    "hu": [("dr", "doktor"), ("b", "bácsi"), ("nőv", "nővér")],
 }
 _ABBREV_RE = {lang: [(re.compile(r"\b%s\." % a, re.IGNORECASE), b) for a, b in lst] for lang, lst in _ABBREV.items()}
+# Russian abbreviations carry a hyphen and no period (tokenizer.py:365-372)
+_ABBREV_RE["ru"] = [(re.compile(r"\b%s\b" % a, re.IGNORECASE), b) for a, b in (("г-жа", "госпожа"), ("г-н", "господин"), ("д-р", "доктор"))]
 
-_SYMBOLS = {
-    "en": [("&", " and "), ("@", " at "), ("%", " percent "), ("#", " hash "), ("$", " dollar "), ("£", " pound "), ("°", " degree ")],
-    "fr": [("&", " et "), ("@", " arobase "), ("%", " pour cent "), ("#", " dièse "), ("$", " dollar "), ("£", " livre "), ("°", " degrés ")],
-    "de": [("&", " und "), ("@", " at "), ("%", " prozent "), ("#", " raute "), ("$", " dollar "), ("£", " pfund "), ("°", " grad ")],
-    "es": [("&", " y "), ("@", " arroba "), ("%", " por ciento "), ("#", " numeral "), ("$", " dolar "), ("£", " libra "), ("°", " grados ")],
-    "it": [("&", " e "), ("@", " chiocciola "), ("%", " per cento "), ("#", " cancelletto "), ("$", " dollaro "), ("£", " sterlina "), ("°", " gradi ")],
-    "pt": [("&", " e "), ("@", " arroba "), ("%", " por cento "), ("#", " cardinal "), ("$", " dólar "), ("£", " libra "), ("°", " graus ")],
+_SYMBOL_WORDS = {   # & @ % # $ £ °  (tokenizer.py:407-594)
+    "en": ("and", "at", "percent", "hash", "dollar", "pound", "degree"),
+    "es": ("y", "arroba", "por ciento", "numeral", "dolar", "libra", "grados"),
+    "fr": ("et", "arobase", "pour cent", "dièse", "dollar", "livre", "degrés"),
+    "de": ("und", "at", "prozent", "raute", "dollar", "pfund", "grad"),
+    "pt": ("e", "arroba", "por cento", "cardinal", "dólar", "libra", "graus"),
+    "it": ("e", "chiocciola", "per cento", "cancelletto", "dollaro", "sterlina", "gradi"),
+    "pl": ("i", "małpa", "procent", "krzyżyk", "dolar", "funt", "stopnie"),
+    "ar": ("و", "على", "في المئة", "رقم", "دولار", "جنيه", "درجة"),
+    "zh": ("和", "在", "百分之", "号", "美元", "英镑", "度"),
+    "cs": ("a", "na", "procento", "křížek", "dolar", "libra", "stupně"),
+    "ru": ("и", "собака", "процентов", "номер", "доллар", "фунт", "градус"),
+    "nl": ("en", "bij", "procent", "hekje", "dollar", "pond", "graden"),
+    "tr": ("ve", "at", "yüzde", "diyez", "dolar", "sterlin", "derece"),
+    "hu": ("és", "kukac", "százalék", "kettőskereszt", "dollár", "font", "fok"),
+    "ko": ("그리고", "에", "퍼센트", "번호", "달러", "파운드", "도"),
 }
+_SYMBOLS = {lang: [(sym, " %s " % w) for sym, w in zip("&@%#$£°", words)] for lang, words in _SYMBOL_WORDS.items()}
 
-_ORDINAL_RE = {
+_ORDINAL_RE = {   # tokenizer.py:603-618
     "en": re.compile(r"([0-9]+)(st|nd|rd|th)"),
+    "es": re.compile(r"([0-9]+)(º|ª|er|o|a|os|as)"),
     "fr": re.compile(r"([0-9]+)(º|ª|er|re|e|ème)"),
     "de": re.compile(r"([0-9]+)(st|nd|rd|th|º|ª|\.(?=\s|$))"),
+    "pt": re.compile(r"([0-9]+)(º|ª|o|a|os|as)"),
+    "it": re.compile(r"([0-9]+)(º|°|ª|o|a|i|e)"),
+    "pl": re.compile(r"([0-9]+)(º|ª|st|nd|rd|th)"),
+    "ar": re.compile(r"([0-9]+)(ون|ين|ث|ر|ى)"),
+    "cs": re.compile(r"([0-9]+)\.(?=\s|$)"),
+    "ru": re.compile(r"([0-9]+)(-й|-я|-е|-ое|-ье|-го)"),
+    "nl": re.compile(r"([0-9]+)(de|ste|e)"),
+    "tr": re.compile(r"([0-9]+)(\.|inci|nci|uncu|üncü|\.)"),
+    "hu": re.compile(r"([0-9]+)(\.|adik|edik|odik|edik|ödik|ödike|ik)"),
+    "ko": re.compile(r"([0-9]+)(번째|번|차|째)"),
 }
 _NUMBER_RE = re.compile(r"[0-9]+")
 _CURRENCY_RE = {
@@ -183,46 +214,86 @@ def _de_ord(n: int) -> str:
 _CARD: Dict[str, Callable[[int], str]] = {"en": _en_card, "fr": _fr_card, "de": _de_card}
 _ORD: Dict[str, Callable[[int], str]] = {"en": _en_ord, "fr": _fr_ord, "de": _de_ord}
 _POINT = {"en": "point", "fr": "virgule", "de": "komma"}
-_CURRENCY_WORDS = {   # (major singular, major plural, minor singular, minor plural, joiner)
+_CURRENCY_WORDS = {   # (major singular, major plural, minor singular, minor plural)
     "en": {"USD": ("dollar", "dollars", "cent", "cents"), "GBP": ("pound", "pounds", "penny", "pence"),
-           "EUR": ("euro", "euro", "cent", "cents"), "join": ", "},
+           "EUR": ("euro", "euro", "cent", "cents")},
     "fr": {"USD": ("dollar", "dollars", "cent", "cents"), "GBP": ("livre", "livres", "penny", "pence"),
-           "EUR": ("euro", "euros", "centime", "centimes"), "join": " et "},
+           "EUR": ("euro", "euros", "centime", "centimes")},
     "de": {"USD": ("dollar", "dollar", "cent", "cent"), "GBP": ("pfund", "pfund", "penny", "pence"),
-           "EUR": ("euro", "euro", "cent", "cent"), "join": " und "},
+           "EUR": ("euro", "euro", "cent", "cent")},
 }
+# joiner between the major and the minor unit of num2words' currency strings (tokenizer.py:651-666); the reference cuts an
+# integer amount at the LAST occurrence of it ("twelve dollars, zero cents" -> "twelve dollars")
+_AND_EQUIVALENTS = {"en": ", ", "es": " con ", "fr": " et ", "de": " und ", "pt": " e ", "it": " e ", "pl": ", ", "cs": ", ",
+                    "ru": ", ", "nl": ", ", "ar": ", ", "tr": ", ", "hu": ", ", "ko": ", "}
+
+# A speller has num2words' call signature: speller(value, lang=..., to="cardinal" | "currency", ordinal=False, currency=None).
+Speller = Callable[..., str]
 
 
-def _spell_decimal(text: str, lang: str) -> str:
-    whole, frac = text.replace(",", ".").split(".")
-    digits = " ".join(_CARD[lang](int(d)) for d in frac)
-    return f"{_CARD[lang](int(whole))} {_POINT[lang]} {digits}"
+def builtin_speller(value, lang="en", to="cardinal", ordinal=False, currency=None) -> str:
+    """en / fr / de spelling in num2words' conventions (see the module docstring); raises NotImplementedError otherwise."""
+    if lang not in _CARD:
+        raise NotImplementedError(lang)
+    if to == "currency":
+        major = int(value)
+        cents = int(round((value - major) * 100))
+        ms, mp, cs, cp = _CURRENCY_WORDS[lang][currency]
+        return (f"{_CARD[lang](major)} {ms if major == 1 else mp}{_AND_EQUIVALENTS[lang]}"
+                f"{_CARD[lang](cents)} {cs if cents == 1 else cp}")
+    if ordinal:
+        return _ORD[lang](int(value))
+    if isinstance(value, float):
+        whole, frac = repr(value).split(".")
+        return f"{_CARD[lang](int(whole))} {_POINT[lang]} " + " ".join(_CARD[lang](int(d)) for d in frac)
+    return _CARD[lang](int(value))
 
 
-def _spell_currency(m: re.Match, lang: str, cur: str) -> str:
-    amount = float(re.sub(r"[^\d.]", "", m.group(0).replace(",", ".")))
-    major, cents = int(amount), int(round((amount - int(amount)) * 100))
-    w = _CURRENCY_WORDS[lang]
-    ms, mp, cs, cp = w[cur]
-    out = f"{_CARD[lang](major)} {ms if major == 1 else mp}"
-    if cents:   # the reference drops the ", zero cents" tail of integer amounts (tokenizer.py:668-673)
-        out += f"{w['join']}{_CARD[lang](cents)} {cs if cents == 1 else cp}"
-    return out
+def default_speller(lang: str):
+    """num2words itself when it is installed (what the reference calls), else the built-in en / fr / de speller, else None
+    (digits stay)."""
+    try:
+        from num2words import num2words
+        return num2words
+    except ImportError:
+        return builtin_speller if lang in _CARD else None
 
 
-def expand_numbers(text: str, lang: str) -> str:
+def expand_numbers(text: str, lang: str, speller: "Speller | None" = None) -> str:
+    """expand_numbers_multilingual (tokenizer.py:681-700) for the non-zh languages: thousands separators removed ("," for
+    en / ru, "." otherwise), then currencies (GBP, USD, EUR; failures ignored as in the reference), decimals (not for tr),
+    ordinals (languages with a pattern), remaining integers."""
     base = lang.split("-")[0]
-    if base not in _CARD:
+    if base == "zh":
+        return text   # the reference's vendored Chinese normaliser (zh_num2words.TextNorm) is not restated
+    spell = speller if speller is not None else default_speller(base)
+    if spell is None:
         return text
-    if base == "en":
+    n2w_lang = "cz" if base == "cs" else base   # tokenizer.py:645: num2words calls Czech "cz"
+
+    def currency(m: "re.Match", cur: str) -> str:
+        amount = float(re.sub(r"[^\d.]", "", m.group(0).replace(",", ".")))
+        full = spell(amount, to="currency", currency=cur, lang=n2w_lang)
+        if amount.is_integer():
+            last = full.rfind(_AND_EQUIVALENTS.get(base, ", "))
+            if last != -1:
+                full = full[:last]
+        return full
+
+    if base in ("en", "ru"):
         text = _COMMA_NUMBER_RE.sub(lambda m: m.group(0).replace(",", ""), text)
     else:
         text = _DOT_NUMBER_RE.sub(lambda m: m.group(0).replace(".", ""), text)
-    for cur in ("GBP", "USD", "EUR"):
-        text = _CURRENCY_RE[cur].sub(lambda m, c=cur: _spell_currency(m, base, c), text)
-    text = _DECIMAL_RE.sub(lambda m: _spell_decimal(m.group(1), base), text)
-    text = _ORDINAL_RE[base].sub(lambda m: _ORD[base](int(m.group(1))), text)
-    return _NUMBER_RE.sub(lambda m: _CARD[base](int(m.group(0))), text)
+    try:
+        for cur in ("GBP", "USD", "EUR"):
+            text = _CURRENCY_RE[cur].sub(lambda m, c=cur: currency(m, c), text)
+    except Exception:
+        pass
+    if base != "tr":
+        text = _DECIMAL_RE.sub(lambda m: spell(float(m.group(1).replace(",", ".")), lang=n2w_lang), text)
+    if base in _ORDINAL_RE:
+        text = _ORDINAL_RE[base].sub(lambda m: spell(int(m.group(1)), ordinal=True, lang=n2w_lang), text)
+    return _NUMBER_RE.sub(lambda m: spell(int(m.group(0)), lang=n2w_lang), text)
 
 
 def expand_abbreviations(text: str, lang: str) -> str:
@@ -237,12 +308,12 @@ def expand_symbols(text: str, lang: str) -> str:
     return text.strip()
 
 
-def multilingual_cleaners(text: str, lang: str) -> str:
+def multilingual_cleaners(text: str, lang: str, speller: "Speller | None" = None) -> str:
     text = text.replace('"', "")
     if lang == "tr":
         text = text.replace("İ", "i").replace("Ö", "ö").replace("Ü", "ü")
     text = text.lower()
-    text = expand_numbers(text, lang)
+    text = expand_numbers(text, lang, speller)
     text = expand_abbreviations(text, lang)
     text = expand_symbols(text, lang)
     return _WS.sub(" ", text)

@@ -25,13 +25,29 @@ _ABBREV = {"mr.", "mrs.", "ms.", "dr.", "prof.", "st.", "sr.", "jr.", "mt.", "vs
            "mar.", "apr.", "jun.", "jul.", "aug.", "sep.", "sept.", "oct.", "nov.", "dec.", "ph.d.", "u.s.", "u.k."}
 
 
-def _sentencize(text: str) -> List[str]:
+def _sentencize(text: str, lang: str = "en") -> List[str]:
     """Rule-based sentence boundaries as spaCy's `sentencizer` draws them on a blank pipeline (tokenizer.py:185-191): a
     sentence ends after a token consisting of sentence punctuation (plus any punctuation-only tokens after it) and the next
     sentence starts at the following token.  The tokenizer is approximated on whitespace-separated words: a word's trailing run
     of sentence punctuation (optionally followed by closing quotes / brackets) is that punctuation token, unless the word is
     one of the tokenizer's abbreviation exceptions, a single letter + '.', or a number / dotted token with no space (3.14,
-    example.com keep their dots because the period is word-internal)."""
+    example.com keep their dots because the period is word-internal).  zh / ja have no spaces: spaCy's Chinese() tokenizer
+    is character-level there, so every sentence-punctuation character (plus closers after it) ends a sentence wherever it
+    stands in the string."""
+    if lang in ("zh", "ja"):
+        out, start, i, n = [], 0, 0, len(text)
+        while i < n:
+            if text[i] in _SENT_PUNCT:
+                j = i + 1
+                while j < n and (text[j] in _SENT_PUNCT or text[j] in _CLOSERS):
+                    j += 1
+                out.append(text[start:j])
+                start = i = j
+            else:
+                i += 1
+        if text[start:].strip():
+            out.append(text[start:])
+        return out
     out, start = [], 0
     for m in re.finditer(r"\S+", text):
         w = m.group(0)
@@ -68,17 +84,17 @@ def find_best_split_point(text: str, target_pos: int, window_size: int = 30) -> 
     return best_pos
 
 
-def split_sentence(text: str, lang: str, text_split_length: int = 250) -> List[str]:
-    """tokenizer.py:119-236: sentences (spaCy sentencizer, restated in _sentencize) are packed greedily into chunks of at most
-    `text_split_length` characters; a sentence longer than the limit is cut at find_best_split_point; a trailing '.' of a
-    chunk becomes a space (":234, prevents annoying sounds")."""
+def split_sentence(text: str, lang: str, text_split_length: int = 250, sentences: Optional[List[str]] = None) -> List[str]:
+    """tokenizer.py:119-236: sentences (spaCy sentencizer, restated in _sentencize; `sentences` injects a precomputed list, as
+    the golden test does) are packed greedily into chunks of at most `text_split_length` characters; a sentence longer than
+    the limit is cut at find_best_split_point; a trailing '.' of a chunk becomes a space (":234, prevents annoying sounds")."""
     text = text.strip()
     if len(text) <= text_split_length:
         return [text]
     splits: List[str] = []
     cur: List[str] = []
     cur_len = 0
-    for sent in _sentencize(text):
+    for sent in (sentences if sentences is not None else _sentencize(text, lang.split("-")[0])):
         s = sent.strip()
         n = len(s)
         if cur_len + n <= text_split_length:

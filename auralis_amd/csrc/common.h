@@ -90,4 +90,7 @@ __device__ __forceinline__ float gelu_new(float x) {
     return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
 }
 
+// erf-form GELU (config.json "activation_function": "gelu", the XTTSGPTConfig class default, xttsv2_gpt_config.py:184)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
 }  // namespace aur

@@ -44,6 +44,11 @@ struct DevBuf {
         HIP_CHECK(hipMalloc(&p, n));
         bytes = n;
     }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
     template <class T>
     T* as() const {
         return reinterpret_cast<T*>(p);
@@ -177,6 +182,7 @@ public:
         n_blocks_ = (long)S * kMaxBlocks + 2L * cfg_.max_speakers;   // + 2 shared prefix blocks per speaker
         kv_layer_stride_ = n_blocks_ * kKvBlockElems;
         kv_half_ = cfg_.kv_fp16 != 0;
+        gemm_prec_ = cfg_.gemm_f32_exact ? 0 : 1;
         kv_.ensure((size_t)cfg_.n_layer * kv_layer_stride_ * (kv_half_ ? 2 : 4));
         for (int b = (int)n_blocks_ - 1; b >= 0; --b) free_blocks_.push_back(b);
         auto ints = [&](DevBuf& b, size_t n) {
@@ -837,11 +843,21 @@ public:
             HIP_CHECK(hipMemcpy(dg.p, gamma, (size_t)K * 4, hipMemcpyHostToDevice));
             HIP_CHECK(hipMemcpy(dbe.p, beta, (size_t)K * 4, hipMemcpyHostToDevice));
         }
-        launch_pack_wt16(dw.as<float>(), N, dwt.as<float>(), K, N, st_);
         GemmRowsArgs a{};
+        DevBuf dsc, dvec;
+        if (ln) {   // LayerNorm folded into the weights, as ensure_gpt() does at load time
+            dsc.ensure((size_t)K * N * 4);
+            dvec.ensure((size_t)2 * N * 4);
+            launch_fold_ln(dw.as<float>(), N, dg.as<float>(), dbe.as<float>(), bias ? db.as<float>() : nullptr, dsc.as<float>(),
+                           dwt.as<float>(), dvec.as<float>(), dvec.as<float>() + N, K, N, st_);
+            a.ln_c1 = dvec.as<float>();
+            a.bias = dvec.as<float>() + N;
+        } else {
+            launch_pack_wt16(dw.as<float>(), N, dwt.as<float>(), K, N, st_);
+            a.bias = bias ? db.as<float>() : nullptr;
+        }
         a.X = dx.as<float>(); a.xmt = mtt; a.Wt = dwt.as<float>(); a.M = M; a.N = N; a.K = K;
-        a.bias = bias ? db.as<float>() : nullptr;
-        a.gamma = ln ? dg.as<float>() : nullptr; a.beta = ln ? dbe.as<float>() : nullptr; a.eps = 1e-5f;
+        a.eps = 1e-5f; a.prec = gemm_prec_;
         a.stats_in = ln ? dst.as<float2>() : nullptr;
         a.out = dout.as<float>(); a.ldo = N; a.omt = mtt;
         launch_gemm_rows(a, ln, (GemmRowsEpi)epi, st_);
@@ -993,7 +1009,9 @@ private:
     };
     struct LayerW {
         const float *ln1w, *ln1b, *wqkv, *bqkv, *wproj, *bproj, *ln2w, *ln2b, *wfc, *bfc, *wproj2, *bproj2;
-        const float *tqkv, *tproj, *tfc, *tproj2;   // pack_wt16 copies for the decode-regime GEMM (gemm_rows_kernel)
+        const float *tqkv, *tproj, *tfc, *tproj2;   // pack_wt16 copies for the decode-regime GEMM (gemm_rows_kernel); tqkv / tfc
+                                                    // have LayerNorm folded in (launch_fold_ln)
+        const float *qkv_c1, *qkv_c2, *fc_c1, *fc_c2;   // ... with these epilogue vectors
     };
     // device-side repack of one [K][N] matrix into the decode GEMM's tile order (done once per load)
     const float* packed_copy(const float* Wm, int ldw, int K, int N) {
@@ -1001,6 +1019,21 @@ private:
         DevBuf& b = *packed_.back();
         b.ensure((size_t)K * N * sizeof(float));
         launch_pack_wt16(Wm, ldw, b.as<float>(), K, N, st_);
+        return b.as<float>();
+    }
+    // LayerNorm-folded packed copy of a [K][N] matrix plus its two epilogue vectors (launch_fold_ln)
+    const float* folded_copy(const float* Wm, const float* gamma, const float* beta, const float* bias, int K, int N,
+                             const float** c1, const float** c2) {
+        fold_scratch_.ensure((size_t)K * N * sizeof(float));
+        packed_.emplace_back(new DevBuf());
+        DevBuf& b = *packed_.back();
+        b.ensure((size_t)K * N * sizeof(float));
+        packed_.emplace_back(new DevBuf());
+        DevBuf& v = *packed_.back();
+        v.ensure((size_t)2 * N * sizeof(float));
+        launch_fold_ln(Wm, N, gamma, beta, bias, fold_scratch_.as<float>(), b.as<float>(), v.as<float>(), v.as<float>() + N, K, N, st_);
+        *c1 = v.as<float>();
+        *c2 = v.as<float>() + N;
         return b.as<float>();
     }
     void ensure_gpt() {
@@ -1017,14 +1050,15 @@ private:
             l.wfc = W(p + "mlp.c_fc.w", (int64_t)H * 4 * H); l.bfc = W(p + "mlp.c_fc.b", 4 * H);
             l.wproj2 = W(p + "mlp.c_proj.w", (int64_t)4 * H * H); l.bproj2 = W(p + "mlp.c_proj.b", H);
             l.tqkv = l.tproj = l.tfc = l.tproj2 = nullptr;
+            l.qkv_c1 = l.qkv_c2 = l.fc_c1 = l.fc_c2 = nullptr;
             layers_.push_back(l);
         }
         packed_.clear();
         if (rows_gemm_) {
             for (auto& l : layers_) {
-                l.tqkv = packed_copy(l.wqkv, 3 * H, H, 3 * H);
+                l.tqkv = folded_copy(l.wqkv, l.ln1w, l.ln1b, l.bqkv, H, 3 * H, &l.qkv_c1, &l.qkv_c2);
                 l.tproj = packed_copy(l.wproj, H, H, H);
-                l.tfc = packed_copy(l.wfc, 4 * H, H, 4 * H);
+                l.tfc = folded_copy(l.wfc, l.ln2w, l.ln2b, l.bfc, H, 4 * H, &l.fc_c1, &l.fc_c2);
                 l.tproj2 = packed_copy(l.wproj2, H, 4 * H, H);
             }
         }
@@ -1036,6 +1070,7 @@ private:
         headb_ = W("mel_head.b", kHeadPad);
         thead_ = rows_gemm_ ? packed_copy(headT_, kHeadPad, H, kHeadPad) : nullptr;
         HIP_CHECK(hipStreamSynchronize(st_));
+        fold_scratch_.release();
         text_emb_ = W("text_emb");
         text_pos_ = W("text_pos");
         text_vocab_ = (int)(w_.at("text_emb").numel / H);
@@ -1124,9 +1159,9 @@ private:
             const LayerW& L = layers_[l];
             void* kvl = kv_layer(l);
             GemmRowsArgs a{};
-            a.M = M; a.eps = 1e-5f;
-            a.X = h; a.xmt = mtt; a.Wt = L.tqkv; a.N = 3 * kHidden; a.K = kHidden; a.bias = L.bqkv;
-            a.gamma = L.ln1w; a.beta = L.ln1b; a.stats_in = w.stats.as<float2>(); a.out = w.qbuf.as<float>(); a.ldo = kHidden;
+            a.M = M; a.eps = 1e-5f; a.prec = gemm_prec_;
+            a.X = h; a.xmt = mtt; a.Wt = L.tqkv; a.N = 3 * kHidden; a.K = kHidden; a.bias = L.qkv_c2;
+            a.ln_c1 = L.qkv_c1; a.stats_in = w.stats.as<float2>(); a.out = w.qbuf.as<float>(); a.ldo = kHidden;
             a.kv_layer = kvl; a.kv_half = kv_half_ ? 1 : 0; a.row_meta = w.row_meta.as<int>(); a.row_slot = d_row_slot; a.slot_kvpos = kvpos; a.block_tables = bt; a.max_blocks = kMaxBlocks;
             gemm_rows(w, a, true, kEpiQkv, 0);
             if (gemm_prof_now_) {
@@ -1138,15 +1173,15 @@ private:
                 launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, nullptr, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, mtt, kv_half_, w.row_meta.as<int>());
             }
             a = GemmRowsArgs{};
-            a.M = M; a.X = w.att.as<float>(); a.xmt = mtt; a.Wt = L.tproj; a.N = kHidden; a.K = kHidden; a.bias = L.bproj;
+            a.M = M; a.prec = gemm_prec_; a.X = w.att.as<float>(); a.xmt = mtt; a.Wt = L.tproj; a.N = kHidden; a.K = kHidden; a.bias = L.bproj;
             a.out = h; a.omt = mtt; a.stats_out = w.stats.as<float2>();
             gemm_rows(w, a, false, kEpiResidual, 1);
             a = GemmRowsArgs{};
-            a.M = M; a.eps = 1e-5f; a.X = h; a.xmt = mtt; a.Wt = L.tfc; a.N = 4 * kHidden; a.K = kHidden; a.bias = L.bfc;
-            a.gamma = L.ln2w; a.beta = L.ln2b; a.stats_in = w.stats.as<float2>(); a.out = w.act.as<float>(); a.omt = mtt;
+            a.M = M; a.prec = gemm_prec_; a.eps = 1e-5f; a.X = h; a.xmt = mtt; a.Wt = L.tfc; a.N = 4 * kHidden; a.K = kHidden; a.bias = L.fc_c2;
+            a.ln_c1 = L.fc_c1; a.stats_in = w.stats.as<float2>(); a.out = w.act.as<float>(); a.omt = mtt;
             gemm_rows(w, a, true, kEpiBiasGelu, 2);
             a = GemmRowsArgs{};
-            a.M = M; a.X = w.act.as<float>(); a.xmt = mtt; a.Wt = L.tproj2; a.N = kHidden; a.K = 4 * kHidden; a.bias = L.bproj2;
+            a.M = M; a.prec = gemm_prec_; a.X = w.act.as<float>(); a.xmt = mtt; a.Wt = L.tproj2; a.N = kHidden; a.K = 4 * kHidden; a.bias = L.bproj2;
             a.out = h; a.omt = mtt;
             if (l + 1 < cfg_.n_layer) a.stats_out = w.stats.as<float2>();   // (ln_f computes its own statistics in final_rows_kernel)
             gemm_rows(w, a, false, kEpiResidual, 3);
@@ -1287,7 +1322,7 @@ private:
         launch_final_rows(w.h.as<float>(), mtt, w.i_sample_slot.as<int>(), lnfw_, lnfb_, fnw_, fnb_, w.ybuf.as<float>(),
                           latents_.as<float>(), (long)kMaxLatRows * kHidden, slot_ngen_.as<int>(), kMaxLatRows, Ms, 1e-5f, w.st);
         GemmRowsArgs a{};
-        a.M = Ms; a.X = w.ybuf.as<float>(); a.xmt = mtt; a.Wt = thead_; a.N = kHeadPad; a.K = kHidden; a.bias = headb_;
+        a.M = Ms; a.prec = gemm_prec_; a.X = w.ybuf.as<float>(); a.xmt = mtt; a.Wt = thead_; a.N = kHeadPad; a.K = kHidden; a.bias = headb_;
         a.out = w.P2.as<float>(); a.ldo = kHeadPad;
         gemm_rows(w, a, false, kEpiBias, 4);
         SamplerArgs sa = sampler_args(w, w.P2.as<float>(), 1, Ms, kHeadPad, zero_bias_.as<float>(), nullptr);
@@ -1909,6 +1944,8 @@ private:
     bool gpt_ready_ = false, voc_ready_ = false;
     std::vector<LayerW> layers_;
     std::vector<std::unique_ptr<DevBuf>> packed_;   // pack_wt16 copies (decode GEMM layout)
+    DevBuf fold_scratch_;                           // load-time scratch of launch_fold_ln
+    int gemm_prec_ = 1;                             // GemmRowsArgs.prec of every decode GEMM (aur_config.gemm_f32_exact)
     const float* thead_ = nullptr;
     int fail_at_step_ = 0;              // AUR_TEST_FAIL_STEP=n: throw inside the n-th aur_step (recovery test)
     bool tile_gemm_ = true;             // AUR_PREFILL_GEMM=splitk selects the round-1 fused-slice kernel for prefill-type GEMMs

@@ -99,9 +99,8 @@ struct GemmRowsArgs {
     int xmt;             // 16-row tiles allocated in X (pk_off's mtt); >= ceil(M / 64) * 4
     const float* Wt;     // packed (pack_wt16)
     int M, N, K;
-    const float* bias;   // [N] or nullptr
-    const float* gamma;  // LN prologue (ln != 0): LayerNorm weight / bias over K == 1024
-    const float* beta;
+    const float* bias;   // [N] or nullptr; LayerNorm-folded GEMMs: c2 of launch_fold_ln (required)
+    const float* ln_c1;  // LayerNorm-folded GEMMs (ln != 0, K == 1024): c1 of launch_fold_ln, Wt = its folded packed weights
     float eps;
     float* out;          // kEpiBias: row-major out[m][n] (ldo);  kEpiBiasGelu: packed rows (omt);  kEpiResidual: packed rows,
                          // out[m][n] += total + bias;  kEpiQkv: row-major q rows [M][1024]
@@ -121,13 +120,27 @@ struct GemmRowsArgs {
     // row itself, so its MFMAs can start on the first K block that arrives and need no workgroup-wide reduction.
     const float2* stats_in;   // LN prologue: [rows][64]
     float2* stats_out;        // kEpiResidual (N == 1024): [rows][64], may be nullptr
-    int nt_w;            // 1: non-temporal loads on the weight stream (read once per step by exactly one CU when there is a
-                         // single row group); launch_gemm_rows sets it from AUR_GEMM_NT
+    int gelu_erf;        // kEpiBiasGelu: 1 = erf form ("gelu"), 0 = tanh form ("gelu_new")
+    int prec;            // arithmetic: 0 = exact f32 MFMA (v_mfma_f32_16x16x4_f32); 1 = every operand split exactly into three bf16
+                         // terms, six bf16 MFMAs per product with fp32 accumulation (same accuracy class as an fp32 dot product,
+                         // not bitwise an fma chain; 2.7x less matrix-pipe time).  aur_config.gemm_f32_exact selects 0.
     long long* prof;     // optional (tools/gemm_bench): 8 wall_clock64 stamps (100 MHz, device-wide) per workgroup, written by wave 0
 };
 void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream_t st);
+// Workgroup shape the launcher picks for a GEMM kind at M rows: 16*mt rows x 16*ntl columns, nw waves (K split nw ways).
+struct GemmRowsShape {
+    int mt, nw, ntl;
+};
+GemmRowsShape gemm_rows_shape(int M, int N, int K, bool ln);
+
 // Wt = pack_wt16(W), W row-major [K][ldw], N % 16 == 0, K % 16 == 0
 void launch_pack_wt16(const float* W, int ldw, float* Wt, int K, int N, hipStream_t st);
+// LayerNorm folded into the GEMM that follows it:  LN(x) W + b = rstd * (x Wf - mean * c1) + c2  with Wf = diag(gamma) W,
+// c1[n] = sum_k Wf[k][n], c2[n] = sum_k beta[k] W[k][n] + b[n].  Writes Wt = pack_wt16(Wf), c1 and c2 ([N] each); `scratch` holds
+// K * N floats (Wf unpacked).  The decode GEMM then multiplies the RAW residual rows and applies the row statistics in its
+// epilogue, so nothing in front of its MFMAs depends on them.
+void launch_fold_ln(const float* W, int ldw, const float* gamma, const float* beta, const float* bias, float* scratch, float* Wt,
+                    float* c1, float* c2, int K, int N, hipStream_t st);
 // decode tail: y[j] = final_norm(ln_f(h[j])) -> ybuf;  latents[slot][ngen[slot]] = final_norm(y[j]);  h and ybuf are
 // packed rows with `mtt` 16-row tiles, latents row-major
 void launch_final_rows(const float* h, int mtt, const int* sample_slot, const float* lnf_w, const float* lnf_b, const float* fn_w,
@@ -175,8 +188,8 @@ void launch_embed_prompt(const int4* desc, const float* spk_cond, const float* t
 // h_mtt > 0: h is written as packed rows and stats[row][64] receives the LayerNorm partials of each row (GemmRowsArgs).
 // row_meta (optional, [M][kRowMetaStride] ints): the step's per-row K/V addressing, gathered once per step for the 30
 // attention launches and QKV epilogues: [0] = K/V position of the new token (slot_kvpos), [1] = slot,
-// [kRowMetaBt ..] = the slot's block table.
-constexpr int kRowMetaStride = 80, kRowMetaBt = 8;
+// [kRowMetaWblk] = the block that position falls in (where the QKV epilogue writes K/V), [kRowMetaBt ..] = the slot's block table.
+constexpr int kRowMetaStride = 80, kRowMetaBt = 8, kRowMetaWblk = 2;
 void launch_embed_decode(const int* row_slot, const int* slot_tok, const int* slot_pos, const float* wte,
                          const float* wpe, float* h, int M, hipStream_t st, int h_mtt = 0, float2* stats = nullptr,
                          int* row_meta = nullptr, const int* slot_kvpos = nullptr, const int* block_tables = nullptr,

@@ -352,6 +352,39 @@ __global__ __launch_bounds__(256) void pack_wt16_kernel(const float* __restrict_
     *reinterpret_cast<f32x4*>(Wt + idx * 4) = v;
 }
 
+// LayerNorm folded into a [K][N] weight matrix: Wf[k][n] = gamma[k] * W[k][n] (then packed like pack_wt16), c1[n] = sum_k Wf[k][n],
+// c2[n] = sum_k beta[k] * W[k][n] + bias[n] (sums in double).  One thread per column for the vectors.
+__global__ __launch_bounds__(256) void fold_ln_vectors_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ bias,
+                                                              float* __restrict__ c1, float* __restrict__ c2, int K, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const float wv = W[(long)k * ldw + n];
+        s1 += (double)(gamma[k] * wv);   // the rounded product the GEMM multiplies with
+        s2 += (double)beta[k] * (double)wv;
+    }
+    c1[n] = (float)s1;
+    c2[n] = (float)(s2 + (bias ? (double)bias[n] : 0.0));
+}
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ gamma,
+                                                         float* __restrict__ out, int K, int N) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)K * N) return;
+    const int k = (int)(idx / N), n = (int)(idx - (long)k * N);
+    out[idx] = gamma[k] * W[(long)k * ldw + n];
+}
+void launch_fold_ln(const float* W, int ldw, const float* gamma, const float* beta, const float* bias, float* scratch, float* Wt,
+                    float* c1, float* c2, int K, int N, hipStream_t st) {
+    AUR_REQUIRE(N % 16 == 0 && K % 16 == 0 && ldw >= N, "fold_ln: shape");
+    trace_launch("fold_ln");
+    hipLaunchKernelGGL(fold_ln_vectors_kernel, dim3((N + 255) / 256), dim3(256), 0, st, W, ldw, gamma, beta, bias, c1, c2, K, N);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)(((long)K * N + 255) / 256)), dim3(256), 0, st, W, ldw, gamma, scratch, K, N);
+    HIP_CHECK(hipGetLastError());
+    launch_pack_wt16(scratch, N, Wt, K, N, st);
+}
+
 void launch_pack_wt16(const float* W, int ldw, float* Wt, int K, int N, hipStream_t st) {
     AUR_REQUIRE(N % 16 == 0 && K % 16 == 0 && ldw >= N, "pack_wt16: shape");
     const long total = (long)(N >> 4) * (K >> 4) * 64;
@@ -360,26 +393,49 @@ void launch_pack_wt16(const float* W, int ldw, float* Wt, int K, int N, hipStrea
     HIP_CHECK(hipGetLastError());
 }
 
-template <int MT, int KCH, bool LN, int EPI, int NW, int NTL = 1>
-__global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
-    // NTL = 16-column tiles per workgroup (each wave keeps MT x NTL accumulator tiles): 2 halves the activation bytes a
-    // workgroup pulls per weight byte; the K order of every output element is the same for NTL = 1 and 2 (bitwise equal)
+// PREC = 1: every fp32 operand is split exactly into three bf16 terms (x = h + m + l, round-to-nearest at each step) and a
+// product runs as six bf16 MFMAs with fp32 accumulation (h*h into `acc`; h*m, m*h, m*m, h*l, l*h into `lo`; the three dropped
+// terms are below 2^-25 of the product): 6 x 17 cycles per 16 x 16 x 32 block instead of 8 x 32 for v_mfma_f32_16x16x4_f32.
+// The two float4 a lane holds for K blocks (2p, 2p + 1) form its 8-element fragment; A and B use the same assignment, so the
+// packed layouts stay as they are.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split3_bf16(const f32x4& x0, const f32x4& x1, bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float x = i < 4 ? x0[i] : x1[i - 4];
+        const __bf16 hh = (__bf16)x;
+        const float r = x - (float)hh;
+        const __bf16 mm = (__bf16)r;
+        h[i] = hh;
+        m[i] = mm;
+        l[i] = (__bf16)(r - (float)mm);
+    }
+}
+
+// DBG (tools/gemm_bench only): bit 0 = no weight loads, bit 1 = no activation loads, bit 2 = no MFMAs
+template <int MT, int KCH, bool LN, int EPI, int NW, int NTL = 1, int PREC = 0, int DBG = 0>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, NW == 16 ? 4 : (NW == 8 ? 6 : 8))))
+void gemm_rows_kernel(GemmRowsArgs a) {
+    // (amdgpu_waves_per_eu: without the cap hipcc schedules for 8 waves per SIMD — 64 VGPRs — and gets there by issuing the tile
+    // loads two at a time between the MFMAs: 5-7 dependent memory round trips per launch instead of one.  A 16-wave workgroup
+    // occupies 4 waves per SIMD anyway.)
+    // NTL = 16-column tiles per workgroup (each wave keeps MT x NTL accumulator tiles): the activation rows a CU pulls through
+    // its L1 are shared by NTL column tiles; the K order of every output element is the same for every NTL (bitwise equal)
     static_assert(!LN || KCH == 1, "LN prologue needs the whole row in one chunk");
     static_assert(NW == 4 || NW == 8 || NW == 16, "waves per workgroup");
     constexpr int NB = 64 / NW;   // 16-deep K blocks per wave per 1024-deep chunk
     __shared__ __attribute__((aligned(16))) float red[NW][MT * NTL * 256];
     __shared__ float rs[LN ? 16 * MT : 1][2];   // (mean, rstd) of the workgroup's rows
-    __shared__ __attribute__((aligned(16))) float gb[LN ? 2 : 1][LN ? 1024 : 4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
     // workgroup -> (column tile, row group): the row groups of one column tile get ids 8 apart (same XCD, adjacent in
     // dispatch order) so that the tile's weights leave HBM once and the other groups hit them in that XCD's L2
     const int n_tiles = a.N / (16 * NTL), n_grp = (a.M + 16 * MT - 1) / (16 * MT);
     int ntile, mgrp;
+    const int L = blockIdx.x;
     {
         // (the grid is padded to a multiple of 8 column tiles: the mel head has 68, and with the plain order its four row
         // groups landed on four XCDs and pulled the weights from HBM four times: PMC 18.7 MB per launch for 4.5 MB of weights)
-        const int L = blockIdx.x;
         const int xcd = L & 7, slot = L >> 3;
         mgrp = slot % n_grp;
         ntile = (slot / n_grp) * 8 + xcd;
@@ -392,100 +448,134 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
     // the last tiles are allocated but undefined: their products stay in their own (never stored) output rows
     const f32x4* xp = reinterpret_cast<const f32x4*>(a.X) + (long)(mgrp * MT) * 64 + lane;
     // K = 4096: two chunk buffers (the loads run one 1024-deep chunk ahead of the MFMAs).  Three buffers measured slower
-    // (13.6 vs 12.3 us at M = 64): the launch is bound by the 512 KB each workgroup pulls through its L1, not by latency.
+    // (13.6 vs 12.3 us at M = 64).
     constexpr int NBUF = (KCH > 1) ? 2 : 1;
     f32x4 bf[NBUF][NTL][NB], af[NBUF][MT][NB];
+    // loads in K-block order (for PREC 1 in pairs of blocks): the MFMAs of block b need exactly the first (b + 1) / NB of the
+    // chunk's loads, and loads return in order
     auto load_chunk = [&](int c, int buf) {
         const int kb0 = c * 64 + NB * w;
 #pragma unroll
-        for (int t = 0; t < NTL; ++t)
+        for (int b = 0; b < NB; ++b) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const f32x4* src = &wt[t * wt_tile + (long)(kb0 + b) * 64];
-                bf[buf][t][b] = a.nt_w ? __builtin_nontemporal_load(src) : *src;
+            for (int t = 0; t < NTL; ++t) {
+                if (DBG & 1) bf[buf][t][b] = f32x4{0.01f * lane, 0.02f, 0.03f, 0.01f * (kb0 + b)};
+                else bf[buf][t][b] = wt[t * wt_tile + (long)(kb0 + b) * 64];
             }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int b = 0; b < NB; ++b) af[buf][mt][b] = xp[((long)(kb0 + b) * a.xmt + mt) * 64];
+            for (int mt = 0; mt < MT; ++mt) {
+                if (DBG & 2) af[buf][mt][b] = f32x4{0.01f * lane, 0.02f, 0.03f, 0.01f * (kb0 + b)};
+                else af[buf][mt][b] = xp[((long)(kb0 + b) * a.xmt + mt) * 64];
+            }
+            if (PREC == 0 || (b & 1)) __builtin_amdgcn_sched_barrier(0);   // (hipcc reorders the loads among themselves otherwise)
+        }
+        // nothing below may move above this line and no load above may sink below it (hipcc otherwise sinks the tile loads
+        // under the LayerNorm barrier and next to their first use)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     };
     if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 0] = (long long)wall_clock64();
-    f32x4 acc[MT][NTL];
+    f32x4 acc[MT][NTL], lo[PREC ? MT : 1][PREC ? NTL : 1];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int t = 0; t < NTL; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // LN prologue inputs first: the statistics partials and gamma / beta are small and must not queue behind the tile loads
-    // (loads return in order).  Wave w combines rows w, w + NW, ...; lane t holds column tile t.
-    constexpr int RPW = LN ? 16 * MT / NW : 1;   // rows per wave
+        for (int t = 0; t < NTL; ++t) {
+            acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (PREC) lo[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    // Epilogue inputs first of all: one output element per thread (e = tid), so its bias, residual value and K/V write
+    // position are known now.  Loaded here they arrive with the operands instead of costing one to three dependent memory
+    // round trips after the reduction (loads return in order: these are the oldest).
+    constexpr int NE = MT * NTL * 256;
+    static_assert(NE <= 64 * NW, "one output element per thread");
+    const int e = min(tid, NE - 1);
+    const int ect = (e >> 8) / MT, emt = (e >> 8) - ect * MT;
+    const int em = m0 + 16 * emt + 4 * ((e & 63) >> 4) + ((e >> 6) & 3), en = n0 + 16 * ect + (e & 15);
+    float ebias = 0.f, ec1 = 0.f;
+    if (a.bias) ebias = a.bias[en];   // (a pointer select here compiles to a FLAT load, after which every wait is vmcnt(0))
+    if (LN) ec1 = a.ln_c1[en];
+    float* eptr = nullptr;
+    float eres = 0.f;
+    if (EPI == kEpiResidual) {
+        eptr = a.out + pk_off(em, en, a.omt);
+        eres = *eptr;
+    }
+    int epos = 0, eblk = 0;
+    if (EPI == kEpiQkv) {
+        if (a.row_meta) {
+            epos = a.row_meta[(long)em * kRowMetaStride];
+            eblk = a.row_meta[(long)em * kRowMetaStride + kRowMetaWblk];
+        }
+    }
+    // LayerNorm is folded into the weights (launch_fold_ln): the MFMAs run on the raw rows, nothing in front of them waits
+    // for the statistics or for the other waves, and the epilogue applies  y = rstd * (x W' - mean * c1) + c2.  The partials
+    // of the rows this wave will combine (rows w, w + NW, ...; lane t holds column tile t) are requested first.
+    constexpr int RPW = LN ? (16 * MT + NW - 1) / NW : 1;   // rows per wave
     float2 pt[RPW];
-    f32x4 gbv = {0.f, 0.f, 0.f, 0.f}, gbv2 = {0.f, 0.f, 0.f, 0.f};
     if (LN) {
 #pragma unroll
-        for (int u = 0; u < RPW; ++u) pt[u] = a.stats_in[(long)(m0 + w + NW * u) * 64 + lane];
-        if (NW >= 8) {
-            if (tid < 512) gbv = *reinterpret_cast<const f32x4*>(((tid < 256) ? a.gamma : a.beta) + 4 * (tid & 255));
-        } else {
-            gbv = *reinterpret_cast<const f32x4*>(a.gamma + 4 * tid);
-            gbv2 = *reinterpret_cast<const f32x4*>(a.beta + 4 * tid);
-        }
+        for (int u = 0; u < RPW; ++u) pt[u] = a.stats_in[(long)(m0 + min(w + NW * u, 16 * MT - 1)) * 64 + lane];
     }
     load_chunk(0, 0);
     if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 1] = (long long)wall_clock64();
-    float mean[MT], rstd[MT];
-    if (LN) {
-        __builtin_amdgcn_sched_barrier(0);   // everything above is in flight before the first wait
-        // gamma / beta go through LDS (8 KB): holding this lane's values in registers next to the A registers of a 64-row
-        // tile spilled
-        if (NW >= 8) {
-            if (tid < 512) *reinterpret_cast<f32x4*>(&gb[tid >> 8][4 * (tid & 255)]) = gbv;
-        } else {
-            *reinterpret_cast<f32x4*>(&gb[0][4 * tid]) = gbv;
-            *reinterpret_cast<f32x4*>(&gb[1][4 * tid]) = gbv2;
+    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 2] = (long long)wall_clock64();
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+        const int cur = c % NBUF;
+        // (NBUF == 1: chunk 0 is already in flight; round 2 re-issued it here, which made the loads above dead and put the
+        // real ones behind the LayerNorm barrier: one extra memory round trip per LN launch)
+        if (NBUF > 1 && c + NBUF - 1 < KCH) load_chunk(c + NBUF - 1, (c + NBUF - 1) % NBUF);
+        if (!LN) __builtin_amdgcn_sched_barrier(0);   // the next chunks' loads are issued before this chunk's MFMAs
+#pragma unroll
+        for (int b = 0; b < NB; b += (PREC ? 2 : 1)) {
+            if constexpr ((DBG & 4) != 0) {
+#pragma unroll
+                for (int t = 0; t < NTL; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][t] += af[cur][mt][b] * bf[cur][t][b];
+            } else if constexpr (PREC == 0) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][mt][b][s], bf[cur][t][b][s], acc[mt][t], 0, 0, 0);
+            } else {
+                bf16x8 ah[MT], am[MT], al[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) split3_bf16(af[cur][mt][b], af[cur][mt][b + 1], ah[mt], am[mt], al[mt]);
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) {
+                    bf16x8 bh, bm, bl;
+                    split3_bf16(bf[cur][t][b], bf[cur][t][b + 1], bh, bm, bl);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        lo[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, lo[mt][t], 0, 0, 0);
+                        lo[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, lo[mt][t], 0, 0, 0);
+                        lo[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[mt], bm, lo[mt][t], 0, 0, 0);
+                        lo[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bm, lo[mt][t], 0, 0, 0);
+                        lo[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[mt], bh, lo[mt][t], 0, 0, 0);
+                        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt][t], 0, 0, 0);
+                    }
+                }
+            }
+            // keep the blocks in load order: hipcc otherwise hoists the LayerNorm arithmetic of every block in front of the
+            // first MFMA, which then waits for (almost) the whole tile
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if (LN) {   // Chan's combination of the 64 tile partials of a row, fixed order (one DPP wave reduction each)
 #pragma unroll
         for (int u = 0; u < RPW; ++u) {
             const int rr = w + NW * u;
             const float mu = wave_sum_dpp(pt[u].x) * (1.0f / 64.0f);
             const float d = pt[u].x - mu;
             const float m2 = wave_sum_dpp(fmaf(16.0f * d, d, pt[u].y));
-            if (lane == 0) {
+            if (lane == 0 && rr < 16 * MT) {
                 rs[rr][0] = mu;
                 rs[rr][1] = 1.0f / sqrtf(m2 * (1.0f / 1024.0f) + a.eps);
             }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            mean[mt] = rs[16 * mt + j][0];
-            rstd[mt] = rs[16 * mt + j][1];
-        }
-    }
-    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 2] = (long long)wall_clock64();
-    if (NBUF == 3) load_chunk(1, 1);
-#pragma unroll
-    for (int c = 0; c < KCH; ++c) {
-        const int cur = c % NBUF;
-        if (c + NBUF - 1 < KCH) load_chunk(c + NBUF - 1, (c + NBUF - 1) % NBUF);
-        if (!LN) __builtin_amdgcn_sched_barrier(0);   // the next chunks' loads are issued before this chunk's MFMAs
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            if (LN) {   // k = 16*(NB*w + b) + 4q + s; normalised block by block so the MFMAs follow the data as it arrives
-                const f32x4 gam = *reinterpret_cast<const f32x4*>(&gb[0][16 * (NB * w + b) + 4 * q]);
-                const f32x4 bet = *reinterpret_cast<const f32x4*>(&gb[1][16 * (NB * w + b) + 4 * q]);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        af[cur][mt][b][s] = (af[cur][mt][b][s] - mean[mt]) * rstd[mt] * gam[s] + bet[s];
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int t = 0; t < NTL; ++t)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][mt][b][s], bf[cur][t][b][s], acc[mt][t], 0, 0, 0);
         }
     }
     // D layout: row = 4*(lane>>4) + r, col = lane&15
@@ -494,26 +584,25 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[w][(t * MT + mt) * 256 + r * 64 + lane] = acc[mt][t][r];
+            for (int r = 0; r < 4; ++r)
+                red[w][(t * MT + mt) * 256 + r * 64 + lane] = PREC ? acc[mt][t][r] + lo[mt][t][r] : acc[mt][t][r];
     if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 3] = (long long)wall_clock64();
     __syncthreads();
     if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 4] = (long long)wall_clock64();
-    for (int e = tid; e < MT * NTL * 256; e += 64 * NW) {
+    if (tid < NE) {
         float t = red[0][e];
 #pragma unroll
         for (int ww = 1; ww < NW; ++ww) t += red[ww][e];
-        const int ct = (e >> 8) / MT, mt = (e >> 8) - ct * MT, r = (e >> 6) & 3, l = e & 63;
-        const int m = m0 + 16 * mt + 4 * (l >> 4) + r, n = n0 + 16 * ct + (l & 15);
-        const bool ok = m < a.M;
-        if (a.bias) t += a.bias[n];
+        const bool ok = em < a.M;
+        if (LN) t = rs[em - m0][1] * (t - rs[em - m0][0] * ec1);
+        t += ebias;
         if (EPI == kEpiBias) {
-            if (ok) a.out[(long)m * a.ldo + n] = t;
+            if (ok) a.out[(long)em * a.ldo + en] = t;
         } else if (EPI == kEpiBiasGelu) {
-            if (ok) a.out[pk_off(m, n, a.omt)] = gelu_new(t);
+            if (ok) a.out[pk_off(em, en, a.omt)] = a.gelu_erf ? gelu_erf(t) : gelu_new(t);
         } else if (EPI == kEpiResidual) {
-            float* p = a.out + pk_off(m, n, a.omt);   // (rows >= M of the last tile are allocated)
-            const float v = *p + t;
-            if (ok) *p = v;
+            const float v = eres + t;
+            if (ok) *eptr = v;   // (rows >= M of the last tile are allocated)
             if (a.stats_out) {   // LayerNorm partials of this 16-column tile: the 16 lanes of a row are adjacent
                 float sm = v;
                 sm += __shfl_xor(sm, 8, 64);
@@ -527,19 +616,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
                 m2 += __shfl_xor(m2, 4, 64);
                 m2 += __shfl_xor(m2, 2, 64);
                 m2 += __shfl_xor(m2, 1, 64);
-                if (ok && (l & 15) == 0) a.stats_out[(long)m * 64 + ntile * NTL + ct] = make_float2(mu, m2);
+                if (ok && (e & 15) == 0) a.stats_out[(long)em * 64 + ntile * NTL + ect] = make_float2(mu, m2);
             }
         } else if (ok) {
-            const int u = n / kHidden, d = n - u * kHidden;
+            const int u = en / kHidden, d = en - u * kHidden;
             if (u == 0) {
-                a.out[(long)m * kHidden + d] = t;
+                a.out[(long)em * kHidden + d] = t;
             } else {
-                int pos, blk;
-                if (a.row_meta) {
-                    pos = a.row_meta[(long)m * kRowMetaStride];
-                    blk = a.row_meta[(long)m * kRowMetaStride + kRowMetaBt + pos / kKvBlockTokens];
-                } else {
-                    const int slot = a.row_slot[m];
+                int pos = epos, blk = eblk;
+                if (!a.row_meta) {
+                    const int slot = a.row_slot[em];
                     pos = a.slot_kvpos[slot];
                     blk = a.block_tables[(long)slot * a.max_blocks + pos / kKvBlockTokens];
                 }
@@ -552,113 +638,86 @@ __global__ __launch_bounds__(64 * NW) void gemm_rows_kernel(GemmRowsArgs a) {
     if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 5] = (long long)wall_clock64();
 }
 
-// Workgroup shapes in use.  16 waves (K-slice 64 per wave, <= 128 VGPRs per lane) everywhere except the 64-row tiles with
-// the LN prologue: 64 A registers + the statistics spilled there, so those run as 8 waves with K-slices of 128 (<= 256
-// VGPRs).  K = 4096 needs two chunk buffers: at most 32 rows per workgroup.
-template <int KCH, bool LN, int EPI>
+// Workgroup shapes in use (tools/gemm_bench measures every one of them per GEMM kind).  16 waves, K-slice 64 per wave, is the
+// default; 8 waves (K-slices of 128) remain for A/B.  K = 4096 needs two chunk buffers: at most 32 rows per workgroup.
+template <int KCH, bool LN, int EPI, int PREC, int DBG = 0>
 static void launch_gemm_rows_mt(const GemmRowsArgs& a, int mt, int nw, hipStream_t st, int ntl = 1) {
     const int n_tiles = a.N / (16 * ntl);
     const int n_grp = (a.M + 16 * mt - 1) / (16 * mt);
     const dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * n_grp));   // whole groups of 8 column tiles (one per XCD); surplus workgroups exit
-    if constexpr (KCH == 1 && LN) {   // 32-column workgroups exist for the LN-prologue GEMMs (N = 3072 / 4096) at 16 or 32 rows
-        if (ntl == 2) {
-            AUR_REQUIRE(a.N % 32 == 0 && mt <= 2 && nw == 8, "gemm_rows: 32-column workgroups: 16 / 32 rows, 8 waves");
-            if (mt == 2) hipLaunchKernelGGL((gemm_rows_kernel<2, KCH, LN, EPI, 8, 2>), grid, dim3(512), 0, st, a);
-            else hipLaunchKernelGGL((gemm_rows_kernel<1, KCH, LN, EPI, 8, 2>), grid, dim3(512), 0, st, a);
-            return;
+    AUR_REQUIRE(a.N % (16 * ntl) == 0, "gemm_rows: N is not a multiple of the workgroup's column tile");
+#define AUR_GR(MT_, NW_, NTL_)                                                                                     \
+    if (mt == MT_ && nw == NW_ && ntl == NTL_) {                                                                   \
+        hipLaunchKernelGGL((gemm_rows_kernel<MT_, KCH, LN, EPI, NW_, NTL_, PREC, DBG>), grid, dim3(64 * NW_), 0, st, a); \
+        return;                                                                                                    \
+    }
+    AUR_GR(1, 16, 1)
+    AUR_GR(2, 16, 1)
+    if constexpr (KCH == 1) {
+        AUR_GR(4, 16, 1)
+        AUR_GR(1, 16, 2)
+        AUR_GR(1, 16, 3)
+        AUR_GR(1, 16, 4)
+        AUR_GR(2, 16, 2)
+        AUR_GR(1, 8, 1)
+        AUR_GR(2, 8, 1)
+        AUR_GR(1, 8, 2)
+    }
+#undef AUR_GR
+    throw InvalidArgument("gemm_rows: no kernel for this (rows, waves, column tiles) workgroup shape");
+}
+
+// Shape policy.  The waves per workgroup fix the K grouping of the reduction, so they depend on the GEMM kind only (16
+// everywhere), never on M: a row's result must not change with the number of live rows.  Rows x columns per workgroup do not
+// enter the arithmetic.  One workgroup per CU when the launch is large enough for it (256 CUs):
+//   LN GEMMs, N = 3072 (QKV): 16 rows x 48 columns  -> 64 x ceil(M/16) workgroups (256 at M = 64); the CU pulls its 16
+//       activation rows once for three column tiles
+//   LN GEMMs, N = 4096 (FC) : 32 rows x 32 columns  -> 128 x ceil(M/32)
+//   N = 1024 (proj, proj2), head: 16 rows x 16 columns
+// AUR_GEMM_SHAPES=r02 restores the round-2 shapes (16 x 16 / 32 x 16 on 8 waves for the LN GEMMs) for A/B.
+GemmRowsShape gemm_rows_shape(int M, int N, int K, bool ln) {
+    static const bool r02 = [] {
+        const char* e = getenv("AUR_GEMM_SHAPES");
+        return e && e[0] == 'r';
+    }();
+    GemmRowsShape s{1, 16, 1};
+    if (ln) {
+        if (r02) {
+            s.nw = 8;
+            s.mt = (N >= 4096 && M > 16) ? 2 : 1;
+        } else if (N % 48 == 0 && N < 4096) {
+            s.ntl = 3;
+        } else if (N % 32 == 0) {
+            s.ntl = 2;
+            s.mt = M > 16 ? 2 : 1;
         }
     }
-    AUR_REQUIRE(ntl == 1, "gemm_rows: column tiles per workgroup");
-    if constexpr (KCH == 1) {   // (two chunk buffers of a 64-row tile do not fit the 128-VGPR budget: K = 4096 caps at 32 rows)
-        if (mt == 4) {
-            if (nw == 8) hipLaunchKernelGGL((gemm_rows_kernel<4, KCH, LN, EPI, 8>), grid, dim3(512), 0, st, a);
-            else hipLaunchKernelGGL((gemm_rows_kernel<4, KCH, LN, EPI, 16>), grid, dim3(1024), 0, st, a);
-            return;
-        }
-    }
-    AUR_REQUIRE(mt <= 2 || KCH == 1, "gemm_rows: rows per workgroup");
-    if (mt == 2) {
-        AUR_REQUIRE(nw != 4, "gemm_rows: 4-wave workgroups exist for 16-row tiles only");
-        if (nw == 8) hipLaunchKernelGGL((gemm_rows_kernel<2, KCH, LN, EPI, 8>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((gemm_rows_kernel<2, KCH, LN, EPI, 16>), grid, dim3(1024), 0, st, a);
-    } else {
-        if constexpr (KCH == 1) {
-            if (nw == 4) {
-                hipLaunchKernelGGL((gemm_rows_kernel<1, KCH, LN, EPI, 4>), grid, dim3(256), 0, st, a);
-                return;
-            }
-        }
-        AUR_REQUIRE(nw != 4, "gemm_rows: 4-wave workgroups exist for K = 1024 only");
-        if (nw == 8) hipLaunchKernelGGL((gemm_rows_kernel<1, KCH, LN, EPI, 8>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((gemm_rows_kernel<1, KCH, LN, EPI, 16>), grid, dim3(1024), 0, st, a);
-    }
+    (void)K;
+    return s;
+}
+
+template <int PREC>
+static void launch_gemm_rows_prec(const GemmRowsArgs& b, bool ln, GemmRowsEpi epi, const GemmRowsShape& s, hipStream_t st) {
+    if (ln && epi == kEpiQkv) launch_gemm_rows_mt<1, true, kEpiQkv, PREC>(b, s.mt, s.nw, st, s.ntl);
+    else if (ln && epi == kEpiBiasGelu) launch_gemm_rows_mt<1, true, kEpiBiasGelu, PREC>(b, s.mt, s.nw, st, s.ntl);
+    else if (ln && epi == kEpiBias) launch_gemm_rows_mt<1, true, kEpiBias, PREC>(b, s.mt, s.nw, st, s.ntl);
+    else if (!ln && epi == kEpiResidual && b.K == 1024) launch_gemm_rows_mt<1, false, kEpiResidual, PREC>(b, s.mt, s.nw, st, s.ntl);
+    else if (!ln && epi == kEpiResidual && b.K == 4096) launch_gemm_rows_mt<4, false, kEpiResidual, PREC>(b, s.mt, s.nw, st, s.ntl);
+    else if (!ln && epi == kEpiBias && b.K == 1024) launch_gemm_rows_mt<1, false, kEpiBias, PREC>(b, s.mt, s.nw, st, s.ntl);
+    else if (!ln && epi == kEpiBias && b.K == 4096) launch_gemm_rows_mt<4, false, kEpiBias, PREC>(b, s.mt, s.nw, st, s.ntl);
+    else throw InvalidArgument("launch_gemm_rows: unsupported (ln, epilogue, K) combination");
 }
 
 void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream_t st) {
     AUR_REQUIRE(a.N % 16 == 0 && (a.K == 1024 || a.K == 4096) && a.M >= 1 && a.xmt >= 4 * ((a.M + 63) / 64), "gemm_rows: shape");
     AUR_REQUIRE((epi != kEpiBiasGelu && epi != kEpiResidual) || a.omt >= (a.M + 15) / 16, "gemm_rows: packed output rows");
-    AUR_REQUIRE(!ln || (a.K == 1024 && a.stats_in), "gemm_rows: LN prologue needs K == 1024 and the row statistics");
+    AUR_REQUIRE(!ln || (a.K == 1024 && a.stats_in && a.ln_c1 && a.bias), "gemm_rows: a LayerNorm-folded GEMM needs K == 1024, the row statistics, c1 and c2");
     AUR_REQUIRE(!a.stats_out || (epi == kEpiResidual && a.N == 1024), "gemm_rows: statistics are emitted for 1024-wide residual rows");
-    // rows per workgroup: the largest of 64 / 32 / 16 that still yields >= 192 workgroups (the chip has 256 CUs and a
-    // workgroup fills one), so N = 1024 GEMMs split the rows and re-read the column tile's weights from L2
-    static const int mt_env = [] {
-        const char* e = getenv("AUR_GEMM_ROWS_MT");
-        return e ? atoi(e) : 0;
-    }();
-    // waves per workgroup fix the K grouping of the reduction, so they depend on the GEMM kind only, never on M (a row's
-    // result must not change with the number of live rows): LN-prologue GEMMs 8 waves, the others 16
-    static const int nw_plain = [] {
-        const char* e = getenv("AUR_GEMM_ROWS_NW");
-        return (e && atoi(e) == 8) ? 8 : 16;
-    }();
-    static const int nw_ln = [] {
-        const char* e = getenv("AUR_GEMM_ROWS_NW_LN");
-        return (e && atoi(e) == 16) ? 16 : 8;
-    }();
-    const int nw = ln ? nw_ln : nw_plain;
-    int mt = 4;
-    while (mt > 1 && ((a.M + 16 * mt - 1) / (16 * mt)) * (a.N / 16) < 192 && a.M > 16 * (mt / 2)) mt >>= 1;
-    // LN-prologue GEMMs (tools/gemm_bench, M = 64, MI355X): 16-row workgroups for N = 3072 (11.8 us vs 14.6 at 64 rows: the
-    // activation tile per workgroup shrinks 4x and L1 fill, ~40 B/clk/CU, is what bounds these kernels), 32 rows for N = 4096
-    // ... and 16 rows x 32 columns per workgroup for N = 4096 (11.7 us vs 12.7 for 32 x 16 and 13.8 for 64 x 16)
-    static const int ntl_env = [] {
-        const char* e = getenv("AUR_GEMM_ROWS_NTL");
-        return e ? atoi(e) : 0;
-    }();
-    // N = 4096 (FC): 32 rows x 16 columns per workgroup (512 workgroups).  tools/gemm_bench, two runs at the end of round 2:
-    // 11.9-12.0 us against 13.3 us for 16 rows x 32 columns and 12.1-12.3 us for 16 x 16; AUR_GEMM_FC_TILE=1x2 restores 16 x 32
-    static const bool fc_1x2 = [] {
-        const char* e = getenv("AUR_GEMM_FC_TILE");
-        return e && e[0] == '1';
-    }();
-    int ntl = 1;
-    if (ln) {
-        mt = 1;
-        if (a.N >= 4096 && nw == 8) {
-            if (fc_1x2) ntl = 2;
-            else mt = 2;
-        }
-        if (ntl_env == 1 || (ntl_env == 2 && nw == 8 && a.N % 32 == 0)) ntl = ntl_env;
-    }
-    while (mt > 1 && a.M <= 16 * (mt / 2)) mt >>= 1;
-    if (mt_env == 1 || mt_env == 2 || mt_env == 4) mt = mt_env;
-    if (ntl == 2 && mt > 2) mt = 2;
-    if (a.K == 4096 && mt > 2) mt = 2;
-    static const int nt_env = [] {
-        const char* e = getenv("AUR_GEMM_NT");
-        return e ? atoi(e) : 0;
-    }();
-    GemmRowsArgs b = a;
-    if (nt_env && (b.M + 16 * mt - 1) / (16 * mt) == 1) b.nt_w = 1;
+    const GemmRowsShape s = gemm_rows_shape(a.M, a.N, a.K, ln);
     trace_launch("gemm_rows_kernel");
-    if (ln && epi == kEpiQkv) launch_gemm_rows_mt<1, true, kEpiQkv>(b, mt, nw, st, ntl);
-    else if (ln && epi == kEpiBiasGelu) launch_gemm_rows_mt<1, true, kEpiBiasGelu>(b, mt, nw, st, ntl);
-    else if (ln && epi == kEpiBias) launch_gemm_rows_mt<1, true, kEpiBias>(b, mt, nw, st, ntl);
-    else if (!ln && epi == kEpiResidual && a.K == 1024) launch_gemm_rows_mt<1, false, kEpiResidual>(b, mt, nw, st);
-    else if (!ln && epi == kEpiResidual && a.K == 4096) launch_gemm_rows_mt<4, false, kEpiResidual>(b, mt, nw, st);
-    else if (!ln && epi == kEpiBias && a.K == 1024) launch_gemm_rows_mt<1, false, kEpiBias>(b, mt, nw, st);
-    else if (!ln && epi == kEpiBias && a.K == 4096) launch_gemm_rows_mt<4, false, kEpiBias>(b, mt, nw, st);
-    else throw InvalidArgument("launch_gemm_rows: unsupported (ln, epilogue, K) combination");
+    AUR_REQUIRE(a.prec == 0 || a.prec == 1, "gemm_rows: prec is 0 (exact f32 MFMA) or 1 (bf16 x 3 split)");
+    if (a.prec == 1) launch_gemm_rows_prec<1>(a, ln, epi, s, st);
+    else launch_gemm_rows_prec<0>(a, ln, epi, s, st);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1046,8 +1105,10 @@ __global__ __launch_bounds__(256) void embed_decode_kernel(const int* __restrict
     if (row_meta) {   // the step's K/V addressing of this row, dense (kRowMetaStride ints)
         int* rm = row_meta + (long)m * kRowMetaStride;
         if (threadIdx.x == 0) {
-            rm[0] = slot_kvpos[slot];
+            const int pos = slot_kvpos[slot];
+            rm[0] = pos;
             rm[1] = slot;
+            rm[kRowMetaWblk] = block_tables[(long)slot * max_blocks + pos / kKvBlockTokens];
         }
         if ((int)threadIdx.x < max_blocks) rm[kRowMetaBt + threadIdx.x] = block_tables[(long)slot * max_blocks + threadIdx.x];
     }

@@ -86,34 +86,50 @@ def cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, n_tokens: int = 280
     }
 
 
-GEMM_KINDS = ["qkv (LN1 prologue, KV page write) [64x1024]x[1024x3072]", "attn proj (+residual) [64x1024]x[1024x1024]",
-              "fc (LN2 prologue, gelu) [64x1024]x[1024x4096]", "mlp proj (+residual) [64x4096]x[4096x1024]",
+GEMM_KINDS = ["qkv (LayerNorm folded, KV page write) [64x1024]x[1024x3072]", "attn proj (+residual) [64x1024]x[1024x1024]",
+              "fc (LayerNorm folded, gelu) [64x1024]x[1024x4096]", "mlp proj (+residual) [64x4096]x[4096x1024]",
               "mel head [64x1024]x[1024x1088]"]
-GEMM_KERNEL_RE = ["gemm_rows_kernel<.*true, 3", "gemm_rows_kernel<1, 1, false, 2", "gemm_rows_kernel<.*true, 1",
-                  "gemm_rows_kernel<1, 4, false, 2", "gemm_rows_kernel<1, 1, false, 0"]
+# gemm_rows_kernel<MT, KCH, LN, EPI, NW, NTL, PREC, DBG>: (LN, EPI) and KCH identify the GEMM kind in a kernel trace
+GEMM_KERNEL_RE = [r"gemm_rows_kernel<\d+, 1, true, 3,", r"gemm_rows_kernel<\d+, 1, false, 2,", r"gemm_rows_kernel<\d+, 1, true, 1,",
+                  r"gemm_rows_kernel<\d+, 4, false, 2,", r"gemm_rows_kernel<\d+, 1, false, 0,"]
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA
+MATMUL_PARAMS_PER_LAYER = 12_582_912   # c_attn + c_proj + c_fc + mlp.c_proj
 
 
-def _rocprof_avgs():
-    """Average kernel durations (us) of the committed rocprofv3 --kernel-trace --stats summary of this command."""
+def _rocprof_table():
+    """The committed rocprofv3 --kernel-trace --stats summary of this command (latest profiles/r*_bench_kernel_stats.csv):
+    {kernel name: (calls, average us)}."""
     import csv
     import glob
-    import re
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_bench_kernel_stats.csv")))
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]*_bench_kernel_stats.csv")))
     if not paths:
         return None, {}
     rows = {}
     with open(paths[-1]) as f:
         for r in csv.DictReader(f):
             rows[r["Name"]] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)
+    return os.path.relpath(paths[-1], ROOT), rows
 
-    def avg(pattern):
-        n = t = 0.0
-        for name, (calls, us) in rows.items():
-            if re.search(pattern, name):
-                n += calls
-                t += calls * us
-        return (t / n) if n else None
-    return os.path.relpath(paths[-1], ROOT), {"avg": avg}
+
+def _rocprof_avg(rows, pattern):
+    import re
+    n = t = 0.0
+    for name, (calls, us) in rows.items():
+        if re.search(pattern, name):
+            n += calls
+            t += calls * us
+    return (t / n) if n else None
+
+
+def _rocprof_by_function(rows):
+    """GPU time per __global__ function: kernel names summed by the part before '<' (all template instantiations together)."""
+    fam = {}
+    for name, (calls, us) in rows.items():
+        key = name.split("<")[0].split("(")[0].strip()
+        c, t = fam.get(key, (0, 0.0))
+        fam[key] = (c + calls, t + calls * us)
+    tot = sum(t for _, t in fam.values()) or 1.0
+    return {k: {"calls": c, "total_ms": t / 1e3, "share": t / tot} for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])}
 
 
 def _traffic():
@@ -124,10 +140,12 @@ def _traffic():
 
 
 def build_report(args, st, dims, world, samples, dt, audio_s):
-    prof_path, prof = _rocprof_avgs()
+    prof_path, prof_rows = _rocprof_table()
     tj = _traffic()
-    pmc = tj.get("r02_decode", {})
-    avg = prof.get("avg", lambda _p: None)
+    pmc = tj.get("r03_decode", {})
+    gemm_peak = FP32_MFMA_PEAK_TFLOPS if args.gemm == "f32" else BF16_MFMA_PEAK_TFLOPS / 6.0
+    gemm_arith = ("exact-f32 MFMA (v_mfma_f32_16x16x4_f32)" if args.gemm == "f32" else
+                  "fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate (peak = dense bf16 / 6)")
 
     def roof(kernel, ms, n, nbytes, flops, mfma_peak, rocprof_re, pmc_key, note):
         ms_l = ms / max(1, n)
@@ -139,13 +157,18 @@ def build_report(args, st, dims, world, samples, dt, audio_s):
         if pm:   # PMC FETCH_SIZE (x2) + WRITE_SIZE of the committed rocprofv3 --pmc passes of this command (profiles/hbm_traffic.json);
             # the ratio to that run's algorithmic bytes carries over to this run's launch size (attention grows with the context)
             r["traffic"] = pm["ratio_to_algorithmic"] * nbytes / max(1, n)
-            r["traffic_source"] = {"file": "profiles/hbm_traffic.json[r02_decode]", "measured_bytes_per_launch": pm["bytes_per_launch"],
+            r["traffic_source"] = {"file": "profiles/hbm_traffic.json[r03_decode]", "measured_bytes_per_launch": pm["bytes_per_launch"],
                                    "algorithmic_bytes_per_launch_in_that_run": pm["algorithmic_bytes_per_launch_in_that_run"],
                                    "ratio": pm["ratio_to_algorithmic"]}
         if flops:
             tf = (flops / max(1, n)) / (ms_l * 1e-3) / 1e12 if ms_l > 0 else 0.0
             r["mfma"] = {"achieved": tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tf / mfma_peak}
-        us = avg(rocprof_re) if rocprof_re else None
+            # which roof binds this launch: time at the HBM peak for its bytes vs time at the matrix-pipe peak for its flops
+            t_hbm = (nbytes / max(1, n)) / (HBM_PEAK_GBPS * 1e9)
+            t_mfma = (flops / max(1, n)) / (mfma_peak * 1e12)
+            r["binding_roof"] = {"name": "hbm" if t_hbm >= t_mfma else "mfma", "floor_us_hbm": t_hbm * 1e6, "floor_us_mfma": t_mfma * 1e6,
+                                 "frac_of_binding_floor": max(t_hbm, t_mfma) / (ms_l * 1e-3) if ms_l > 0 else 0.0}
+        us = _rocprof_avg(prof_rows, rocprof_re) if rocprof_re else None
         if us:
             g2 = (nbytes / max(1, n)) / (us * 1e-6) / 1e9
             r["rocprof"] = {"avg_launch_us": us, "achieved": g2, "frac": g2 / HBM_PEAK_GBPS, "source": prof_path}
@@ -153,33 +176,58 @@ def build_report(args, st, dims, world, samples, dt, audio_s):
 
     conv_kernel = "conv1d_mfma_f16_kernel" if args.vocoder == "fp16" else "conv1d_mfma_kernel"
     # SURVEY 8(d) counts the vocoder's layer-granular activation traffic in fp32 (21 301 B per output sample); conv_bytes is the
-    # same accounting in the dtype each tensor is really stored in (the ResBlock intermediate is fp16)
+    # same accounting in the dtype each tensor is really stored in
     roof_conv = roof(f"{conv_kernel} (HiFi-GAN convs, all instantiations)", st["conv_ms"], st["conv_launches"], st["conv_bytes"],
-                     st["conv_flops"], FP32_MFMA_PEAK_TFLOPS if args.vocoder == "fp32" else 2500.0, conv_kernel, None,
-                     "bytes counted as stored (fp32 activations, fp16 ResBlock intermediate)")
-    roof_conv["traffic"] = tj.get(f"conv_{args.vocoder}_bytes_per_launch")
+                     st["conv_flops"], FP32_MFMA_PEAK_TFLOPS if args.vocoder == "fp32" else BF16_MFMA_PEAK_TFLOPS, conv_kernel, None,
+                     "bytes counted as stored")
+    conv_pmc = tj.get("r03_conv", {}).get(f"conv_{args.vocoder}")
+    if conv_pmc:   # PMC passes of the CURRENT layouts (profiles/hbm_traffic.json["r03_conv"]); absent = not measured this round
+        roof_conv["traffic"] = conv_pmc["bytes_per_launch"]
+        roof_conv["traffic_source"] = {"file": "profiles/hbm_traffic.json[r03_conv]", **conv_pmc}
     if st["conv_ms"] > 0:
         g = 21301.0 * samples / world / (st["conv_ms"] * 1e-3) / 1e9
         roof_conv["survey_8d_fp32_bytes"] = {"bytes_per_sample": 21301, "achieved": g, "frac": g / HBM_PEAK_GBPS}
-    roof_attn = roof("paged_attention_kernel<false, KVH, ..> (decode: one query row per sequence against its paged K/V)",
-                     st["attn_ms"], st["attn_launches"], st["attn_bytes"], 0.0, 1.0, r"paged_attention_kernel<false, (false|true), ", "attention",
+    roof_attn = roof("paged_attention_kernel (decode: one query row per sequence against its paged K/V)",
+                     st["attn_ms"], st["attn_launches"], st["attn_bytes"], 0.0, 1.0, r"paged_attention_kernel<", "attention",
                      "algorithmic bytes = K and V rows of every live sequence's context (8 KiB per token per layer) + q + out")
     gemms = []
     for k in range(5):
         gemms.append(roof("gemm_rows_kernel: " + GEMM_KINDS[k], st["gemm_kind_ms"][k], st["gemm_kind_launches"][k],
-                          st["gemm_kind_bytes"][k], st["gemm_kind_flops"][k], FP32_MFMA_PEAK_TFLOPS, GEMM_KERNEL_RE[k],
+                          st["gemm_kind_bytes"][k], st["gemm_kind_flops"][k], gemm_peak, GEMM_KERNEL_RE[k],
                           ["gemm_qkv", "gemm_proj", "gemm_fc", "gemm_proj2", "gemm_head"][k],
-                          "algorithmic bytes = weights + activation rows in + rows out (fp32 as stored); exact-f32 MFMA"))
-    roof_gemm_all = roof("gemm_rows_kernel (all five decode GEMMs together)", st["gemm_ms_raw"], st["gemm_launches"], st["gemm_bytes"],
-                         st["gemm_flops"], FP32_MFMA_PEAK_TFLOPS, None, None, "family aggregate of the entries in decode_gemm_kernels")
-    # which single kernel has the most GPU time in the timed region?  (sampled per-launch averages x launches per step)
+                          "algorithmic bytes = weights + activation rows in + rows out (fp32 as stored); " + gemm_arith))
+    roof_gemm = roof("gemm_rows_kernel (decode-regime GEMMs: qkv, attn proj, fc, mlp proj, mel head — every template instantiation)",
+                     st["gemm_ms_raw"], st["gemm_launches"], st["gemm_bytes"], st["gemm_flops"], gemm_peak, r"gemm_rows_kernel<", None,
+                     "per-launch average over the five GEMM kinds weighted by their launch counts; per-kind entries in "
+                     "decode_gemm_kernels; HIP-event durations (fixed cost of an event pair NOT subtracted here)")
     n_dec = max(1, st["decode_steps"])
-    est = {"attn": roof_attn["avg_launch_ms"] * args.layers * n_dec, "conv": st["conv_ms"]}
-    for k in range(4):
-        est[f"gemm{k}"] = gemms[k]["avg_launch_ms"] * args.layers * n_dec
-    top = max(est, key=est.get)
-    dominant = roof_attn if top == "attn" else roof_conv if top == "conv" else gemms[int(top[4:])]
-    dominant = dict(dominant, est_total_ms_in_timed_region=est[top], est_total_ms_of_candidates=est)
+    per_layer = sum(g["avg_launch_ms"] for g in gemms[:4]) * 1e3
+    roof_gemm["four_gemms_per_layer_us"] = {"events": per_layer,
+                                            "rocprof": (sum((_rocprof_avg(prof_rows, GEMM_KERNEL_RE[k]) or 0.0) for k in range(4)) or None)}
+    # which __global__ function has the most GPU time in the timed region?  sampled per-launch averages x launches per step
+    est = {"paged_attention_kernel": roof_attn["avg_launch_ms"] * args.layers * n_dec,
+           conv_kernel: st["conv_ms"],
+           "gemm_rows_kernel": (per_layer * 1e-3 * args.layers + gemms[4]["avg_launch_ms"]) * n_dec,
+           "gemm_tile_kernel (prefill, upper bound: whole prefill phase)": st["prefill_ms"]}
+    by_family = {"paged_attention_kernel": roof_attn, conv_kernel: roof_conv, "gemm_rows_kernel": roof_gemm}
+    order = sorted(by_family, key=lambda k: -est[k])
+    top = order[0]
+    dominant = dict(by_family[top], est_total_ms_in_timed_region=est[top], est_total_ms_of_candidates=est,
+                    rocprof_time_by_function=_rocprof_by_function(prof_rows) if prof_rows else None)
+    second = by_family[order[1]]
+    # prefill against the exact-f32 MFMA peak (north_star: ">= 40 % MFMA util on GPT prefill"): matmul flops of the prompt rows over
+    # the event-timed prefill phases (which also hold the prompt attention, LayerNorm and embedding launches: a lower bound)
+    prefill = None
+    if st["prefill_ms"] > 0:
+        fl = 2.0 * MATMUL_PARAMS_PER_LAYER * args.layers * st["prefill_rows"]
+        tf = fl / (st["prefill_ms"] * 1e-3) / 1e12
+        prefill = {"kernel": "gemm_tile_kernel (prompt rows, exact-f32 MFMA)", "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS,
+                   "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS, "prefill_rows": st["prefill_rows"], "prefill_ms": st["prefill_ms"],
+                   "note": "matmul flops of the prompt rows (2 x 12 582 912 x layers per row; speaker-prefix rows are shared and "
+                           "not recomputed) over the whole prefill phase"}
+        us = _rocprof_avg(prof_rows, r"gemm_tile_kernel<128, 128")
+        if us:
+            prefill["rocprof_fc_launch"] = {"avg_launch_us": us, "source": prof_path}
     # whole decode step against the HBM roofline: weights once per step + K/V of every live context
     dstep = None
     if st["decode_steps"]:
@@ -189,13 +237,15 @@ def build_report(args, st, dims, world, samples, dt, audio_s):
                  "fp32_as_stored": {"bytes_per_step": b32, "achieved_GBps": b32 / ms / 1e6, "frac": b32 / ms / 1e6 / HBM_PEAK_GBPS},
                  "survey_8d_fp16": {"bytes_per_step": b32 / 2, "achieved_GBps": b32 / 2 / ms / 1e6,
                                     "frac": b32 / 2 / ms / 1e6 / HBM_PEAK_GBPS},
-                 "note": "fp32 weights and K/V are what this engine stores and streams (exact-f32 parity mode); SURVEY 8(d) quotes the "
-                         "reference GPU path's fp16 storage, i.e. half the bytes for the same step"}
+                 "note": "fp32 weights and K/V are what this engine stores and streams; SURVEY 8(d) quotes the reference GPU path's "
+                         "fp16 storage, i.e. half the bytes for the same step"}
     return {
         "metric": "audio_samples_per_s (64-way batch; rtf = wall_s / audio_s alongside)",
         "value": samples / dt, "unit": "audio-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32" if args.vocoder == "fp32" else "f32 (GPT) + f16-in/f32-acc MFMA (vocoder convs)")
+        "dtype": ("f32 (GPT: storage, softmax, LayerNorm, sampler; decode GEMMs "
+                  + ("on exact-f32 MFMA" if args.gemm == "f32" else "as exact 3-way bf16 splits of the f32 operands, f32 accumulate") + ")")
+                 + ("" if args.vocoder == "fp32" else " + f16-in/f32-acc MFMA (vocoder convs)")
                  + (" + f16 K/V pool (throughput mode, not the parity configuration)" if args.kv == "fp16" else ""), "data": "synthetic",
         "rtf": dt / audio_s, "audio_sec_per_wall_sec": audio_s / dt,
         "config": {"workload": f"{args.batch} concurrent 200-char utterances per GPU (70 text tokens -> "
@@ -204,12 +254,14 @@ def build_report(args, st, dims, world, samples, dt, audio_s):
                                f"continuous batching; BASELINE.json configs[2]"
                                + ("; consecutive steps pipelined (vocoder of batch k overlaps GPT of batch k+1)" if args.pipeline else ""),
                    "utterances_per_gpu": args.batch, "mel_tokens": args.tokens, "gpt_layers": args.layers,
-                   "vocoder_mfma_inputs": args.vocoder, "kv_cache": args.kv,
+                   "vocoder_mfma_inputs": args.vocoder, "kv_cache": args.kv, "decode_gemm_arithmetic": args.gemm,
                    "parallelism": f"dp{world} (independent utterances, 1 RCCL broadcast of conditioning)"},
         "roofline": dominant,
-        "roofline_second_kernel": roof_conv,
+        "roofline_second_kernel": second,
+        "roofline_vocoder": roof_conv,
+        "prefill_roofline": prefill,
         "decode_gemm_kernels": gemms,
-        "decode_gemm_family": roof_gemm_all,
+        "decode_gemm_family": roof_gemm,
         "decode_attention": roof_attn,
         "decode_step_roofline": dstep,
         "event_pair_overhead_ms": st["event_pair_overhead_ms"],
@@ -242,6 +294,10 @@ def main():
     ap.add_argument("--kv", choices=["fp32", "fp16"], default="fp32",
                     help="paged K/V pool dtype: fp32 = the bit-exact parity mode (default, the reported metric); fp16 = opt-in "
                          "throughput mode (aur_config.kv_fp16), half the attention bytes, ids may differ after a near-tie")
+    ap.add_argument("--gemm", choices=["bf16x3", "f32"], default="bf16x3",
+                    help="arithmetic of the decode-regime GEMMs: bf16x3 = exact 3-way bf16 split of the fp32 operands, 6 bf16 MFMAs per "
+                         "product, fp32 accumulate (default, the configuration the parity tests run); f32 = v_mfma_f32_16x16x4_f32 "
+                         "(aur_config.gemm_f32_exact)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the extra fp16-K/V measurement after the timed run")
     ap.add_argument("--pipeline", action="store_true",
@@ -284,7 +340,7 @@ def main():
     xtts_sd = make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd)
     eng = NativeEngine(n_layer=args.layers, max_seqs=args.batch, device=local_rank, profile=True,
                        vocoder_fp16=(args.vocoder == "fp16"), return_latents=False,   # audio + tokens, as TTSOutput
-                       kv_fp16=(args.kv == "fp16"))
+                       kv_fp16=(args.kv == "fp16"), gemm_f32_exact=(args.gemm == "f32"))
     packed = pack_all(gpt_sd, xtts_sd)
     eng.load_weights(packed)
     _log("weights resident")
@@ -381,7 +437,8 @@ def main():
     if world == 1 and args.kv == "fp32" and not args.no_throughput_mode:
         eng.close()
         eng = NativeEngine(n_layer=args.layers, max_seqs=args.batch, device=local_rank, profile=False,
-                           vocoder_fp16=(args.vocoder == "fp16"), return_latents=False, kv_fp16=True)
+                           vocoder_fp16=(args.vocoder == "fp16"), return_latents=False, kv_fp16=True,
+                           gemm_f32_exact=(args.gemm == "f32"))
         eng.load_weights(packed)
         eng.set_conditioning(SPK, cond.numpy(), spk.numpy())
         run_steps(-1, 1)

@@ -51,6 +51,10 @@ typedef struct aur_config {
                                  and P.V stay fp32), which halves the bytes the decode attention streams.  NOT the parity mode:
                                  greedy ids can differ from the fp32 reference after a near-tie (measured rate: DESIGN.md §4).
                                  0 (default) = fp32 K/V, bit-exact contract */
+    int32_t gemm_f32_exact;   /* decode-regime GEMMs (one token per live sequence): 0 (default) = every fp32 operand is split exactly
+                                 into three bf16 terms and a product runs as six bf16 MFMAs with fp32 accumulation (the accuracy of
+                                 an fp32 dot product at 2.7x less matrix-pipe time); 1 = v_mfma_f32_16x16x4_f32, bitwise an fp32
+                                 fma chain.  Prompt rows always run on exact-f32 MFMA */
 } aur_config;
 
 /* One named fp32 tensor.  Names are the packed names produced by auralis_amd/weights.py from the

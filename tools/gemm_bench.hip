@@ -1,7 +1,9 @@
-// Standalone micro-benchmark of the decode-regime GEMM kernels (no Python, no engine): per-launch time of every
-// workgroup shape back to back on one stream, in-kernel phase stamps (s_memtime), shader-clock calibration, and a
-// 5-launch layer chain.  Build + run on the GPU box:  bash tools/gemm_bench.sh
+// Standalone micro-benchmark of the decode-regime GEMM kernels (no Python, no engine): per-launch time of workgroup shapes
+// and arithmetic modes back to back on one stream, in-kernel phase stamps, a correctness check of every variant against the
+// exact-f32 16 x 16 workgroup result, and the decode layer chain (QKV GEMM, attention, proj, FC, proj2 over 30 layers of
+// distinct weights and K/V) in both arithmetic modes.  Build + run:  bash tools/gemm_bench.sh
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -23,28 +25,14 @@ static float* dalloc(size_t n, float scale, unsigned seed) {
     return d;
 }
 
-__global__ void clock_kernel(long long* out, int spin) {
-    const long long c0 = __builtin_amdgcn_s_memtime();
-    const long long w0 = wall_clock64();
-    float x = (float)threadIdx.x;
-    for (int i = 0; i < spin; ++i) x = fmaf(x, 1.000001f, 0.5f);
-    const long long c1 = __builtin_amdgcn_s_memtime();
-    const long long w1 = wall_clock64();
-    if (threadIdx.x == 0) {
-        out[0] = c1 - c0;
-        out[1] = w1 - w0;
-        out[2] = (long long)x;
-    }
-}
-__global__ void empty_kernel(float* p) {
-    if (p == nullptr && threadIdx.x == 9999) p[0] = 1.f;
-}
-
 struct Shape {
     const char* name;
     int N, K;
     bool ln;
     GemmRowsEpi epi;
+};
+struct Cfg {
+    int mt, nw, ntl, prec;
 };
 
 template <class F>
@@ -65,45 +53,42 @@ static float time_us(hipStream_t st, int iters, F&& f) {
     return ms * 1000.f / iters;
 }
 
-static void launch_variant(const GemmRowsArgs& a, const Shape& s, int mt, int nw, hipStream_t st, int ntl = 1) {
-    if (s.ln && s.epi == kEpiQkv) launch_gemm_rows_mt<1, true, kEpiQkv>(a, mt, nw, st, ntl);
-    else if (s.ln && s.epi == kEpiBiasGelu) launch_gemm_rows_mt<1, true, kEpiBiasGelu>(a, mt, nw, st, ntl);
-    else if (s.ln && s.epi == kEpiBias) launch_gemm_rows_mt<1, true, kEpiBias>(a, mt, nw, st, ntl);
-    else if (s.K == 1024 && s.epi == kEpiResidual) launch_gemm_rows_mt<1, false, kEpiResidual>(a, mt, nw, st);
-    else if (s.K == 4096 && s.epi == kEpiResidual) launch_gemm_rows_mt<4, false, kEpiResidual>(a, mt, nw, st);
-    else if (s.K == 1024 && s.epi == kEpiBias) launch_gemm_rows_mt<1, false, kEpiBias>(a, mt, nw, st);
-    else launch_gemm_rows_mt<4, false, kEpiBias>(a, mt, nw, st);
+template <int PREC>
+static void launch_variant_p(const GemmRowsArgs& a, const Shape& s, const Cfg& c, hipStream_t st) {
+    if (s.ln && s.epi == kEpiQkv) launch_gemm_rows_mt<1, true, kEpiQkv, PREC>(a, c.mt, c.nw, st, c.ntl);
+    else if (s.ln && s.epi == kEpiBiasGelu) launch_gemm_rows_mt<1, true, kEpiBiasGelu, PREC>(a, c.mt, c.nw, st, c.ntl);
+    else if (s.ln && s.epi == kEpiBias) launch_gemm_rows_mt<1, true, kEpiBias, PREC>(a, c.mt, c.nw, st, c.ntl);
+    else if (s.K == 1024 && s.epi == kEpiResidual) launch_gemm_rows_mt<1, false, kEpiResidual, PREC>(a, c.mt, c.nw, st, c.ntl);
+    else if (s.K == 4096 && s.epi == kEpiResidual) launch_gemm_rows_mt<4, false, kEpiResidual, PREC>(a, c.mt, c.nw, st, c.ntl);
+    else if (s.K == 1024 && s.epi == kEpiBias) launch_gemm_rows_mt<1, false, kEpiBias, PREC>(a, c.mt, c.nw, st, c.ntl);
+    else launch_gemm_rows_mt<4, false, kEpiBias, PREC>(a, c.mt, c.nw, st, c.ntl);
     HIP_CHECK(hipGetLastError());
+}
+static void launch_variant(const GemmRowsArgs& a, const Shape& s, const Cfg& c, hipStream_t st) {
+    if (c.prec) launch_variant_p<1>(a, s, c, st);
+    else launch_variant_p<0>(a, s, c, st);
 }
 
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 64;
+    const bool quick = argc > 2 && atoi(argv[2]) == 1;   // 1: chains only
     HIP_CHECK(hipSetDevice(0));
     hipStream_t st;
     HIP_CHECK(hipStreamCreate(&st));
-    // ---- clock calibration: shader cycles per wall-clock tick (100 MHz) while idle / right after a burst
-    long long* dclk;
-    HIP_CHECK(hipMalloc(&dclk, 64));
-    for (int rep = 0; rep < 3; ++rep) {
-        hipLaunchKernelGGL(clock_kernel, dim3(1), dim3(64), 0, st, dclk, 200000);
-        long long h[3];
-        HIP_CHECK(hipMemcpyAsync(h, dclk, 24, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        printf("clock: %lld shader cycles in %lld wall ticks (100 MHz) -> %.0f MHz\n", h[0], h[1], 100.0 * h[0] / h[1]);
-    }
-    const float e256 = time_us(st, 500, [&] { hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(1024), 0, st, (float*)dclk); });
-    printf("empty kernel, 256 x 1024 threads, back to back: %.2f us per launch\n", e256);
-
-    // ---- buffers
-    const int H = 1024;
+    const int H = 1024, MTT = 16;
     float* X = dalloc((size_t)256 * 4096, 1.0f, 1);
     float* hres = dalloc((size_t)256 * 4096, 1.0f, 2);
+    float* hres0 = dalloc((size_t)256 * 4096, 1.0f, 2);
     float* out = dalloc((size_t)256 * 4096, 0.f, 3);
     float* bias = dalloc(4096, 0.1f, 4);
     float* gamma = dalloc(4096, 1.0f, 5);
     float* beta = dalloc(4096, 0.1f, 6);
-    float* kv = dalloc((size_t)(64 * 66 + 8) * kKvBlockElems, 0.f, 7);
-    std::vector<int> hslot(256), hpos(256, 100), hbt(256 * 66);
+    const int n_layers = 30;
+    const long kv_blocks = 64 * 66 + 8;
+    float* kv = nullptr;   // one K/V pool per layer: attention streams 127 MB per launch from HBM, as in the engine
+    HIP_CHECK(hipMalloc(&kv, (size_t)n_layers * kv_blocks * kKvBlockElems * 4));
+    HIP_CHECK(hipMemset(kv, 0, (size_t)n_layers * kv_blocks * kKvBlockElems * 4));
+    std::vector<int> hslot(256), hpos(256, 243), hbt(256 * 66);
     for (int i = 0; i < 256; ++i) hslot[i] = i % 64;
     for (int i = 0; i < 64 * 66; ++i) hbt[i] = i;
     int *dslot, *dpos, *dbt;
@@ -113,22 +98,37 @@ int main(int argc, char** argv) {
     HIP_CHECK(hipMemcpy(dslot, hslot.data(), 256 * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dpos, hpos.data(), 256 * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dbt, hbt.data(), 64 * 66 * 4, hipMemcpyHostToDevice));
+    // dense per-row K/V addressing as embed_decode_kernel writes it once per step
+    int* drm;
+    {
+        std::vector<int> hrm((size_t)256 * kRowMetaStride, 0);
+        for (int i = 0; i < 256; ++i) {
+            int* rm = &hrm[(size_t)i * kRowMetaStride];
+            const int slot = hslot[i], pos = hpos[i];
+            rm[0] = pos;
+            rm[1] = slot;
+            rm[kRowMetaWblk] = hbt[slot * 66 + pos / kKvBlockTokens];
+            for (int j = 0; j < 66; ++j) rm[kRowMetaBt + j] = hbt[slot * 66 + j];
+        }
+        HIP_CHECK(hipMalloc(&drm, hrm.size() * 4));
+        HIP_CHECK(hipMemcpy(drm, hrm.data(), hrm.size() * 4, hipMemcpyHostToDevice));
+    }
     float2* dstats;
     HIP_CHECK(hipMalloc(&dstats, 256 * 64 * sizeof(float2)));
-    HIP_CHECK(hipMemset(dstats, 0, 256 * 64 * sizeof(float2)));
+    {   // plausible LayerNorm partials (mean 0, M2 = 16/3 per 16-column tile of uniform(-1, 1) data)
+        std::vector<float2> hs(256 * 64, make_float2(0.f, 16.f / 3.f));
+        HIP_CHECK(hipMemcpy(dstats, hs.data(), hs.size() * sizeof(float2), hipMemcpyHostToDevice));
+    }
     long long* dprof;
     HIP_CHECK(hipMalloc(&dprof, 4096 * 8 * 8));
 
-    const Shape shapes[] = {{"qkv  N=3072 K=1024 LN  kv-write", 3072, 1024, true, kEpiQkv},
-                            {"proj N=1024 K=1024     residual", 1024, 1024, false, kEpiResidual},
-                            {"fc   N=4096 K=1024 LN  gelu    ", 4096, 1024, true, kEpiBiasGelu},
-                            {"prj2 N=1024 K=4096     residual", 1024, 4096, false, kEpiResidual},
-                            {"head N=1088 K=1024     bias    ", 1088, 1024, false, kEpiBias},
-                            {"qkv' N=3072 K=1024 noLN bias   ", 3072, 1024, false, kEpiBias},
-                            {"fc'  N=4096 K=1024 noLN bias   ", 4096, 1024, false, kEpiBias}};
-    // 30 distinct weight matrices per shape so that the stream really comes from HBM (a single 12-16 MB matrix would sit
-    // in the 256 MiB Infinity Cache across iterations)
-    const int NREP = 24;
+    const Shape shapes[] = {{"qkv ", 3072, 1024, true, kEpiQkv},
+                            {"proj", 1024, 1024, false, kEpiResidual},
+                            {"fc  ", 4096, 1024, true, kEpiBiasGelu},
+                            {"prj2", 1024, 4096, false, kEpiResidual},
+                            {"head", 1088, 1024, false, kEpiBias}};
+    const int NREP = 24;   // distinct weight matrices per shape: the stream really comes from HBM
+    if (!quick)
     for (const Shape& s : shapes) {
         std::vector<float*> wt(NREP);
         float* wsrc = dalloc((size_t)s.K * s.N, 0.05f, 11);
@@ -137,78 +137,90 @@ int main(int argc, char** argv) {
             launch_pack_wt16(wsrc, s.N, wt[r], s.K, s.N, st);
         }
         HIP_CHECK(hipStreamSynchronize(st));
-        for (int ntl : {1, 2})
-        for (int nt : {0})
-        for (int nw : {16, 8, 4})
-            for (int mt : {1, 2, 4}) {
-                if (nw == 4 && (mt != 1 || s.K != 1024 || ntl != 1)) continue;
-                if (ntl == 2 && !(s.ln && nw == 8 && mt <= 2)) continue;
-                if (nt && (M + 16 * mt - 1) / (16 * mt) != 1) continue;
-                if (s.K == 4096 && mt == 4) continue;
-                if (16 * (mt / 2) >= M && mt > 1) continue;
-                GemmRowsArgs a{};
-                a.X = X; a.xmt = 16; a.omt = 16; a.M = M; a.N = s.N; a.K = s.K; a.bias = bias; a.gamma = gamma; a.beta = beta; a.eps = 1e-5f;
-                a.out = (s.epi == kEpiResidual) ? hres : out; a.ldo = (s.epi == kEpiQkv) ? H : s.N;
-                a.kv_layer = kv; a.row_slot = dslot; a.slot_kvpos = dpos; a.block_tables = dbt; a.max_blocks = 66; a.nt_w = nt; a.stats_in = dstats; a.stats_out = (s.epi == kEpiResidual && s.N == 1024) ? dstats : nullptr;
-                int it = 0;
-                const float us = time_us(st, 240, [&] {
-                    a.Wt = wt[it++ % NREP];
-                    launch_variant(a, s, mt, nw, st, ntl);
-                });
-                const int n_grp = (M + 16 * mt - 1) / (16 * mt);
-                const int nwg = ((s.N / (16 * ntl) + 7) / 8 * 8) * n_grp;
-                // phase stamps of one launch
-                HIP_CHECK(hipMemsetAsync(dprof, 0, (size_t)nwg * 64, st));
-                a.prof = dprof;
-                a.Wt = wt[5];
-                launch_variant(a, s, mt, nw, st, ntl);
-                HIP_CHECK(hipStreamSynchronize(st));
-                std::vector<long long> hp((size_t)nwg * 8);
-                HIP_CHECK(hipMemcpy(hp.data(), dprof, hp.size() * 8, hipMemcpyDeviceToHost));
-                long long t_min = -1, t_max = 0;
-                double ph[5] = {0, 0, 0, 0, 0};
-                int live = 0;
-                std::vector<double> st_us, en_us;
-                for (int g = 0; g < nwg; ++g) {
-                    if (hp[g * 8] == 0) continue;   // surplus workgroups of a padded grid exit before the first stamp
-                    ++live;
-                    t_min = t_min < 0 ? hp[g * 8] : std::min(t_min, hp[g * 8]);
-                    t_max = std::max(t_max, hp[g * 8 + 5]);
-                }
-                for (int g = 0; g < nwg; ++g) {
-                    if (hp[g * 8] == 0) continue;
-                    for (int k = 0; k < 5; ++k) ph[k] += (double)(hp[g * 8 + k + 1] - hp[g * 8 + k]) / live;
-                    st_us.push_back((double)(hp[g * 8] - t_min) / 100.0);
-                    en_us.push_back((double)(hp[g * 8 + 5] - t_min) / 100.0);
-                }
-                std::sort(st_us.begin(), st_us.end());
-                std::sort(en_us.begin(), en_us.end());
-                printf("    workgroup starts (us after the first): p50 %.2f p90 %.2f max %.2f | ends: p10 %.2f p50 %.2f p90 %.2f max %.2f\n",
-                       st_us[st_us.size() / 2], st_us[st_us.size() * 9 / 10], st_us.back(), en_us[en_us.size() / 10], en_us[en_us.size() / 2],
-                       en_us[en_us.size() * 9 / 10], en_us.back());
-                const double mb = 4.0 * ((double)s.K * s.N + (double)M * s.K + (double)M * s.N) / 1e6;
-                printf("%s M=%d cols/wg=%d rows/wg=%2d waves=%2d wgs=%4d : %6.2f us/launch  %5.2f TB/s | 10-ns ticks: span %6lld issue %5.0f ln+wait %6.0f mfma %6.0f bar %5.0f epi %5.0f\n",
-                       s.name, M, 16 * ntl, 16 * mt, nw, nwg, us, mb / us, t_max - t_min, ph[0], ph[1], ph[2], ph[3], ph[4]);
+        std::vector<Cfg> cfgs;
+        cfgs.push_back({1, 16, 1, 0});   // reference for the correctness check
+        if (s.ln) {
+            for (int prec : {0, 1}) {
+                cfgs.push_back({1, 8, 1, prec});
+                if (M > 16) cfgs.push_back({2, 8, 1, prec});
+                cfgs.push_back({1, 16, 2, prec});
+                if (s.N % 48 == 0) cfgs.push_back({1, 16, 3, prec});
+                cfgs.push_back({1, 16, 4, prec});
+                if (M > 16) cfgs.push_back({2, 16, 2, prec});
+                if (M > 16) cfgs.push_back({2, 16, 1, prec});
+                if (prec) cfgs.push_back({1, 16, 1, prec});
             }
-        // reference: the round-1 split-K kernel on the same shape (slab sums not included)
-        {
-            float* P;
-            HIP_CHECK(hipMalloc(&P, (size_t)16 * 128 * 4096 * 4));
-            const GemmPlan pl = gemm_plan(M, s.K);
-            if (s.N % 64 == 0) {
-                const float us = time_us(st, 240, [&] { launch_gemm_splitk(X, s.K, wsrc, P, M, s.N, s.K, pl, st, nullptr); });
-                printf("%s M=%d round-1 split-K (slabs %d, epilogue launches not included): %6.2f us/launch (weights L3-resident)\n", s.name, M, pl.slabs, us);
+        } else {
+            cfgs.push_back({1, 16, 1, 1});
+            if (M > 16) cfgs.push_back({2, 16, 1, 0});
+            if (M > 16) cfgs.push_back({2, 16, 1, 1});
+            if (s.K == 1024 && s.N % 32 == 0) cfgs.push_back({1, 16, 2, 0});
+            if (s.K == 1024 && s.N % 32 == 0) cfgs.push_back({1, 16, 2, 1});
+        }
+        std::vector<float> ref;
+        for (const Cfg& c : cfgs) {
+            GemmRowsArgs a{};
+            a.X = X; a.xmt = MTT; a.omt = MTT; a.M = M; a.N = s.N; a.K = s.K; a.bias = bias; a.ln_c1 = s.ln ? gamma : nullptr; a.eps = 1e-5f;
+            a.out = (s.epi == kEpiResidual) ? hres : out; a.ldo = (s.epi == kEpiQkv) ? H : s.N;
+            a.kv_layer = kv; a.row_slot = dslot; a.slot_kvpos = dpos; a.block_tables = dbt; a.max_blocks = 66; a.stats_in = dstats; a.row_meta = drm;
+            // correctness: one launch on a fresh output, compared element-wise with the reference configuration
+            HIP_CHECK(hipMemcpyAsync(hres, hres0, (size_t)256 * 4096 * 4, hipMemcpyDeviceToDevice, st));
+            HIP_CHECK(hipMemsetAsync(out, 0, (size_t)256 * 4096 * 4, st));
+            a.Wt = wt[0];
+            launch_variant(a, s, c, st);
+            HIP_CHECK(hipStreamSynchronize(st));
+            std::vector<float> got((size_t)256 * 4096);
+            HIP_CHECK(hipMemcpy(got.data(), a.out, got.size() * 4, hipMemcpyDeviceToHost));
+            double maxd = 0, maxr = 0;
+            if (ref.empty()) ref = got;
+            for (size_t i = 0; i < got.size(); ++i) {
+                maxd = std::max(maxd, (double)fabsf(got[i] - ref[i]));
+                maxr = std::max(maxr, (double)fabsf(ref[i]));
             }
-            HIP_CHECK(hipFree(P));
+            a.stats_out = (s.epi == kEpiResidual && s.N == 1024) ? dstats + 128 * 64 : nullptr;
+            int it = 0;
+            const float us = time_us(st, 240, [&] {
+                a.Wt = wt[it++ % NREP];
+                launch_variant(a, s, c, st);
+            });
+            const int n_grp = (M + 16 * c.mt - 1) / (16 * c.mt);
+            const int nwg = ((s.N / (16 * c.ntl) + 7) / 8 * 8) * n_grp;
+            HIP_CHECK(hipMemsetAsync(dprof, 0, (size_t)nwg * 64, st));
+            a.prof = dprof;
+            a.Wt = wt[5];
+            launch_variant(a, s, c, st);
+            HIP_CHECK(hipStreamSynchronize(st));
+            std::vector<long long> hp((size_t)nwg * 8);
+            HIP_CHECK(hipMemcpy(hp.data(), dprof, hp.size() * 8, hipMemcpyDeviceToHost));
+            long long t_min = -1, t_max = 0;
+            double ph[5] = {0, 0, 0, 0, 0};
+            int live = 0;
+            std::vector<double> en_us;
+            for (int g = 0; g < nwg; ++g) {
+                if (hp[g * 8] == 0) continue;
+                ++live;
+                t_min = t_min < 0 ? hp[g * 8] : std::min(t_min, hp[g * 8]);
+                t_max = std::max(t_max, hp[g * 8 + 5]);
+            }
+            for (int g = 0; g < nwg; ++g) {
+                if (hp[g * 8] == 0) continue;
+                for (int k = 0; k < 5; ++k) ph[k] += (double)(hp[g * 8 + k + 1] - hp[g * 8 + k]) / live;
+                en_us.push_back((double)(hp[g * 8 + 5] - t_min) / 100.0);
+            }
+            std::sort(en_us.begin(), en_us.end());
+            printf("%s M=%d rows/wg=%2d cols/wg=%2d waves=%2d prec=%d wgs=%4d : %6.2f us/launch | max|d| vs ref %.2e (max|ref| %.2e) | 10-ns ticks: span %5lld issue %4.0f ln+wait %5.0f mfma %5.0f bar %4.0f epi %4.0f | ends p10 %.2f p50 %.2f max %.2f\n",
+                   s.name, M, 16 * c.mt, 16 * c.ntl, c.nw, c.prec, nwg, us, maxd, maxr, t_max - t_min, ph[0], ph[1], ph[2], ph[3], ph[4],
+                   en_us[en_us.size() / 10], en_us[en_us.size() / 2], en_us.back());
+            fflush(stdout);
         }
         for (int r = 0; r < NREP; ++r) HIP_CHECK(hipFree(wt[r]));
         HIP_CHECK(hipFree(wsrc));
     }
-    // ---- the four GEMMs of a block chained over 30 layers with distinct weights (1.5 GB: streams from HBM), default policy
+    // ---- the decode layer chained over 30 layers with distinct weights (1.5 GB) and K/V pools (127 MB read per attention launch)
     {
-        std::vector<float*> wq(30), wp(30), wf(30), w2(30);
+        std::vector<float*> wq(n_layers), wp(n_layers), wf(n_layers), w2(n_layers);
         float* src = dalloc((size_t)4096 * 1024, 0.05f, 21);
-        for (int l = 0; l < 30; ++l) {
+        for (int l = 0; l < n_layers; ++l) {
             HIP_CHECK(hipMalloc(&wq[l], (size_t)3072 * 1024 * 4));
             HIP_CHECK(hipMalloc(&wp[l], (size_t)1024 * 1024 * 4));
             HIP_CHECK(hipMalloc(&wf[l], (size_t)4096 * 1024 * 4));
@@ -222,28 +234,34 @@ int main(int argc, char** argv) {
         float* act = dalloc((size_t)256 * 4096, 0.5f, 22);
         float* att = dalloc((size_t)256 * 1024, 0.5f, 23);
         float* qb = dalloc((size_t)256 * 1024, 0.f, 24);
-        auto chain = [&] {
-            for (int l = 0; l < 30; ++l) {
+        auto chain = [&](bool attn, int prec) {
+            for (int l = 0; l < n_layers; ++l) {
+                float* kvl = kv + (size_t)l * kv_blocks * kKvBlockElems;
                 GemmRowsArgs a{};
-                a.M = M; a.eps = 1e-5f; a.X = hres; a.xmt = 16; a.Wt = wq[l]; a.N = 3072; a.K = 1024; a.bias = bias; a.gamma = gamma;
-                a.beta = beta; a.stats_in = dstats; a.out = qb; a.ldo = 1024; a.kv_layer = kv; a.row_slot = dslot; a.slot_kvpos = dpos; a.block_tables = dbt;
+                a.M = M; a.prec = prec; a.eps = 1e-5f; a.X = hres; a.xmt = MTT; a.Wt = wq[l]; a.N = 3072; a.K = 1024; a.bias = bias; a.ln_c1 = gamma;
+                a.stats_in = dstats; a.out = qb; a.ldo = 1024; a.kv_layer = kvl; a.row_slot = dslot; a.slot_kvpos = dpos; a.block_tables = dbt; a.row_meta = drm;
                 a.max_blocks = 66;
                 launch_gemm_rows(a, true, kEpiQkv, st);
+                if (attn) launch_paged_attention(qb, kvl, dslot, nullptr, dpos, dbt, 66, att, M, st, MTT, false, drm);
                 a = GemmRowsArgs{};
-                a.M = M; a.X = att; a.xmt = 16; a.Wt = wp[l]; a.N = 1024; a.K = 1024; a.bias = bias; a.out = hres; a.omt = 16; a.stats_out = dstats;
+                a.M = M; a.prec = prec; a.X = att; a.xmt = MTT; a.Wt = wp[l]; a.N = 1024; a.K = 1024; a.bias = bias; a.out = hres; a.omt = MTT; a.stats_out = dstats + 128 * 64;
                 launch_gemm_rows(a, false, kEpiResidual, st);
                 a = GemmRowsArgs{};
-                a.M = M; a.eps = 1e-5f; a.X = hres; a.xmt = 16; a.Wt = wf[l]; a.N = 4096; a.K = 1024; a.bias = bias; a.gamma = gamma;
-                a.beta = beta; a.stats_in = dstats; a.out = act; a.omt = 16;
+                a.M = M; a.prec = prec; a.eps = 1e-5f; a.X = hres; a.xmt = MTT; a.Wt = wf[l]; a.N = 4096; a.K = 1024; a.bias = bias; a.ln_c1 = gamma;
+                a.stats_in = dstats; a.out = act; a.omt = MTT;
                 launch_gemm_rows(a, true, kEpiBiasGelu, st);
                 a = GemmRowsArgs{};
-                a.M = M; a.X = act; a.xmt = 16; a.Wt = w2[l]; a.N = 1024; a.K = 4096; a.bias = bias; a.out = hres; a.omt = 16; a.stats_out = dstats;
+                a.M = M; a.prec = prec; a.X = act; a.xmt = MTT; a.Wt = w2[l]; a.N = 1024; a.K = 4096; a.bias = bias; a.out = hres; a.omt = MTT; a.stats_out = dstats + 128 * 64;
                 launch_gemm_rows(a, false, kEpiResidual, st);
             }
         };
-        const float us = time_us(st, 20, chain);
-        printf("chain of 30 x (qkv, proj, fc, proj2), default shapes, M=%d: %.1f us per layer (%.2f ms per step), weights %.2f TB/s\n", M,
-               us / 30, us / 1000, 30 * 50.33e6 / us / 1e6);
+        for (int attn : {0, 1})
+            for (int prec : {0, 1}) {
+                const float us = time_us(st, 20, [&] { chain(attn != 0, prec); });
+                printf("chain of 30 x (qkv,%s proj, fc, proj2) M=%d shapes=%s prec=%d: %.1f us per layer (%.3f ms per step)\n",
+                       attn ? " attention," : "", M, getenv("AUR_GEMM_SHAPES") ? getenv("AUR_GEMM_SHAPES") : "r03", prec, us / n_layers, us / 1000);
+                fflush(stdout);
+            }
     }
     return 0;
 }
