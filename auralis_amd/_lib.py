@@ -25,7 +25,7 @@ class aur_config(C.Structure):
     _fields_ = [("n_layer", C.c_int32), ("max_seqs", C.c_int32), ("max_prefill_rows", C.c_int32),
                 ("max_speakers", C.c_int32), ("vocoder_min_batch", C.c_int32), ("profile", C.c_int32),
                 ("vocoder_fp16", C.c_int32), ("second_pass", C.c_int32), ("return_latents", C.c_int32), ("kv_fp16", C.c_int32),
-                ("gemm_f32_exact", C.c_int32)]
+                ("gemm_f32_exact", C.c_int32), ("gelu_erf", C.c_int32)]
 
 
 class aur_tensor_desc(C.Structure):
@@ -75,9 +75,10 @@ class aur_stats(C.Structure):
 EXPORTS = [
     "aur_last_error", "aur_version", "aur_engine_create", "aur_engine_destroy", "aur_load_weights",
     "aur_set_conditioning", "aur_set_conditioning_device", "aur_has_conditioning", "aur_compute_conditioning", "aur_comm_unique_id", "aur_comm_init", "aur_broadcast_conditioning",
+    "aur_comm_info", "aur_conditioning_checksum",
     "aur_submit", "aur_step", "aur_poll_finished",
     "aur_release", "aur_vocode", "aur_sync", "aur_get_stats", "aur_reset_stats", "aur_dbg_gemm", "aur_dbg_gemm_rows",
-    "aur_dbg_gemm_tile_map", "aur_dbg_layernorm", "aur_dbg_conv1d", "aur_dbg_conv1d_f16", "aur_dbg_prefill", "aur_dbg_sample",
+    "aur_dbg_layernorm", "aur_dbg_conv1d", "aur_dbg_conv1d_f16", "aur_dbg_prefill", "aur_dbg_sample",
 ]
 
 _lib = None
@@ -112,6 +113,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "aur_comm_unique_id": [C.POINTER(C.c_uint8)],
         "aur_comm_init": [eng, C.POINTER(C.c_uint8), C.c_int32, C.c_int32],
         "aur_broadcast_conditioning": [eng, C.c_uint64, C.c_int32],
+        "aur_comm_info": [eng, ip, ip],
+        "aur_conditioning_checksum": [eng, C.c_uint64, C.POINTER(C.c_uint64)],
         "aur_compute_conditioning": [eng, C.POINTER(fp), ip, C.c_int32, C.POINTER(aur_cond_params), fp, fp],
         "aur_submit": [eng, C.POINTER(aur_seq_desc), C.POINTER(C.c_uint64)],
         "aur_step": [eng, ip, ip],
@@ -121,9 +124,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "aur_sync": [eng],
         "aur_get_stats": [eng, C.POINTER(aur_stats)],
         "aur_reset_stats": [eng],
-        "aur_dbg_gemm": [eng, fp, fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32],
+        "aur_dbg_gemm": [eng, fp, fp, fp, C.c_int32, C.c_int32, C.c_int32],
         "aur_dbg_gemm_rows": [eng, fp, fp, fp, fp, fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32],
-        "aur_dbg_gemm_tile_map": [C.c_int32, C.c_int32, C.c_int32, C.c_int32, ip],
         "aur_dbg_layernorm": [eng, fp, fp, fp, fp, C.c_int32],
         "aur_dbg_conv1d": [eng, fp, fp, fp, fp, fp, ip, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                            C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32],
@@ -164,10 +166,10 @@ class NativeEngine:
     def __init__(self, n_layer: int = 30, max_seqs: int = 64, device: int = 0, max_prefill_rows: int = 0,
                  max_speakers: int = 0, vocoder_min_batch: int = 0, profile: bool = False, vocoder_fp16: bool = False,
                  second_pass: bool = False, return_latents: bool = True, kv_fp16: bool = False,
-                 gemm_f32_exact: bool = False):
+                 gemm_f32_exact: bool = False, gelu_erf: bool = False):
         self.lib = load_library()
         cfg = aur_config(n_layer, max_seqs, max_prefill_rows, max_speakers, vocoder_min_batch, int(profile),
-                         int(vocoder_fp16), int(second_pass), int(return_latents), int(kv_fp16), int(gemm_f32_exact))
+                         int(vocoder_fp16), int(second_pass), int(return_latents), int(kv_fp16), int(gemm_f32_exact), int(gelu_erf))
         h = C.c_void_p()
         self._check(self.lib.aur_engine_create(C.byref(cfg), device, C.byref(h)))
         self.h = h
@@ -242,6 +244,18 @@ class NativeEngine:
     def broadcast_conditioning(self, key: int, root: int = 0):
         """Collective over the engine's communicator: the voice `key` registered on `root` arrives on every other rank."""
         self._check(self.lib.aur_broadcast_conditioning(self.h, key, root))
+
+    def comm_info(self):
+        """(ranks, rank) as the engine's RCCL communicator reports them (ncclCommCount / ncclCommUserRank); (0, -1) before comm_init."""
+        n, r = C.c_int32(0), C.c_int32(-1)
+        self._check(self.lib.aur_comm_info(self.h, C.byref(n), C.byref(r)))
+        return int(n.value), int(r.value)
+
+    def conditioning_checksum(self, key: int) -> int:
+        """FNV-1a over the voice's conditioning as it sits in device memory (cross-rank equality check after a broadcast)."""
+        out = C.c_uint64(0)
+        self._check(self.lib.aur_conditioning_checksum(self.h, key, C.byref(out)))
+        return int(out.value)
 
     def set_conditioning_device(self, key: int, d_gpt_cond_ptr: int, d_spk_ptr: int):
         self._check(self.lib.aur_set_conditioning_device(self.h, key, C.c_void_p(d_gpt_cond_ptr), C.c_void_p(d_spk_ptr)))
@@ -319,13 +333,14 @@ class NativeEngine:
         self._check(self.lib.aur_reset_stats(self.h))
 
     # -- per-kernel debug entry points -------------------------------------------------------------------
-    def dbg_gemm(self, X, W, kw: int = 0) -> np.ndarray:
+    def dbg_gemm(self, X, W) -> np.ndarray:
+        """prefill-regime GEMM (gemm_tile_kernel): X @ W"""
         X, W = _f32(X), _f32(W)
         M, K = X.shape
         K2, N = W.shape
         assert K == K2
         out = np.empty((M, N), dtype=np.float32)
-        self._check(self.lib.aur_dbg_gemm(self.h, _fp(X), _fp(W), _fp(out), M, N, K, kw))
+        self._check(self.lib.aur_dbg_gemm(self.h, _fp(X), _fp(W), _fp(out), M, N, K))
         return out
 
     def dbg_gemm_rows(self, X, W, bias=None, gamma=None, beta=None, res=None, epi: int = 0) -> np.ndarray:

@@ -62,7 +62,10 @@ def encode(pcm: np.ndarray, sample_rate: int, fmt: str = "wav", sample_width: in
     """float mono PCM in [-1, 1] -> bytes in `fmt` (the reference's format list: mp3, opus, aac, flac, wav, pcm)."""
     fmt = fmt.lower()
     if fmt in ("pcm", "raw"):
-        return _to_int(pcm, sample_width).tobytes()
+        x = _to_int(pcm, sample_width)
+        if sample_width == 3:   # 24-bit samples travel as 3 little-endian bytes each (the int32 carrier has 4)
+            return x.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :3].tobytes()
+        return x.tobytes()
     if fmt == "wav":
         return wav_bytes(pcm, sample_rate, sample_width)
     if fmt == "flac":   # lossless: 16 bit for sample_width 2 (the reference's default), 24 bit above

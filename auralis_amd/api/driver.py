@@ -24,12 +24,22 @@ class EngineDriver:
         self._thread = threading.Thread(target=self._run, name="auralis-amd-driver", daemon=True)
         self._thread.start()
 
-    def submit(self, loop: asyncio.AbstractEventLoop, **seq) -> "asyncio.Future":
+    def submit(self, loop: asyncio.AbstractEventLoop, reregister=None, **seq) -> "asyncio.Future":
+        """`reregister` (optional, no arguments): registers the sequence's voice again.  The engine's speaker table is bounded and
+        a voice is only pinned from aur_submit on, so between the caller's presence check and this call another request can
+        have evicted it; the engine then answers "unknown speaker_key" (AUR_E_INVALID) and the submission is repeated once
+        after `reregister()`."""
         if self._error is not None:
             raise RuntimeError("engine driver stopped") from self._error
         fut = loop.create_future()
         with self._lock:
-            sid = self.engine.submit(**seq)
+            try:
+                sid = self.engine.submit(**seq)
+            except Exception as e:
+                if reregister is None or "unknown speaker_key" not in str(e):
+                    raise
+                reregister()
+                sid = self.engine.submit(**seq)
             self._pending[sid] = (loop, fut)
         self._wake.set()
         return fut

@@ -58,16 +58,18 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
         reference forwards to vLLM (tensor_parallel_size, pipeline_parallel_size, gpt_model, torch_dtype, device_map;
         XTTSv2.py:235-243) are accepted; tp/pp other than 1 are rejected (the path shards by utterance)."""
         from .._lib import NativeEngine
-        from ..checkpoint import load_checkpoint
+        from ..checkpoint import load_checkpoint, read_checkpoint_config
         from ..weights import pack_all
         if kwargs.get("tensor_parallel_size", 1) != 1 or kwargs.get("pipeline_parallel_size", 1) != 1:
             raise ValueError("the MI355X path replicates the 0.4 B-parameter model per GPU; use one engine per GPU")
         gpt_sd, xtts_sd = load_checkpoint(pretrained_model_name_or_path)
-        n_layer = 1 + max(int(k.split(".")[2]) for k in gpt_sd if k.startswith("gpt.h."))
+        # both config.json are read and checked against what the kernels are compiled for (XTTSv2.py:276-277 builds
+        # XTTSGPTConfig / XTTSConfig from them); the activation and the generation length come from the file
+        ck = read_checkpoint_config(pretrained_model_name_or_path, gpt_sd)
         # vocoder="fp16": HiFi-GAN convs on fp16-input / fp32-accumulate MFMA (waveform within 1e-5 RMS of the fp32
         # path, the reference's own GPU path autocasts to fp16); vocoder="fp32": exact-f32 MFMA parity mode
-        native = NativeEngine(n_layer=n_layer, max_seqs=max(1, max_concurrency), device=device,
-                              vocoder_fp16=(vocoder == "fp16"), return_latents=False)
+        native = NativeEngine(n_layer=ck.n_layer, max_seqs=max(1, max_concurrency), device=device,
+                              vocoder_fp16=(vocoder == "fp16"), return_latents=False, gelu_erf=ck.gelu_erf)
         native.load_weights(pack_all(gpt_sd, xtts_sd))
         if any(k.startswith("conditioning_encoder.") for k in xtts_sd):
             from ..weights import pack_conditioning
@@ -86,6 +88,7 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
         cond_w = {k: v for k, v in xtts_sd.items()
                   if k.startswith(("conditioning_", "hifigan_decoder.speaker_encoder.", "mel_stats"))}
         return cls(native, XTTSTokenizer(tok_file, vocab_size=vocab, synthetic=synthetic_tok), max_concurrency=max_concurrency,
+                   gpt_max_audio_tokens=ck.gpt_max_audio_tokens,
                    conditioning_weights=cond_w if any(k.startswith("conditioning_encoder.") for k in cond_w) else None)
 
     @property
@@ -193,8 +196,9 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
         if gpt_cond_latent is None or speaker_embeddings is None:
             gpt_cond_latent, speaker_embeddings = await self.get_audio_conditioning(
                 request.speaker_files, request.max_ref_length, request.gpt_cond_len, request.gpt_cond_chunk_len)
-        key = self._register_speaker(np.asarray(gpt_cond_latent, dtype=np.float32),
-                                     np.asarray(speaker_embeddings, dtype=np.float32))
+        g_np = np.asarray(gpt_cond_latent, dtype=np.float32)
+        s_np = np.asarray(speaker_embeddings, dtype=np.float32)
+        key = self._register_speaker(g_np, s_np)
         chunks = self.tokenizer.batch_encode_with_split(request.text, request.language)
         loop = asyncio.get_running_loop()
         handles, ids = [], []
@@ -206,7 +210,8 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
                         ^ self._seed_counter) & 0xFFFFFFFF
             else:
                 seed = (request.seed + idx) & 0xFFFFFFFF
-            fut = self.driver.submit(loop, text_ids=text_ids, speaker_key=key, temperature=request.temperature,
+            fut = self.driver.submit(loop, reregister=lambda: self.native.set_conditioning(key, g_np, s_np),
+                                     text_ids=text_ids, speaker_key=key, temperature=request.temperature,
                                      top_p=request.top_p, top_k=request.top_k,
                                      repetition_penalty=request.repetition_penalty,
                                      max_tokens=self.gpt_max_audio_tokens, seed=seed)

@@ -16,7 +16,8 @@ from __future__ import annotations
 import json
 import math
 import os
-from typing import Dict, Optional, Tuple
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
@@ -223,6 +224,95 @@ def save_checkpoint(root: str, gpt_sd: Dict[str, Tensor], xtts_sd: Dict[str, Ten
     with open(os.path.join(root, "core_xttsv2", "config.json"), "w") as f:
         json.dump({"model_type": "xtts", "gpt_config": {"num_hidden_layers": n_layer},
                    **({"synthetic_tokenizer": True} if synthetic_tokenizer else {})}, f)
+
+
+@dataclass
+class CheckpointConfig:
+    """What the engine takes from the checkpoint's two config.json (the reference builds XTTSGPTConfig / XTTSConfig from them,
+    XTTSv2.py:276-277; defaults are the config CLASS defaults, xttsv2_gpt_config.py:133-186, xttsv2_config.py:212-260)."""
+    n_layer: int = 30
+    activation: str = "gelu"        # XTTSGPTConfig default; checkpoint_converter.py:197 writes "gelu_new"
+    gpt_max_audio_tokens: int = 605  # max_tokens of every generation (XTTSv2.py:735)
+    max_text_tokens: int = 402
+    languages: Optional[List[str]] = None
+
+    @property
+    def gelu_erf(self) -> bool:
+        return self.activation == "gelu"
+
+
+class CheckpointConfigError(ValueError):
+    """The checkpoint describes a model the compiled kernels cannot run (AUR_E_INVALID at the Python boundary)."""
+
+
+def _load_json(path: str) -> Optional[dict]:
+    if not os.path.isfile(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def read_checkpoint_config(root: str, gpt_sd: Optional[Dict[str, Tensor]] = None) -> CheckpointConfig:
+    """gpt/config.json (XTTSGPTConfig) and core_xttsv2/config.json (XTTSConfig) -> CheckpointConfig.  Every dimension the HIP
+    kernels are compiled for is checked against the file; a mismatch raises CheckpointConfigError naming the key (the kernels
+    would otherwise run a different model silently).  The activation is honoured: "gelu_new" / "gelu_pytorch_tanh" = tanh
+    form, "gelu" = erf form (aur_config.gelu_erf); anything else is refused."""
+    g = GPTDims()
+    gj = _load_json(os.path.join(root, "gpt", "config.json"))
+    xj = _load_json(os.path.join(root, "core_xttsv2", "config.json"))
+    if gj is None:
+        raise FileNotFoundError(f"{os.path.join(root, 'gpt', 'config.json')}: the GPT config of the checkpoint is required "
+                                "(activation_function, token ids and sizes are read from it)")
+    nested = (xj or {}).get("gpt_config") or {}
+
+    def get(key, default):
+        return gj.get(key, nested.get(key, default))
+
+    def need(key, default, want, what):
+        v = get(key, default)
+        if v is None:
+            v = want
+        if v != want:
+            raise CheckpointConfigError(f"gpt/config.json: {key} = {v!r}, but the MI355X kernels are built for {what} = {want!r}")
+
+    need("hidden_size", 1024, g.hidden, "hidden size")
+    need("num_attention_heads", 16, g.n_head, "attention heads")
+    n_inner = get("n_inner", 4096)
+    if (n_inner if n_inner is not None else 4 * g.hidden) != g.n_inner:
+        raise CheckpointConfigError(f"gpt/config.json: n_inner = {n_inner!r}, but the MI355X kernels are built for {g.n_inner}")
+    need("num_audio_tokens", 1026, g.mel_vocab, "mel vocabulary")
+    need("start_audio_token", 1024, g.start_token, "start id")
+    need("stop_audio_token", 1025, g.stop_token, "stop id")
+    eps = float(get("layer_norm_epsilon", 1e-5))
+    if abs(eps - g.ln_eps) > 1e-12:
+        raise CheckpointConfigError(f"gpt/config.json: layer_norm_epsilon = {eps!r}, kernels use {g.ln_eps!r}")
+    act = get("activation_function", "gelu")
+    if act in ("gelu_new", "gelu_pytorch_tanh"):
+        act = "gelu_new"
+    elif act != "gelu":
+        raise CheckpointConfigError(f"gpt/config.json: activation_function = {act!r}; supported: 'gelu_new' (tanh form) and 'gelu' (erf form)")
+    max_audio = int(get("max_audio_tokens", 605))
+    gen_max = int(get("gpt_max_audio_tokens", max_audio))
+    if max_audio + 3 > g.mel_positions or gen_max > g.max_audio_tokens:
+        raise CheckpointConfigError(f"gpt/config.json: max_audio_tokens = {max_audio} / gpt_max_audio_tokens = {gen_max}; the engine "
+                                    f"keeps {g.mel_positions} mel positions and {g.max_audio_tokens} latent rows per sequence")
+    max_text = int(get("max_text_tokens", 402))
+    if max_text + 2 > g.text_positions:
+        raise CheckpointConfigError(f"gpt/config.json: max_text_tokens = {max_text}; the engine keeps {g.text_positions} text positions")
+    n_layer = int(get("num_hidden_layers", 30))
+    if gpt_sd is not None:
+        have = 1 + max(int(k.split(".")[2]) for k in gpt_sd if k.startswith("gpt.h."))
+        if have != n_layer:
+            raise CheckpointConfigError(f"gpt/config.json: num_hidden_layers = {n_layer}, gpt2_model.safetensors holds {have} blocks")
+    if xj is not None:
+        v = VocoderDims()
+        for key, want in (("input_sample_rate", v.input_sample_rate), ("output_sample_rate", v.output_sample_rate),
+                          ("output_hop_length", v.output_hop_length), ("decoder_input_dim", v.in_dim), ("d_vector_dim", v.d_vector),
+                          ("gpt_code_stride_len", v.ar_mel_length_compression)):
+            if key in xj and xj[key] != want:
+                raise CheckpointConfigError(f"core_xttsv2/config.json: {key} = {xj[key]!r}, but the vocoder kernels are built for {want!r}")
+    return CheckpointConfig(n_layer=n_layer, activation=act, gpt_max_audio_tokens=gen_max, max_text_tokens=max_text,
+                            languages=(xj or {}).get("languages"))
 
 
 def load_checkpoint(root: str) -> Tuple[Dict[str, Tensor], Dict[str, Tensor]]:

@@ -171,8 +171,6 @@ public:
         // of other sequences, the latency-bound decode kernels get the CUs first and the vocoder fills what is left
         int prio_lo = 0, prio_hi = 0;
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        if (const char* e = getenv("AUR_STREAM_PRIORITY"))
-            if (atoi(e) == 0) prio_lo = prio_hi = 0;
         HIP_CHECK(hipStreamCreateWithPriority(&st_, hipStreamDefault, prio_hi));   // blocking w.r.t. the null stream on purpose
         AUR_REQUIRE(c.n_layer >= 1 && c.n_layer <= 64, "n_layer in [1,64]");
         AUR_REQUIRE(c.max_seqs >= 1 && c.max_seqs <= 4096, "max_seqs in [1,4096]");
@@ -212,28 +210,20 @@ public:
         HIP_CHECK(hipEventRecord(ev_lat_, st_));
         latpool_.ensure((size_t)2 * S * kMaxLatRows * kHidden * sizeof(float));
         for (int i = 2 * S - 1; i >= 0; --i) latpool_free_.push_back(i);
-        HIP_CHECK(hipEventCreate(&ev_ws1_));
         ws_[0].st = st_;
         ws_[1].st = st2_;
         xt_f16_ = cfg_.vocoder_fp16 != 0;   // fp16 storage of the ResBlock c1 -> c2 intermediate (bit-identical, see ConvArgs)
         if (const char* e = getenv("AUR_XT_F16")) xt_f16_ = xt_f16_ && atoi(e) != 0;
-        if (const char* e = getenv("AUR_VOC_ACT2")) act2_ = atoi(e) != 0;
-        if (const char* e = getenv("AUR_DECODE_STREAMS")) decode_streams_ = atoi(e);
         if (const char* e = getenv("AUR_DECODE_PIPELINE")) pipeline_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_SAMPLER_FULL_SORT")) sampler_full_sort_ = atoi(e) != 0;
-        if (const char* e = getenv("AUR_FUSE_GELU")) fuse_gelu_ = atoi(e) != 0;
-        if (const char* e = getenv("AUR_DECODE_GEMM")) rows_gemm_ = std::string(e) != "splitk";
-        if (const char* e = getenv("AUR_PREFILL_GEMM")) tile_gemm_ = std::string(e) != "splitk";   // A/B: round-1 prefill GEMM
-        AUR_REQUIRE(rows_gemm_ || !kv_half_, "kv_fp16 needs the gemm_rows decode chain (AUR_DECODE_GEMM=splitk keeps fp32 K/V)");
         if (const char* e = getenv("AUR_TEST_FAIL_STEP")) fail_at_step_ = atoi(e);
+        if (const char* e = getenv("AUR_TEST_FAIL_VOC")) fail_at_voc_ = atoi(e);
 
         for (int i = 0; i < 2; ++i) {
             HIP_CHECK(hipEventCreateWithFlags(&ev_rb_[i], hipEventDisableTiming));
             HIP_CHECK(hipEventCreate(&ev_ds_[i]));
             HIP_CHECK(hipEventCreate(&ev_de_[i]));
         }
-        if (const char* e = getenv("AUR_DECODE_GRAPH")) decode_graph_ = atoi(e) != 0;
-        HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
         HIP_CHECK(hipEventCreate(&ev_a_));
         HIP_CHECK(hipEventCreate(&ev_b_));
         HIP_CHECK(hipStreamSynchronize(st_));
@@ -254,10 +244,7 @@ public:
             (void)hipEventDestroy(ev_ds_[i]);
             (void)hipEventDestroy(ev_de_[i]);
         }
-        if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
         if (comm_) (void)Rccl::get().CommDestroy(comm_);
-        (void)hipEventDestroy(ev_fork_);
-        (void)hipEventDestroy(ev_ws1_);
         (void)hipEventDestroy(ev_lat_);
         (void)hipEventDestroy(ev_voc_done_);
         (void)hipStreamDestroy(st_voc_);
@@ -335,6 +322,8 @@ public:
         int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
         int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
         int (*CommDestroy)(void*) = nullptr;
+        int (*CommCount)(void*, int*) = nullptr;
+        int (*CommUserRank)(void*, int*) = nullptr;
         const char* (*GetErrorString)(int) = nullptr;
         static Rccl& get() {
             static Rccl r = [] {
@@ -347,6 +336,8 @@ public:
                 x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
                 x.Broadcast = reinterpret_cast<decltype(x.Broadcast)>(dlsym(h, "ncclBroadcast"));
                 x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+                x.CommCount = reinterpret_cast<decltype(x.CommCount)>(dlsym(h, "ncclCommCount"));
+                x.CommUserRank = reinterpret_cast<decltype(x.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
                 x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
                 if (!x.GetUniqueId || !x.CommInitRank || !x.Broadcast || !x.CommDestroy) throw StateError("RCCL symbols missing");
                 return x;
@@ -398,6 +389,45 @@ public:
             HIP_CHECK(hipStreamSynchronize(st_));
         }
         if (comm_rank_ != root) set_conditioning(key, bcast_buf_.as<float>(), bcast_buf_.as<float>() + kCond, true);
+    }
+
+    // what the communicator itself reports (not the values comm_init was called with)
+    void comm_info(int32_t* n_ranks, int32_t* rank) {
+        std::lock_guard<std::mutex> gl(gpu_mu_);
+        *n_ranks = 0;
+        *rank = -1;
+        if (!comm_) return;
+        AUR_REQUIRE(Rccl::get().CommCount && Rccl::get().CommUserRank, "RCCL: ncclCommCount / ncclCommUserRank missing");
+        int n = 0, r = -1;
+        Rccl::get().check(Rccl::get().CommCount(comm_, &n), "ncclCommCount");
+        Rccl::get().check(Rccl::get().CommUserRank(comm_, &r), "ncclCommUserRank");
+        *n_ranks = n;
+        *rank = r;
+    }
+    // FNV-1a over the voice's conditioning as registered in device memory
+    uint64_t conditioning_checksum(uint64_t key) {
+        constexpr int kCond = 32 * kHidden;
+        std::vector<float> h((size_t)kCond + 512);
+        {
+            std::lock_guard<std::mutex> gl(gpu_mu_);
+            use();
+            int row;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                row = speaker_row(key, false);
+            }
+            if (row < 0) throw InvalidArgument("conditioning_checksum: unknown speaker_key");
+            HIP_CHECK(hipMemcpyAsync(h.data(), spk_table_.as<float>() + (long)row * kCond, (size_t)kCond * 4, hipMemcpyDeviceToHost, st_));
+            HIP_CHECK(hipMemcpyAsync(h.data() + kCond, spk_emb_.as<float>() + (long)row * 512, 512 * 4, hipMemcpyDeviceToHost, st_));
+            HIP_CHECK(hipStreamSynchronize(st_));
+        }
+        uint64_t x = 1469598103934665603ull;
+        const unsigned char* b = reinterpret_cast<const unsigned char*>(h.data());
+        for (size_t i = 0; i < h.size() * 4; ++i) {
+            x ^= b[i];
+            x *= 1099511628211ull;
+        }
+        return x;
     }
 
     bool has_conditioning(uint64_t key) {
@@ -472,7 +502,7 @@ public:
             }
         }
         RowWs& w = ws_[0];
-        graph_active_.clear();
+        last_active_.clear();
         const int S = cfg_.max_seqs;
         std::vector<int4> desc;
         std::vector<int> row_slot(32, S), row_pos(32);
@@ -577,7 +607,7 @@ public:
         (void)hipGetLastError();
         infl_.on = false;
         just_finished_.clear();
-        graph_active_.clear();
+        last_active_.clear();
         n_gemm_events_ = 0;
         n_conv_events_ = 0;
         gemm_prof_now_ = false;
@@ -601,11 +631,12 @@ public:
             if (s) fail(s);
         for (Seq* s : voc_queue_) fail(s);
         voc_queue_.clear();
-        if (voc_active_) {
-            for (Seq* s : voc_batch_)
-                if (s->state != SeqState::DONE) fail(s);
-            if (voc_block_) voc_block_->refs--;
-        }
+        // the vocoder batch, whether it had been launched completely (voc_active_) or the throw came from inside voc_launch
+        // after the sequences had left the queue
+        for (Seq* s : voc_batch_)
+            if (s->state != SeqState::DONE) fail(s);
+        if (voc_block_held_ && voc_block_) voc_block_->refs--;
+        voc_block_held_ = false;
         voc_batch_.clear();
         voc_active_ = false;
     }
@@ -766,34 +797,18 @@ public:
     }
 
     // ------------------------------------------------------------------ debug entry points
-    void dbg_gemm(const float* X, const float* Wm, float* out, int M, int N, int K, int kw) {
+    // prefill-regime GEMM (gemm_tile_kernel) on host data: out = X @ W
+    void dbg_gemm(const float* X, const float* Wm, float* out, int M, int N, int K) {
         use();
-        GemmPlan pl = gemm_plan(M, K);
-        if (kw == 1) {   // kw == 1: force the split (one slab per slice) form; kw == 2: force the fused form
-            pl.fused = false; pl.slabs = pl.slices;
-        } else if (kw == 2) {
-            pl.fused = true; pl.slabs = 1;
-        }
-        if (kw == 3) {   // kw == 3: the prefill-regime LDS-tiled kernel
-            pl.tile = true; pl.slabs = 1;
-        }
-        const int S = pl.slabs;
-        DevBuf dx, dw, dp, dout;
+        DevBuf dx, dw, dp;
         dx.ensure((size_t)M * K * 4);
         dw.ensure((size_t)K * N * 4);
-        dp.ensure((size_t)S * M * N * 4);
+        dp.ensure((size_t)M * N * 4);
         HIP_CHECK(hipMemcpy(dx.p, X, (size_t)M * K * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(dw.p, Wm, (size_t)K * N * 4, hipMemcpyHostToDevice));
-        if (pl.tile) launch_gemm_tile(dx.as<float>(), K, dw.as<float>(), dp.as<float>(), M, N, K, st_);
-        else launch_gemm_splitk(dx.as<float>(), K, dw.as<float>(), dp.as<float>(), M, N, K, pl, st_);
+        launch_gemm_tile(dx.as<float>(), K, dw.as<float>(), dp.as<float>(), M, N, K, st_);
         HIP_CHECK(hipStreamSynchronize(st_));
-        std::vector<float> hp((size_t)S * M * N);
-        HIP_CHECK(hipMemcpy(hp.data(), dp.p, hp.size() * 4, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < (size_t)M * N; ++i) {
-            float t = hp[i];
-            for (int s = 1; s < S; ++s) t += hp[(size_t)s * M * N + i];
-            out[i] = t;
-        }
+        HIP_CHECK(hipMemcpy(out, dp.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     }
     // decode-regime GEMM on host data: out = epi(LN?(X) @ W + bias); W is the plain [K][N] matrix, packed on the device by
     // the same pack_wt16 the engine uses at load time.  epi: 0 bias, 1 bias + gelu_new, 2 out += (X @ W + bias).
@@ -1054,7 +1069,7 @@ private:
             layers_.push_back(l);
         }
         packed_.clear();
-        if (rows_gemm_) {
+        {
             for (auto& l : layers_) {
                 l.tqkv = folded_copy(l.wqkv, l.ln1w, l.ln1b, l.bqkv, H, 3 * H, &l.qkv_c1, &l.qkv_c2);
                 l.tproj = packed_copy(l.wproj, H, H, H);
@@ -1068,7 +1083,7 @@ private:
         fnw_ = W("final_norm.w", H); fnb_ = W("final_norm.b", H);
         headT_ = W("mel_head.wT", (int64_t)H * kHeadPad);
         headb_ = W("mel_head.b", kHeadPad);
-        thead_ = rows_gemm_ ? packed_copy(headT_, kHeadPad, H, kHeadPad) : nullptr;
+        thead_ = packed_copy(headT_, kHeadPad, H, kHeadPad);
         HIP_CHECK(hipStreamSynchronize(st_));
         fold_scratch_.release();
         text_emb_ = W("text_emb");
@@ -1080,7 +1095,7 @@ private:
     }
     void ensure_rows(RowWs& w, int M) {
         if (M <= w.rows_cap) return;
-        graph_active_.clear();   // buffers move: a captured decode graph is stale
+        last_active_.clear();   // buffers move: the row indices have to be uploaded again
         const int cap = (std::max(M, 64) + 63) / 64 * 64;   // whole 64-row groups: the decode chain keeps its rows packed (pk_off)
         w.ybuf.ensure((size_t)cap * kHidden * 4);
         w.stats.ensure((size_t)cap * 64 * sizeof(float2));
@@ -1090,38 +1105,14 @@ private:
         w.qbuf.ensure((size_t)cap * kHidden * 4);
         w.att.ensure((size_t)cap * kHidden * 4);
         w.act.ensure((size_t)cap * 4 * kHidden * 4);
-        // slabs: small M uses split-K (<=16 slabs of M x 1024 or 4 slabs of M x 4096), large M one slab
-        const size_t slab = std::max((size_t)16 * std::min(cap, 128) * 4096, (size_t)cap * 4096);
-        w.P.ensure(slab * 4);
+        w.P.ensure((size_t)cap * 4096 * 4);   // one GEMM output slab (prefill)
         w.i_row_slot.ensure((size_t)cap * 4);
         w.i_row_pos.ensure((size_t)cap * 4);
         w.i_desc.ensure((size_t)cap * sizeof(int4));
         w.rows_cap = cap;
     }
-    // profile mode: HIP-event pairs around the GEMM launches of every 16th decode step (sampled: 121 per step)
-    bool gemm(RowWs& w, const float* X, int ldx, const float* Wm, float* P, int M, int N, int K, const GemmPlan& pl,
-              const GemmGelu* gelu = nullptr) {
-        if (pl.tile) {
-            launch_gemm_tile(X, ldx, Wm, P, M, N, K, w.st, gelu);
-            return gelu != nullptr;
-        }
-        if (!gemm_prof_now_) return launch_gemm_splitk(X, ldx, Wm, P, M, N, K, pl, w.st, gelu);
-        if (n_gemm_events_ == gemm_events_.size()) {
-            ConvEvent e{};
-            HIP_CHECK(hipEventCreate(&e.a));
-            HIP_CHECK(hipEventCreate(&e.b));
-            gemm_events_.push_back(e);
-        }
-        ConvEvent& ev = gemm_events_[n_gemm_events_++];
-        ev.kind = -1;
-        ev.flops = 2.0 * M * N * K;
-        ev.bytes = 4.0 * ((double)K * N + (double)M * K + (double)M * N);   // weights + X + Y (the split-K slabs are implementation traffic)
-        HIP_CHECK(hipEventRecord(ev.a, w.st));
-        const bool applied = launch_gemm_splitk(X, ldx, Wm, P, M, N, K, pl, w.st, gelu);
-        HIP_CHECK(hipEventRecord(ev.b, w.st));
-        return applied;
-    }
-    // decode-regime GEMM launch (gemm_rows_kernel) with the same sampled event timing.  Algorithmic bytes of a launch:
+    // decode-regime GEMM launch (gemm_rows_kernel); profile mode: HIP-event pairs around the launches of every 16th decode
+    // step.  Algorithmic bytes of a launch:
     // weights once + the activation rows once + the output tile once (the residual epilogue reads and writes it).
     ConvEvent& prof_event(int kind, double flops, double bytes) {
         if (n_gemm_events_ == gemm_events_.size()) {
@@ -1178,7 +1169,7 @@ private:
             gemm_rows(w, a, false, kEpiResidual, 1);
             a = GemmRowsArgs{};
             a.M = M; a.prec = gemm_prec_; a.eps = 1e-5f; a.X = h; a.xmt = mtt; a.Wt = L.tfc; a.N = 4 * kHidden; a.K = kHidden; a.bias = L.fc_c2;
-            a.ln_c1 = L.fc_c1; a.stats_in = w.stats.as<float2>(); a.out = w.act.as<float>(); a.omt = mtt;
+            a.ln_c1 = L.fc_c1; a.stats_in = w.stats.as<float2>(); a.out = w.act.as<float>(); a.omt = mtt; a.gelu_erf = cfg_.gelu_erf ? 1 : 0;
             gemm_rows(w, a, true, kEpiBiasGelu, 2);
             a = GemmRowsArgs{};
             a.M = M; a.prec = gemm_prec_; a.X = w.act.as<float>(); a.xmt = mtt; a.Wt = L.tproj2; a.N = kHidden; a.K = 4 * kHidden; a.bias = L.bproj2;
@@ -1234,41 +1225,29 @@ private:
         }
         n_gemm_events_ = 0;
     }
+    // Prompt rows (prefill, speaker prefix, literal second pass): explicit row positions, exact-f32 LDS-tiled GEMMs (one slab, k
+    // ascending for every M => a prompt's rows do not depend on what else was admitted), separate LayerNorm launches.
     void forward_rows(RowWs& w, int M, const int* d_row_slot, const int* d_row_pos) {
         float* h = w.h.as<float>();
         float* xn = w.xn.as<float>();
         float* P = w.P.as<float>();
         const int* bt = block_tables_.as<int>();
         const int* kvpos = slot_kvpos_.as<int>();
+        AUR_REQUIRE(d_row_pos != nullptr, "forward_rows: prompt rows carry explicit positions");
         launch_rows_ln(nullptr, 0, nullptr, h, layers_[0].ln1w, layers_[0].ln1b, xn, M, 1e-5f, w.st);
-        GemmPlan p1 = gemm_plan(M, kHidden), p4 = gemm_plan(M, 4 * kHidden);
-        // prefill-type calls (explicit row positions: prompt prefill, speaker prefix, literal second pass) run on the LDS-tiled
-        // GEMM whatever M is (one slab, k ascending for every M => a prompt's rows do not depend on what else was admitted);
-        // the round-1 decode chain (d_row_pos == nullptr, AUR_DECODE_GEMM=splitk) keeps the split-K kernel
-        const bool tile = tile_gemm_ && d_row_pos != nullptr;
-        if (tile) {
-            p1.tile = p4.tile = true;
-            p1.slabs = p4.slabs = 1;
-        }
-        const int S1 = p1.slabs, S4 = p4.slabs;
         for (int l = 0; l < cfg_.n_layer; ++l) {
             const LayerW& L = layers_[l];
             void* kvl = kv_layer(l);
-            gemm(w, xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, p1);
-            if (d_row_pos == nullptr) {   // decode (round-1 chain, fp32 K/V only): one fused launch
-                launch_qkv_attention_fused(P, S1, L.bqkv, (float*)kvl, d_row_slot, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st);
-            } else {
-                launch_qkv_epilogue(P, S1, L.bqkv, w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, w.st, kv_half_);
-                launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, 0, kv_half_);
-            }
-            gemm(w, w.att.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, p1);
-            launch_rows_ln(P, S1, L.bproj, h, L.ln2w, L.ln2b, xn, M, 1e-5f, w.st);
-            const GemmGelu ge{L.bfc, w.act.as<float>()};
-            if (!gemm(w, xn, kHidden, L.wfc, P, M, 4 * kHidden, kHidden, p1, fuse_gelu_ ? &ge : nullptr))
-                launch_bias_gelu(P, S1, L.bfc, w.act.as<float>(), M, 4 * kHidden, w.st);
-            gemm(w, w.act.as<float>(), 4 * kHidden, L.wproj2, P, M, kHidden, 4 * kHidden, p4);
+            launch_gemm_tile(xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, w.st);
+            launch_qkv_epilogue(P, 1, L.bqkv, w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, w.st, kv_half_);
+            launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, 0, kv_half_);
+            launch_gemm_tile(w.att.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, w.st);
+            launch_rows_ln(P, 1, L.bproj, h, L.ln2w, L.ln2b, xn, M, 1e-5f, w.st);
+            const GemmGelu ge{L.bfc, w.act.as<float>(), cfg_.gelu_erf ? 1 : 0};
+            launch_gemm_tile(xn, kHidden, L.wfc, P, M, 4 * kHidden, kHidden, w.st, &ge);
+            launch_gemm_tile(w.act.as<float>(), 4 * kHidden, L.wproj2, P, M, kHidden, 4 * kHidden, w.st);
             const bool last = (l + 1 == cfg_.n_layer);
-            launch_rows_ln(P, S4, L.bproj2, h, last ? lnfw_ : layers_[l + 1].ln1w, last ? lnfb_ : layers_[l + 1].ln1b,
+            launch_rows_ln(P, 1, L.bproj2, h, last ? lnfw_ : layers_[l + 1].ln1w, last ? lnfb_ : layers_[l + 1].ln1b,
                            xn, M, 1e-5f, w.st);
         }
     }
@@ -1301,7 +1280,7 @@ private:
         w.i_next_kvpos.ensure((size_t)std::max(Ms, 64) * 4);
         w.i_out_tok.ensure((size_t)std::max(Ms, 64) * 4);
         w.ybuf.ensure((size_t)std::max(Ms, 64) * kHidden * 4);
-        w.P2.ensure((size_t)4 * std::max(Ms, 64) * kHeadPad * 4);
+        w.P2.ensure((size_t)std::max(Ms, 64) * kHeadPad * 4);
         HIP_CHECK(hipMemcpyAsync(w.i_sample_row.p, sample_row.data(), (size_t)Ms * 4, hipMemcpyHostToDevice, w.st));
         HIP_CHECK(hipMemcpyAsync(w.i_sample_slot.p, sample_slot.data(), (size_t)Ms * 4, hipMemcpyHostToDevice, w.st));
         if (next_kvpos)
@@ -1310,9 +1289,8 @@ private:
     void sample_kernels(RowWs& w, int Ms, bool has_next_kvpos) {
         launch_final_norm(w.xn.as<float>(), w.i_sample_row.as<int>(), w.i_sample_slot.as<int>(), fnw_, fnb_, w.ybuf.as<float>(),
                           latents_.as<float>(), (long)kMaxLatRows * kHidden, slot_ngen_.as<int>(), kMaxLatRows, Ms, 1e-5f, w.st);
-        const GemmPlan ph = gemm_plan(Ms, kHidden);
-        gemm(w, w.ybuf.as<float>(), kHidden, headT_, w.P2.as<float>(), Ms, kHeadPad, kHidden, ph);
-        SamplerArgs a = sampler_args(w, w.P2.as<float>(), ph.slabs, Ms, kHeadPad, headb_, has_next_kvpos ? w.i_next_kvpos.as<int>() : nullptr);
+        launch_gemm_tile(w.ybuf.as<float>(), kHidden, headT_, w.P2.as<float>(), Ms, kHeadPad, kHidden, w.st);
+        SamplerArgs a = sampler_args(w, w.P2.as<float>(), 1, Ms, kHeadPad, headb_, has_next_kvpos ? w.i_next_kvpos.as<int>() : nullptr);
         launch_sampler(a, w.st);
     }
     // decode tail of the gemm_rows chain: rows are the live sequences in order (sample_row = identity), w.h holds the
@@ -1363,7 +1341,7 @@ private:
     // blocks, which are simply overwritten.  The default path (latent stash) never runs this.
     void second_pass(const std::vector<Seq*>& seqs) {
         RowWs& w = ws_[0];
-        graph_active_.clear();
+        last_active_.clear();
         std::vector<int4> desc;
         std::vector<int> row_slot, row_pos, lat_row0;
         for (Seq* s : seqs) {
@@ -1434,7 +1412,7 @@ private:
     }
     void prefill(const std::vector<Seq*>& seqs) {
         RowWs& w = ws_[0];
-        graph_active_.clear();   // prefill reuses chain 0's index buffers: the decode graph's inputs must be re-uploaded
+        last_active_.clear();   // prefill reuses the index buffers of the decode chain
         std::vector<int4> desc;
         std::vector<int> row_slot, row_pos, sample_row, sample_slot, next_kvpos;
         std::vector<SlotInit> init;
@@ -1481,22 +1459,15 @@ private:
         sample_collect(w, sample_slot);
         retire_finished();
     }
-    // One decode step.  The kernel chain of a step (embed -> 30 layers -> final_norm -> head GEMM -> sampler, ~250
-    // launches) depends only on device-resident state, so it is captured once per live-set shape in a hipGraph and
-    // replayed while the set of live slots is unchanged; only the token / finished read-back stays outside.
-    // AUR_DECODE_STREAMS=2 splits the live sequences into two chains on two streams inside the graph (the M = 32
-    // GEMMs are latency bound, the attention is bandwidth bound: the chains fill each other's gaps).
+    // One decode step: embed -> 30 x (QKV GEMM, attention, proj, FC, proj2) -> final norms -> head GEMM -> sampler, 154
+    // launches that depend only on device-resident state (hipGraph replay of the chain was measured within noise in round 2:
+    // the launches are already back to back).
     void decode_kernels(RowWs& w, int Mk) {
         launch_embed_decode(w.i_row_slot.as<int>(), slot_tok_.as<int>(), slot_pos_.as<int>(), wte_, wpe_, w.h.as<float>(), Mk, w.st,
-                            rows_gemm_ ? w.rows_cap / 16 : 0, rows_gemm_ ? w.stats.as<float2>() : nullptr,
-                            rows_gemm_ ? w.row_meta.as<int>() : nullptr, slot_kvpos_.as<int>(), block_tables_.as<int>(), kMaxBlocks);
-        if (rows_gemm_) {
-            forward_decode(w, Mk, w.i_row_slot.as<int>());
-            sample_kernels_decode(w, Mk);
-        } else {   // AUR_DECODE_GEMM=splitk: the round-1 chain (split-K slabs + LN / GELU epilogue launches), kept for A/B
-            forward_rows(w, Mk, w.i_row_slot.as<int>(), nullptr);
-            sample_kernels(w, Mk, false);
-        }
+                            w.rows_cap / 16, w.stats.as<float2>(), w.row_meta.as<int>(), slot_kvpos_.as<int>(),
+                            block_tables_.as<int>(), kMaxBlocks);
+        forward_decode(w, Mk, w.i_row_slot.as<int>());
+        sample_kernels_decode(w, Mk);
     }
     // ---- pipelined decode (default): the step's kernel chain depends only on device-resident state, so step s+1 is
     // enqueued BEFORE the host waits for the token / finished-flag read-back of step s (otherwise the GPU idles for the
@@ -1512,8 +1483,7 @@ private:
     InFlight launch_decode_step(const std::vector<int>& active) {
         RowWs& w = ws_[0];
         const int M = (int)active.size();
-        const bool same_set = (active == graph_active_ && graph_n_ws_ == 1);
-        if (!same_set) {
+        if (active != last_active_) {
             w.sample_slot = active;
             w.sample_row.resize(M);
             for (int i = 0; i < M; ++i) w.sample_row[i] = i;
@@ -1521,11 +1491,6 @@ private:
             HIP_CHECK(hipMemcpyAsync(w.i_row_slot.p, w.sample_slot.data(), (size_t)M * 4, hipMemcpyHostToDevice, st_));
             sample_upload(w, w.sample_row, w.sample_slot, nullptr);
             HIP_CHECK(hipStreamSynchronize(st_));   // pageable sources: the vectors may change before the copies run
-            graph_active_.clear();
-            same_set_streak_ = 0;
-            graph_ok_ = false;   // a captured graph belongs to another live set (or to buffers that have moved)
-        } else {
-            ++same_set_streak_;
         }
         InFlight f;
         f.on = true;
@@ -1533,22 +1498,6 @@ private:
         f.buf = rb_next_;
         rb_next_ ^= 1;
         f.profiled = cfg_.profile != 0 && (decode_step_count_++ % 16 == 0);
-        // hipGraph replay once the live set has been stable for a few steps (re-capturing ~250 nodes on every change of a
-        // ragged batch would cost more than it saves); profiled steps are launched directly so that their GEMMs carry events
-        const bool use_graph = decode_graph_ && !debug_sync() && !f.profiled && same_set_streak_ >= 3;
-        if (use_graph && !graph_ok_) {
-            if (graph_exec_) {
-                HIP_CHECK(hipGraphExecDestroy(graph_exec_));
-                graph_exec_ = nullptr;
-            }
-            hipGraph_t g = nullptr;
-            HIP_CHECK(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
-            decode_kernels(w, M);
-            HIP_CHECK(hipStreamEndCapture(st_, &g));
-            HIP_CHECK(hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0));
-            HIP_CHECK(hipGraphDestroy(g));
-            graph_ok_ = true;
-        }
         pin_rb_[f.buf].ensure(((size_t)cfg_.max_seqs * 2 + 16) * sizeof(int));
         // algorithmic bytes of this step: every live sequence's context (prompt + tokens so far, + 1 if the previous step is
         // still in flight) in K and V, all layers; the weights once
@@ -1560,18 +1509,13 @@ private:
         stats_.decode_kv_bytes += (kv_half_ ? 4.0 : 8.0) * kHidden * step_kv_tokens_ * cfg_.n_layer;
         stats_.decode_weight_bytes += 4.0 * ((double)cfg_.n_layer * 12.0 * kHidden * kHidden + (double)kHidden * kMelVocab);
         HIP_CHECK(hipEventRecord(ev_ds_[f.buf], st_));
-        if (use_graph) {
-            HIP_CHECK(hipGraphLaunch(graph_exec_, st_));
-        } else {
-            gemm_prof_now_ = f.profiled;
-            decode_kernels(w, M);
-            gemm_prof_now_ = false;
-        }
+        gemm_prof_now_ = f.profiled;
+        decode_kernels(w, M);
+        gemm_prof_now_ = false;
         HIP_CHECK(hipEventRecord(ev_de_[f.buf], st_));
         sample_readback(w, M, st_, pin_rb_[f.buf].as<int>());
         HIP_CHECK(hipEventRecord(ev_rb_[f.buf], st_));
-        graph_active_ = active;
-        graph_n_ws_ = 1;
+        last_active_ = active;
         return f;
     }
     void collect_decode_step(InFlight& f) {
@@ -1620,78 +1564,7 @@ private:
         if (infl_.on) collect_decode_step(infl_);
         retire_finished();
     }
-    void decode(const std::vector<int>& active) {
-        if (decode_streams_ < 2) {
-            decode_pipelined(active);
-            return;
-        }
-        // two-chain A/B mode (AUR_DECODE_STREAMS=2): one synchronous step per call
-        const int M = (int)active.size();
-        const int n_ws = (M >= 16) ? 2 : 1;
-        const bool same_set = (active == graph_active_ && n_ws == graph_n_ws_);
-        if (!same_set) {
-            for (int k = 0; k < n_ws; ++k) {
-                RowWs& w = ws_[k];
-                const int lo = (int)((long)M * k / n_ws), hi = (int)((long)M * (k + 1) / n_ws);
-                w.sample_slot.assign(active.begin() + lo, active.begin() + hi);
-                const int Mk = hi - lo;
-                w.sample_row.resize(Mk);
-                for (int i = 0; i < Mk; ++i) w.sample_row[i] = i;
-                ensure_rows(w, Mk);
-                HIP_CHECK(hipMemcpyAsync(w.i_row_slot.p, w.sample_slot.data(), (size_t)Mk * 4, hipMemcpyHostToDevice, st_));
-                sample_upload(w, w.sample_row, w.sample_slot, nullptr);
-            }
-            HIP_CHECK(hipStreamSynchronize(st_));
-            HIP_CHECK(hipStreamSynchronize(st2_));
-            graph_active_.clear();   // any cached graph was captured for another live set / other buffers
-        }
-        const bool use_graph = decode_graph_ && !debug_sync();
-        if (use_graph && (!same_set || !graph_exec_)) {
-            if (graph_exec_) {
-                HIP_CHECK(hipGraphExecDestroy(graph_exec_));
-                graph_exec_ = nullptr;
-            }
-            hipGraph_t g = nullptr;
-            HIP_CHECK(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
-            if (n_ws == 2) {
-                HIP_CHECK(hipEventRecord(ev_fork_, st_));
-                HIP_CHECK(hipStreamWaitEvent(st2_, ev_fork_, 0));
-            }
-            for (int k = 0; k < n_ws; ++k) decode_kernels(ws_[k], (int)ws_[k].sample_slot.size());
-            if (n_ws == 2) {
-                HIP_CHECK(hipEventRecord(ev_ws1_, st2_));
-                HIP_CHECK(hipStreamWaitEvent(st_, ev_ws1_, 0));
-            }
-            HIP_CHECK(hipStreamEndCapture(st_, &g));
-            HIP_CHECK(hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0));
-            HIP_CHECK(hipGraphDestroy(g));
-            graph_active_ = active;
-            graph_n_ws_ = n_ws;
-        }
-        if (use_graph) {
-            HIP_CHECK(hipGraphLaunch(graph_exec_, st_));
-        } else {
-            gemm_prof_now_ = cfg_.profile != 0 && (decode_step_count_++ % 16 == 0);
-            for (int k = 0; k < n_ws; ++k) decode_kernels(ws_[k], (int)ws_[k].sample_slot.size());
-            gemm_prof_now_ = false;
-            if (n_ws == 2) {
-                HIP_CHECK(hipEventRecord(ev_ws1_, st2_));
-                HIP_CHECK(hipStreamWaitEvent(st_, ev_ws1_, 0));
-            }
-            graph_active_ = active;
-            graph_n_ws_ = n_ws;
-        }
-        for (int k = 0; k < n_ws; ++k) sample_readback(ws_[k], (int)ws_[k].sample_slot.size(), st_);
-        HIP_CHECK(hipEventRecord(ev_b_, st_));
-        HIP_CHECK(hipStreamSynchronize(st_));
-        float ms = 0.f;
-        HIP_CHECK(hipEventElapsedTime(&ms, ev_a_, ev_b_));
-        stats_.gpt_ms += ms;
-        collect_gemm_events();
-        for (int k = 0; k < n_ws; ++k) sample_collect(ws_[k], ws_[k].sample_slot);
-        retire_finished();
-        stats_.decode_rows += M;
-    }
+    void decode(const std::vector<int>& active) { decode_pipelined(active); }
 
     // ------------------------------------------------------------------ vocoder
     void ensure_voc() {
@@ -1822,7 +1695,7 @@ private:
                 for (int c = 0; c < 3; ++c) {
                     const float* r = (c == 0) ? A : Cb;
                     // rounds 1 and 2: the first conv reads the fp16 activated copy the previous round's second conv left in Ch
-                    const bool c1_h = xt_f16_ && act2_ && c > 0;
+                    const bool c1_h = xt_f16_ && c > 0;
                     ConvArgs b1{};
                     b1.base_len = d_len; b1.B = B;
                     b1.x = c1_h ? reinterpret_cast<const float*>(Ch) : r; b1.x_f16 = c1_h ? 1 : 0; b1.wp = v_c1_[i][j][c].wp; b1.wp16 = v_c1_[i][j][c].wp16; b1.bias = v_c1_[i][j][c].bias; b1.out = Bb;
@@ -1833,7 +1706,7 @@ private:
                     conv(b1, rk[j], rd[c], totT * mul_out, totT * mul_out);
                     ConvArgs b2 = b1;
                     b2.out_act_f16 = 0; b2.x_f16 = xt_f16_ ? 1 : 0;
-                    if (xt_f16_ && act2_ && c < 2) { b2.act2 = Ch; b2.act2_slope = 0.1f; }
+                    if (xt_f16_ && c < 2) { b2.act2 = Ch; b2.act2_slope = 0.1f; }
                     b2.x = Bb; b2.wp = v_c2_[i][j][c].wp; b2.wp16 = v_c2_[i][j][c].wp16; b2.bias = v_c2_[i][j][c].bias; b2.res = r;
                     b2.padl = (rk[j] - 1) / 2;
                     if (c < 2) {
@@ -1874,7 +1747,10 @@ private:
                 voc_block_ = result_blocks_.back().get();
             }
             voc_block_->refs = 1;   // held by the in-flight batch
+            voc_block_held_ = true;
         }
+        if (fail_at_voc_ > 0 && --fail_at_voc_ == 0)   // AUR_TEST_FAIL_VOC=n: fault injection inside the n-th vocoder launch
+            throw HipError("injected failure (AUR_TEST_FAIL_VOC)");
         voc_block_->buf.ensure((size_t)B * voc_max_samples_ * 4 + (cfg_.return_latents ? (size_t)B * kMaxLatRows * kHidden * 4 : 0));
         HIP_CHECK(hipStreamWaitEvent(st_voc_, ev_lat_, 0));   // latents parked by the main stream
         run_vocoder(B, voc_nl_, latpool_.as<float>(), (long)kMaxLatRows * kHidden, &rows, cond, tmp_wav_.as<float>(),
@@ -1930,6 +1806,7 @@ private:
         {
             std::lock_guard<std::mutex> lk(mu_);
             voc_block_->refs--;   // the batch's own hold
+            voc_block_held_ = false;
         }
         voc_batch_.clear();
         voc_active_ = false;
@@ -1948,8 +1825,8 @@ private:
     int gemm_prec_ = 1;                             // GemmRowsArgs.prec of every decode GEMM (aur_config.gemm_f32_exact)
     const float* thead_ = nullptr;
     int fail_at_step_ = 0;              // AUR_TEST_FAIL_STEP=n: throw inside the n-th aur_step (recovery test)
-    bool tile_gemm_ = true;             // AUR_PREFILL_GEMM=splitk selects the round-1 fused-slice kernel for prefill-type GEMMs
-    bool rows_gemm_ = true;             // AUR_DECODE_GEMM=splitk selects the round-1 decode chain
+    int fail_at_voc_ = 0;               // AUR_TEST_FAIL_VOC=n: throw inside the n-th vocoder launch, after the batch left the queue
+    bool voc_block_held_ = false;       // the vocoder batch holds a reference on voc_block_
     const float *wte_ = nullptr, *wpe_ = nullptr, *lnfw_ = nullptr, *lnfb_ = nullptr, *fnw_ = nullptr, *fnb_ = nullptr,
                 *headT_ = nullptr, *headb_ = nullptr, *text_emb_ = nullptr, *text_pos_ = nullptr;
     int text_vocab_ = 0, text_positions_ = 0;
@@ -1998,21 +1875,11 @@ private:
     PinBuf pin_rb_[2];
     hipEvent_t ev_rb_[2] = {nullptr, nullptr}, ev_ds_[2] = {nullptr, nullptr}, ev_de_[2] = {nullptr, nullptr};
     int rb_next_ = 0;
-    bool fuse_gelu_ = true;             // AUR_FUSE_GELU=0: separate bias_gelu launch after the prefill FC GEMM too (A/B)
     bool sampler_full_sort_ = false;    // AUR_SAMPLER_FULL_SORT=1: disable the sampler's top-k fast path (A/B)
     bool pipeline_ = true;              // AUR_DECODE_PIPELINE=0: wait for every read-back before launching the next step
     bool xt_f16_ = false;               // set in the constructor: fp16 vocoder => fp16 c1 -> c2 intermediate (AUR_XT_F16=0 disables)
-    int same_set_streak_ = 0;
-    bool graph_ok_ = false;             // graph_exec_ was captured for the current live set and buffers
-    bool decode_graph_ = false;         // AUR_DECODE_GRAPH=1: replay the decode step as a hipGraph once the live set has been
-                                        // stable for 3 steps (measured within noise of direct launches: 872.6/876.5 vs 880.0/869.5 ms)
-    hipGraphExec_t graph_exec_ = nullptr;
-    std::vector<int> graph_active_;
-    int graph_n_ws_ = 0;
-    hipEvent_t ev_fork_ = nullptr;
-    int decode_streams_ = 1;   // 2 measured slower on MI355X (host launch bound without graphs); kept for A/B via AUR_DECODE_STREAMS
+    std::vector<int> last_active_;      // live slots whose row indices are resident in the decode chain's index buffers
     hipStream_t st2_ = nullptr;
-    hipEvent_t ev_ws1_ = nullptr;
     DevBuf i_init_;
     DevBuf dbg_lnf_, dbg_logits_;
     bool dbg_capture_ = false;
@@ -2020,7 +1887,6 @@ private:
     ConvLayer v_pre_, v_ups_[4], v_c1_[4][3][3], v_c2_[4][3][3];
     const float* v_post_ = nullptr;
     DevBuf v_meta_, v_z_, v_s0_, v_A_, v_B_, v_C_, v_D_, v_E_, v_Ch_, tmp_lat_, tmp_wav_;
-    bool act2_ = true;                  // AUR_VOC_ACT2=0: first convs of rounds 1, 2 read the fp32 residual stream (A/B)
     std::vector<ConvEvent> conv_events_;
     std::vector<ConvEvent> gemm_events_;
     size_t n_gemm_events_ = 0;
@@ -2133,6 +1999,17 @@ int aur_broadcast_conditioning(aur_engine* e, uint64_t key, int32_t root) {
     CHECK_PTR(e);
     return guarded([&] { e->impl.broadcast_conditioning(key, root); });
 }
+int aur_comm_info(aur_engine* e, int32_t* n_ranks, int32_t* rank) {
+    CHECK_PTR(e);
+    CHECK_PTR(n_ranks);
+    CHECK_PTR(rank);
+    return guarded([&] { e->impl.comm_info(n_ranks, rank); });
+}
+int aur_conditioning_checksum(aur_engine* e, uint64_t key, uint64_t* out) {
+    CHECK_PTR(e);
+    CHECK_PTR(out);
+    return guarded([&] { *out = e->impl.conditioning_checksum(key); });
+}
 int aur_compute_conditioning(aur_engine* e, const float* const* pcm, const int32_t* n_samples, int32_t n_refs, const aur_cond_params* p,
                              float* out_gpt_cond, float* out_spk_emb) {
     CHECK_PTR(e);
@@ -2184,23 +2061,9 @@ int aur_reset_stats(aur_engine* e) {
     CHECK_PTR(e);
     return guarded([&] { e->impl.reset_stats(); });
 }
-int aur_dbg_gemm_tile_map(int32_t gx, int32_t gy, int32_t gz, int32_t group, int32_t* out3) {
-    CHECK_PTR(out3);
-    return guarded([&] {
-        AUR_REQUIRE(gx > 0 && gy > 0 && gz > 0 && group >= 0, "tile map: grid");
-        const int n = gx * gy * gz;
-        for (int L = 0; L < n; ++L) {
-            int nt, sl, mt;
-            aur::gemm_tile_map(L, gx, gy, gz, group, nt, sl, mt);
-            out3[3 * L] = nt;
-            out3[3 * L + 1] = sl;
-            out3[3 * L + 2] = mt;
-        }
-    });
-}
-int aur_dbg_gemm(aur_engine* e, const float* X, const float* W, float* out, int32_t M, int32_t N, int32_t K, int32_t kw) {
+int aur_dbg_gemm(aur_engine* e, const float* X, const float* W, float* out, int32_t M, int32_t N, int32_t K) {
     CHECK_PTR(e);
-    return guarded([&] { e->impl.dbg_gemm(X, W, out, M, N, K, kw); });
+    return guarded([&] { e->impl.dbg_gemm(X, W, out, M, N, K); });
 }
 int aur_dbg_gemm_rows(aur_engine* e, const float* X, const float* W, const float* bias, const float* gamma, const float* beta,
                       float* out, int32_t M, int32_t N, int32_t K, int32_t epi, int32_t ln) {

@@ -10,71 +10,13 @@ constexpr int kHeadDim = 64;
 constexpr int kKvBlockTokens = 16;                                    // paged-KV block size (vLLM default)
 constexpr long kKvBlockElems = 2L * kHeads * kKvBlockTokens * kHeadDim;  // one layer, K and V
 
-// Split-K weight-streaming GEMM on exact-f32 MFMA (16x16x4):
-//   P[s][m][n] = sum_{k in slice s} X[m][k] * W[k][n],   W row-major [K][N] (HF Conv1D layout on disk)
-// N % 64 == 0, kw % 16 == 0.  P is [slabs][M][N] (see GemmPlan).
-struct GemmPlan {
-    int kw;      // K per wave (4 waves per workgroup => slices of 4*kw)
-    int slices;  // K / (4*kw)
-    bool fused;  // slice loop inside the kernel (one output slab) instead of one slab per slice
-    int slabs;   // slabs the epilogue has to sum
-    bool tile = false;   // prefill-regime LDS-tiled kernel (launch_gemm_tile) instead of the split-K kernel; slabs == 1
-};
-GemmPlan gemm_plan(int M, int K);
-
-// Workgroup -> (column tile, K-slice, M-tile) of the split-K GEMM.  Workgroups are dispatched x-fastest and consecutive ids
-// go to consecutive XCDs, so ids that are 8 apart share an XCD (one L2):
-//  * nw = gx*gy weight tiles, a multiple of 8: each XCD owns nw/8 weight tiles and walks all gz M-tiles of one weight tile
-//    back to back (the weight tile leaves HBM once);
-//  * group > 0 (experiment, fused-slice plan with many M-tiles): the XCD walks its weight tiles inside blocks of `group`
-//    M-tiles, so that the activation rows of a block (group*32 rows) stay in L2 across the XCD's weight tiles instead of
-//    being re-fetched once per weight tile;
-//  * otherwise the plain order.
-// Any bijection is correct; results do not depend on it.
-__host__ __device__ inline void gemm_tile_map(int L, int gx, int gy, int gz, int group, int& ntile, int& slice, int& mtile) {
-    const int nw = gx * gy;
-    int wt;
-    if ((nw & 7) == 0) {
-        const int xcd = L & 7, slot = L >> 3, n_loc = nw >> 3;
-        if (group > 0 && group < gz) {
-            const int full = gz / group, per = n_loc * group;
-            int mg, wl, mi;
-            if (slot < full * per) {
-                mg = slot / per;
-                const int r = slot - mg * per;
-                wl = r / group;
-                mi = r - wl * group;
-            } else {
-                const int gt = gz - full * group, r = slot - full * per;
-                mg = full;
-                wl = r / gt;
-                mi = r - wl * gt;
-            }
-            mtile = mg * group + mi;
-            wt = wl * 8 + xcd;
-        } else {
-            mtile = slot % gz;
-            wt = (slot / gz) * 8 + xcd;
-        }
-    } else {
-        mtile = L / nw;
-        wt = L - mtile * nw;
-    }
-    ntile = wt % gx;
-    slice = wt / gx;
-}
-// Optional bias + gelu_new epilogue of the FC GEMM, fused-slice plan only (M > 128, i.e. prefill): the totals are in
-// registers, so act[m][n] = gelu_new(total + bias[n]) is written instead of the slab (same arithmetic order as
-// launch_bias_gelu on the slabs).  The split plan keeps the separate launch: a last-arriver tail inside the GEMM was
-// measured (r01): with agent-scope fences (buffer_wbl2/buffer_inv per workgroup) the step got 20 % slower, with
-// workgroup-scope fences it gained 0.5 % but is only correct while all K-slices of a tile share one XCD's L2.
+// Optional bias + GELU epilogue of the prefill FC GEMM: act[m][n] = gelu(total + bias[n]) is written instead of the slab.
+// erf: 1 = erf form (config.json "activation_function": "gelu"), 0 = tanh form ("gelu_new").
 struct GemmGelu {
     const float* bias;
     float* act;
+    int erf;
 };
-// returns true when the gelu tail was applied (false: caller runs launch_bias_gelu on the slabs)
-bool launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M, int N, int K, const GemmPlan& pl,
-                        hipStream_t st, const GemmGelu* gelu = nullptr);
 
 // ---- decode-regime GEMM (M = live sequences; every weight leaves HBM once per step) ---------------------------------
 // One workgroup = 16 waves = one [16*MT rows] x [16 columns] output tile over the FULL K: wave w owns K-slice
@@ -159,9 +101,6 @@ void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, 
 void launch_rows_ln(const float* P, int S, const float* bias, float* h, const float* gamma, const float* beta,
                     float* out, int M, float eps, hipStream_t st);
 
-// act[m][n] = gelu_new(sum_s P[s][m][n] + bias[n])
-void launch_bias_gelu(const float* P, int S, const float* bias, float* act, int M, int N, hipStream_t st);
-
 // qkv = sum_s P[s] + bias;  q -> qbuf[m][1024];  k,v -> paged cache of this layer at (slot, pos)
 // kv_half (here and below): the pool stores fp16 K/V (same [block][K|V][head][16][64] layout, half the bytes); values are
 // rounded to nearest on the way in, scores / softmax / P.V stay fp32
@@ -174,12 +113,6 @@ void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, 
 void launch_paged_attention(const float* qbuf, const void* kv_layer, const int* row_slot, const int* row_pos,
                             const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
                             hipStream_t st, int out_mtt = 0, bool kv_half = false, const int* row_meta = nullptr);
-
-// decode rows (one new token per sequence): qkv epilogue + KV page write + attention in one launch, reading the QKV
-// GEMM slabs directly (bitwise the same result as launch_qkv_epilogue + launch_paged_attention)
-void launch_qkv_attention_fused(const float* P, int S, const float* bias, float* kv_layer, const int* row_slot,
-                                const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
-                                hipStream_t st);
 
 // prompt rows: desc[m] = {kind, a, b, _}: kind 0 -> spk_cond[b][a][:], 1 -> text_emb[a]+text_pos[b], 2 -> wte[a]+wpe[b]
 void launch_embed_prompt(const int4* desc, const float* spk_cond, const float* text_emb, const float* text_pos,

@@ -15,16 +15,8 @@ __device__ __forceinline__ long kv_offset(int blk, int kv, int head, int tok) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Split-K weight-streaming GEMM.  One workgroup = 4 waves = one 64x64 output tile over a K-range of 4*kw;
-// wave w streams rows [kbeg + w*kw, +kw) of W straight from HBM into registers as float4 (16 lanes x 16 B =
-// one 256-B row segment, 4 rows per instruction) — no LDS round trip for an operand that is read once.
-// MFMA v_mfma_f32_16x16x4_f32 with a permuted K and N order so that the float4 loads ARE the fragments:
-//   step (s', c):  A[i][k'] = X[m][kb + 4k' + s'],  B[k'][j'] = W[kb + 4k' + s'][n0 + 4j' + c]
-//   D[i][j'] accumulates column n0 + 4j' + c, i.e. lane j' owns 4 consecutive columns across c = 0..3.
-// Sum of the S split-K partial slabs of one float4 column group plus the bias, in the fixed order
-// ((p[0] + p[1]) + ... + p[S-1]) + bias.  Loads go out four at a time at clamped slab indices (a counted loop of
-// dependent `t += load` made hipcc wait for every slab separately: S + 1 serialized round trips per consumer kernel);
-// the surplus lanes of the last group add 0.
+// Sum of S partial slabs of one float4 column group plus the bias, in the fixed order ((p[0] + p[1]) + ... + p[S-1]) + bias
+// (the prefill GEMM writes one slab, S == 1; S == 0 callers skip it).  Loads go out four at a time at clamped slab indices.
 __device__ __forceinline__ f32x4 slab_sum(const float* __restrict__ p0, long sstride, int S, const float* __restrict__ bias_n) {
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_n);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -40,163 +32,6 @@ __device__ __forceinline__ f32x4 slab_sum(const float* __restrict__ p0, long sst
         t += (s + 3 < S) ? d : zero;
     }
     return t + bv;
-}
-
-// MTW = 16-row MFMA tiles per wave: the workgroup owns a (16*MTW) x 64 output tile.  GELU (fused-slice plan only): the
-// register totals get bias + gelu_new and go to `act` instead of P.
-template <bool FUSED, int MTW, bool GELU>
-__global__ __launch_bounds__(256) void gemm_splitk_kernel(const float* __restrict__ X, int ldx,
-                                                          const float* __restrict__ W, float* __restrict__ P,
-                                                          int M, int N, int n_slices, GemmGelu ep, int tile_group) {
-    // 4 waves = the 4 K-quarters of one 256-deep slice.  Each wave streams its 64 weight rows x 64 columns once
-    // (16 float4 loads issued back to back, so one HBM latency covers the whole slice) and multiplies them with the
-    // tile's activation rows.  Reduction order per output element is ((k0 + k1) + k2) + k3, then slices in order.
-    constexpr int KW = 64;
-    constexpr int MR = 16 * MTW;
-    __shared__ __attribute__((aligned(16))) float red[3][MR][68];
-    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
-    const int i = lane & 15, q = lane >> 4;
-    int ntile, slice, mtile;   // XCD-aware tile order, see gemm_tile_map
-    gemm_tile_map(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y, gridDim.z, tile_group,
-                  ntile, slice, mtile);
-    const int n0 = ntile * 64, m0 = mtile * MR;
-    const int s_begin = FUSED ? 0 : slice, s_end = FUSED ? n_slices : slice + 1;
-
-    const float* xp[MTW];
-#pragma unroll
-    for (int mt = 0; mt < MTW; ++mt) {
-        const int r = m0 + 16 * mt + i;
-        xp[mt] = X + (long)(r < M ? r : 0) * ldx + 4 * q;   // rows >= M alias row 0: never stored
-    }
-    f32x4 total[MTW][4];
-
-    for (int s = s_begin; s < s_end; ++s) {
-        const int kbeg = (s * 4 + ks) * KW;
-        const float* wp = W + (long)(kbeg + 4 * q) * N + n0 + 4 * i;
-        f32x4 bf[4][4], af[4][MTW];
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-#pragma unroll
-            for (int sp = 0; sp < 4; ++sp)
-                bf[kb][sp] = *reinterpret_cast<const f32x4*>(wp + (long)(16 * kb + sp) * N);
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) af[kb][mt] = *reinterpret_cast<const f32x4*>(xp[mt] + kbeg + 16 * kb);
-        }
-        // keep every load above this line: hipcc otherwise sinks each load next to its first use and the wave
-        // pays one HBM round trip per load instead of one per slice
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 acc[MTW][4];
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[mt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int sp = 0; sp < 4; ++sp)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt)
-                        acc[mt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kb][mt][sp], bf[kb][sp][c], acc[mt][c], 0, 0, 0);
-        if (ks > 0) {
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * mt + 4 * q + r;
-                    f32x4 v = {acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
-                    *reinterpret_cast<f32x4*>(&red[ks - 1][row][4 * i]) = v;
-                }
-        }
-        __syncthreads();
-        if (ks == 0) {
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * mt + 4 * q + r;
-                    f32x4 v = {acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
-                    v += *reinterpret_cast<const f32x4*>(&red[0][row][4 * i]);
-                    v += *reinterpret_cast<const f32x4*>(&red[1][row][4 * i]);
-                    v += *reinterpret_cast<const f32x4*>(&red[2][row][4 * i]);
-                    if (FUSED) {
-                        total[mt][r] = (s == 0) ? v : total[mt][r] + v;
-                    } else if (m0 + row < M) {
-                        *reinterpret_cast<f32x4*>(P + ((long)s * M + m0 + row) * N + n0 + 4 * i) = v;
-                    }
-                }
-        }
-        if (FUSED) __syncthreads();   // LDS tiles consumed before the next slice overwrites them
-    }
-    if (FUSED && ks == 0) {
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (GELU) bv = *reinterpret_cast<const f32x4*>(ep.bias + n0 + 4 * i);
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * mt + 4 * q + r;
-                if (m0 + row < M) {
-                    if (GELU) {
-                        const f32x4 t = total[mt][r] + bv;
-                        f32x4 o;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) o[c] = gelu_new(t[c]);
-                        *reinterpret_cast<f32x4*>(ep.act + (long)(m0 + row) * N + n0 + 4 * i) = o;
-                    } else {
-                        *reinterpret_cast<f32x4*>(P + (long)(m0 + row) * N + n0 + 4 * i) = total[mt][r];
-                    }
-                }
-            }
-    }
-}
-
-// K is always cut into slices of 4*64; M <= 128 writes one slab per slice (more workgroups for the
-// weight-streaming decode regime), larger M fuses the slice loop in-kernel (one slab, same arithmetic order).
-GemmPlan gemm_plan(int M, int K) {
-    GemmPlan p;
-    p.kw = 64;
-    p.slices = K / (4 * p.kw);
-    p.fused = M > 128;
-    p.slabs = p.fused ? 1 : p.slices;
-    return p;
-}
-
-bool launch_gemm_splitk(const float* X, int ldx, const float* W, float* P, int M, int N, int K, const GemmPlan& pl,
-                        hipStream_t st, const GemmGelu* gelu) {
-    AUR_REQUIRE(N % 64 == 0 && pl.kw == 64 && K == pl.slices * 4 * pl.kw && ldx % 4 == 0, "gemm: shape");
-    trace_launch("gemm_splitk_kernel");
-    static const int mtw = [] {
-        const char* e = getenv("AUR_GEMM_MTW");
-        return (e && atoi(e) == 1) ? 1 : 2;
-    }();
-    // AUR_GEMM_GROUP=<g>: M-tile blocks of g in the fused-slice plan when the activation panel of a block fits an L2 next
-    // to the XCD's weight tiles (K = 1024: g = 8 -> 1 MB); experiment, default off (one r01 data point: no gain)
-    static const int group_env = [] {
-        const char* e = getenv("AUR_GEMM_GROUP");
-        return e ? atoi(e) : 0;
-    }();
-    const int group = (pl.fused && K <= 1024) ? group_env : 0;
-    const GemmGelu none{nullptr, nullptr};
-    bool applied = false;
-    if (pl.fused) {
-        dim3 grid(N / 64, 1, (M + 31) / 32);
-        if (gelu) {
-            hipLaunchKernelGGL((gemm_splitk_kernel<true, 2, true>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices, *gelu, group);
-            applied = true;
-        } else {
-            hipLaunchKernelGGL((gemm_splitk_kernel<true, 2, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices, none, group);
-        }
-    } else if (mtw == 1) {
-        dim3 grid(N / 64, pl.slices, (M + 15) / 16);
-        hipLaunchKernelGGL((gemm_splitk_kernel<false, 1, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices, none, 0);
-    } else {
-        dim3 grid(N / 64, pl.slices, (M + 31) / 32);
-        hipLaunchKernelGGL((gemm_splitk_kernel<false, 2, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, pl.slices, none, 0);
-    }
-    HIP_CHECK(hipGetLastError());
-    return applied;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -303,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const float* __restri
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (row < M) {
-                    if (GELU) ep.act[(long)row * N + col] = gelu_new(acc[mi][ni][r] + bv);
+                    if (GELU) ep.act[(long)row * N + col] = ep.erf ? gelu_erf(acc[mi][ni][r] + bv) : gelu_new(acc[mi][ni][r] + bv);
                     else P[(long)row * N + col] = acc[mi][ni][r];
                 }
             }
@@ -314,15 +149,11 @@ void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, 
                       const GemmGelu* gelu) {
     AUR_REQUIRE(N % 64 == 0 && K % 16 == 0 && ldx % 4 == 0 && M >= 1, "gemm_tile: shape");
     trace_launch("gemm_tile_kernel");
-    const GemmGelu none{nullptr, nullptr};
+    const GemmGelu none{nullptr, nullptr, 0};
     // N = 1024 GEMMs (attention and MLP projections): 128 x 128 tiles give 8 x ceil(M/128) workgroups — 288 for a 64-prompt
     // prefill, 1.1 per CU, half the chip idle in the second round — so they run on 64 x 64 tiles (1136 workgroups).  The k order
     // of every output element is the same for both shapes.
-    static const int small_env = [] {
-        const char* e = getenv("AUR_GEMM_TILE_SMALL_N");
-        return e ? atoi(e) : 1024;
-    }();
-    if (N <= small_env || N % 128 != 0) {
+    if (N <= 1024 || N % 128 != 0) {
         const dim3 grid((unsigned)((N / 64) * ((M + 63) / 64)));
         if (gelu) hipLaunchKernelGGL((gemm_tile_kernel<64, 64, true>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, K, *gelu);
         else hipLaunchKernelGGL((gemm_tile_kernel<64, 64, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, K, none);
@@ -674,18 +505,10 @@ static void launch_gemm_rows_mt(const GemmRowsArgs& a, int mt, int nw, hipStream
 //       activation rows once for three column tiles
 //   LN GEMMs, N = 4096 (FC) : 32 rows x 32 columns  -> 128 x ceil(M/32)
 //   N = 1024 (proj, proj2), head: 16 rows x 16 columns
-// AUR_GEMM_SHAPES=r02 restores the round-2 shapes (16 x 16 / 32 x 16 on 8 waves for the LN GEMMs) for A/B.
 GemmRowsShape gemm_rows_shape(int M, int N, int K, bool ln) {
-    static const bool r02 = [] {
-        const char* e = getenv("AUR_GEMM_SHAPES");
-        return e && e[0] == 'r';
-    }();
     GemmRowsShape s{1, 16, 1};
     if (ln) {
-        if (r02) {
-            s.nw = 8;
-            s.mt = (N >= 4096 && M > 16) ? 2 : 1;
-        } else if (N % 48 == 0 && N < 4096) {
+        if (N % 48 == 0 && N < 4096) {
             s.ntl = 3;
         } else if (N % 32 == 0) {
             s.ntl = 2;
@@ -771,28 +594,6 @@ void launch_rows_ln(const float* P, int S, const float* bias, float* h, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bias_gelu_kernel(const float* __restrict__ P, int S,
-                                                        const float* __restrict__ bias, float* __restrict__ act,
-                                                        int M, int N) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // float4 index
-    const long total = (long)M * N / 4;
-    if (idx >= total) return;
-    const int n = (int)((idx * 4) % N);
-    const f32x4 t = slab_sum(P + idx * 4, (long)M * N, S, bias + n);
-    f32x4 o;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) o[c] = gelu_new(t[c]);
-    *reinterpret_cast<f32x4*>(act + idx * 4) = o;
-}
-
-void launch_bias_gelu(const float* P, int S, const float* bias, float* act, int M, int N, hipStream_t st) {
-    const long total = (long)M * N / 4;
-    trace_launch("bias_gelu_kernel");
-    hipLaunchKernelGGL(bias_gelu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, S, bias, act, M, N);
-    HIP_CHECK(hipGetLastError());
-}
-
-// ------------------------------------------------------------------------------------------------
 
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x8g __attribute__((ext_vector_type(8)));
@@ -846,25 +647,16 @@ void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Paged causal attention: one workgroup per (row, head).  16 lanes x float4 span the 64-wide head; a wave
-// reads 4 consecutive cached tokens (1 KiB contiguous) per instruction; 4 waves stride the context.
-// Scores are reduced with wavefront shuffles; online softmax per 16-lane group; groups merged through LDS.
-// FUSED (decode rows only): the row's q/k/v come straight from the QKV GEMM slabs (+ bias); the block writes its own
-// k,v into the page and uses them from registers, so the separate qkv_epilogue launch disappears.  Token t is still
-// handled by the same lane group in the same iteration => bitwise the same result as the unfused pair.
-template <bool FUSED, bool KVH, bool PF = false, int UN = 4>
-__global__ __launch_bounds__(256) void paged_attention_kernel(const float* __restrict__ qbuf,
-                                                              void* __restrict__ kv_layer_v,
-                                                              const int* __restrict__ row_slot,
-                                                              const int* __restrict__ row_pos,
+// Paged causal attention: one workgroup per (row, head).  16 lanes x float4 (fp32 pool) or 8 lanes x 8 halves (fp16 pool) span
+// the 64-wide head, so one wave instruction covers 4 / 8 consecutive cached tokens (1 KiB contiguous); 4 waves stride the
+// context.  Scores are reduced with wavefront shuffles; online softmax per lane group; groups merged through LDS.
+template <bool KVH>
+__global__ __launch_bounds__(256) void paged_attention_kernel(const float* __restrict__ qbuf, const void* __restrict__ kv_layer_v,
+                                                              const int* __restrict__ row_slot, const int* __restrict__ row_pos,
                                                               const int* __restrict__ slot_kvpos,
                                                               const int* __restrict__ block_tables, int max_blocks,
-                                                              float* __restrict__ out, const float* __restrict__ P,
-                                                              int S, const float* __restrict__ bias, int M, int out_mtt,
-                                                              const int* __restrict__ row_meta) {
-    static_assert(!(FUSED && KVH), "the slab-fused decode path keeps fp32 K/V");
-    // every lane moves 16 B per cached token: 16 lanes x 4 floats (fp32 pool) or 8 lanes x 8 halves (fp16 pool) span the 64-wide
-    // head, so one wave instruction covers TPW = 4 or 8 consecutive tokens (1 KiB contiguous either way)
+                                                              float* __restrict__ out, int out_mtt, const int* __restrict__ row_meta) {
+    constexpr int UN = 4;                    // token steps in flight per workgroup iteration (8 measured slower: registers)
     constexpr int LPT = KVH ? 8 : 16;        // lanes per token
     constexpr int EPL = kHeadDim / LPT;      // elements per lane
     constexpr int TPW = 64 / LPT;            // tokens per wave instruction
@@ -892,41 +684,20 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
     // of predicated so that the loads can be hoisted).  The first batch goes out before q is assembled: it does not depend on q.
     // (the fp16 pool's values stay packed, 4 registers per 8 halves, until they are used: as floats they cost 104 VGPRs)
     using RawT = typename std::conditional<KVH, h16x8g, f32x4>::type;
-    RawT kraw[UN], vraw[UN], knext[UN], vnext[UN];
-    auto load_kv = [&](int t0, RawT (&kd)[UN], RawT (&vd)[UN]) {
+    RawT kraw[UN], vraw[UN];
+    auto load_kv = [&](int t0) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int t = min(t0 + 4 * TPW * u + wv * TPW + g, n_keys - 1);
             const int blk = bt[t / kKvBlockTokens];
             const long off = kv_offset(blk, 0, head, t % kKvBlockTokens) + dl * EPL;
-            kd[u] = *reinterpret_cast<const RawT*>(kv_layer + off);
-            vd[u] = *reinterpret_cast<const RawT*>(kv_layer + off + (long)kHeads * kKvBlockTokens * kHeadDim);
+            kraw[u] = *reinterpret_cast<const RawT*>(kv_layer + off);
+            vraw[u] = *reinterpret_cast<const RawT*>(kv_layer + off + (long)kHeads * kKvBlockTokens * kHeadDim);
         }
     };
-    load_kv(0, kraw, vraw);
-    float qv[EPL], own_k[EPL], own_v[EPL];
-#pragma unroll
-    for (int c = 0; c < EPL; ++c) own_k[c] = own_v[c] = 0.f;
-    if constexpr (FUSED) {
-        constexpr int N = 3 * kHidden;
-        const int col = head * kHeadDim + dl * 4;
-        const float* p0 = P + (long)m * N + col;
-        const f32x4 q4 = slab_sum(p0, (long)M * N, S, bias + col);
-        const f32x4 k4 = slab_sum(p0 + kHidden, (long)M * N, S, bias + kHidden + col);
-        const f32x4 v4 = slab_sum(p0 + 2 * kHidden, (long)M * N, S, bias + 2 * kHidden + col);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            qv[c] = q4[c];
-            own_k[c] = k4[c];
-            own_v[c] = v4[c];
-        }
-        if (wv == 0 && g == 0) {
-            float* kvw = reinterpret_cast<float*>(kv_layer_v);
-            const long off = kv_offset(bt[pos / kKvBlockTokens], 0, head, pos % kKvBlockTokens) + dl * 4;
-            *reinterpret_cast<f32x4*>(kvw + off) = k4;
-            *reinterpret_cast<f32x4*>(kvw + off + (long)kHeads * kKvBlockTokens * kHeadDim) = v4;
-        }
-    } else {
+    load_kv(0);
+    float qv[EPL];
+    {
         const float* qp = qbuf + (long)m * kHidden + head * kHeadDim + dl * EPL;
 #pragma unroll
         for (int c4 = 0; c4 < EPL / 4; ++c4) {
@@ -941,14 +712,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
     for (int c = 0; c < EPL; ++c) o[c] = 0.f;
     constexpr int STEP = 4 * TPW * UN;   // tokens per workgroup iteration
     for (int t0 = 0; t0 < n_keys; t0 += STEP) {
-        // the next iteration's loads are in flight while this one is reduced (one memory round trip per iteration was
-        // exposed before: the workgroups of a CU only partly covered for each other)
-        const bool more = PF && t0 + STEP < n_keys;
-        if (PF) {
-            if (more) load_kv(t0 + STEP, knext, vnext);
-        } else if (t0 > 0) {
-            load_kv(t0, kraw, vraw);
-        }
+        if (t0 > 0) load_kv(t0);
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int t = t0 + 4 * TPW * u + wv * TPW + g;
@@ -958,13 +722,6 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
             for (int c = 0; c < EPL; ++c) {
                 kx[c] = (float)kraw[u][c];
                 vx[c] = (float)vraw[u][c];
-            }
-            if (FUSED && t == pos) {   // own token: registers (the page write above may not be visible yet)
-#pragma unroll
-                for (int c = 0; c < EPL; ++c) {
-                    kx[c] = own_k[c];
-                    vx[c] = own_v[c];
-                }
             }
             float sc = (qv[0] * kx[0] + qv[1] * kx[1]) + (qv[2] * kx[2] + qv[3] * kx[3]);
             if constexpr (EPL == 8) sc += (qv[4] * kx[4] + qv[5] * kx[5]) + (qv[6] * kx[6] + qv[7] * kx[7]);
@@ -979,13 +736,6 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
 #pragma unroll
                 for (int c = 0; c < EPL; ++c) o[c] = o[c] * alpha + p * vx[c];
                 mi = mn;
-            }
-        }
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                kraw[u] = knext[u];
-                vraw[u] = vnext[u];
             }
         }
     }
@@ -1017,49 +767,12 @@ void launch_paged_attention(const float* qbuf, const void* kv_layer, const int* 
                             const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
                             hipStream_t st, int out_mtt, bool kv_half, const int* row_meta) {
     trace_launch("paged_attention_kernel");
-    // AUR_ATTN_PREFETCH=1: issue the next iteration's K/V loads before reducing the current one.  Measured (r02, 64 x ctx ~243):
-    // fp32 pool 26.0 vs 25.1 us, fp16 pool 17.7 vs 17.2 us per launch, i.e. the ~40 extra VGPRs cost more residency than the
-    // overlap buys (the 4-7 workgroups of a CU already cover for each other) => off.
-    static const int pf = [] {
-        const char* e = getenv("AUR_ATTN_PREFETCH");
-        return e ? atoi(e) : 0;
-    }();
-    const bool prefetch = pf != 0;
-    // AUR_ATTN_UN=8: 8 instead of 4 token steps (2 x 8 K/V loads per lane) in flight per workgroup iteration: half the
-    // serialized memory round trips per row at the cost of registers the 4 workgroups per CU do not need anyway
-    static const int un = [] {
-        const char* e = getenv("AUR_ATTN_UN");
-        return e ? atoi(e) : 4;
-    }();
-    // every (UN, PF) variant visits the tokens of a (wave, lane group) partial in ascending order, so they are bitwise equal
-#define AUR_ATT(KVH_, PF_, UN_)                                                                                                 \
-    hipLaunchKernelGGL((paged_attention_kernel<false, KVH_, PF_, UN_>), dim3(M, kHeads), dim3(256), 0, st, qbuf,                \
-                       const_cast<void*>(kv_layer), row_slot, row_pos, slot_kvpos, block_tables, max_blocks, out,               \
-                       (const float*)nullptr, 0, (const float*)nullptr, M, out_mtt, row_meta)
-#define AUR_ATT_UN(KVH_, PF_)              \
-    do {                                   \
-        if (un == 2) AUR_ATT(KVH_, PF_, 2); \
-        else if (un == 8) AUR_ATT(KVH_, PF_, 8); \
-        else AUR_ATT(KVH_, PF_, 4);        \
-    } while (0)
-    if (kv_half) {
-        if (prefetch) AUR_ATT_UN(true, true);
-        else AUR_ATT_UN(true, false);
-    } else {
-        if (prefetch) AUR_ATT_UN(false, true);
-        else AUR_ATT_UN(false, false);
-    }
-#undef AUR_ATT_UN
-#undef AUR_ATT
-    HIP_CHECK(hipGetLastError());
-}
-
-void launch_qkv_attention_fused(const float* P, int S, const float* bias, float* kv_layer, const int* row_slot,
-                                const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
-                                hipStream_t st) {
-    trace_launch("paged_attention_kernel<fused>");
-    hipLaunchKernelGGL((paged_attention_kernel<true, false>), dim3(M, kHeads), dim3(256), 0, st, (const float*)nullptr, (void*)kv_layer,
-                       row_slot, (const int*)nullptr, slot_kvpos, block_tables, max_blocks, out, P, S, bias, M, 0, (const int*)nullptr);
+    if (kv_half)
+        hipLaunchKernelGGL(paged_attention_kernel<true>, dim3(M, kHeads), dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos,
+                           slot_kvpos, block_tables, max_blocks, out, out_mtt, row_meta);
+    else
+        hipLaunchKernelGGL(paged_attention_kernel<false>, dim3(M, kHeads), dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos,
+                           slot_kvpos, block_tables, max_blocks, out, out_mtt, row_meta);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1279,7 +992,7 @@ __device__ __forceinline__ float exp_noise(unsigned seed, unsigned step, unsigne
     const unsigned a = lowbias32(v * 0x9E3779B1u + seed);
     const unsigned b = lowbias32(a ^ (step * 0x85EBCA77u + 0x165667B1u));
     const float u = ((float)(b >> 8) + 1.0f) * (1.0f / 16777216.0f);
-    return -logf(u);
+    return fmaxf(-logf(u), 2.98023224e-08f);   // 2^-25: u == 1 would give -0.0, and p / -0.0 is NaN for a masked-out id (p = 0)
 }
 __device__ __forceinline__ unsigned f2ord(float f) {
     const unsigned u = __float_as_uint(f);

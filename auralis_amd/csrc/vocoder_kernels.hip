@@ -460,17 +460,6 @@ __global__ __launch_bounds__(256, ((PF && !XH) || WIDE) ? 2 : 3) void conv1d_mfm
     conv_epilogue<WM, WN, MT, NTW>(a, acc, b, mtile, q0, wv, l31, hi, len_in, n_q);
 }
 
-// AUR_VOC_LDS_PAD=<bytes> (experiment): unused dynamic LDS per conv workgroup, i.e. fewer vocoder workgroups per CU, so that a
-// vocoder batch running next to the decode steps of the following batch leaves wave slots and LDS to the latency-bound decode
-// kernels (bench.py --pipeline)
-static size_t conv_lds_pad() {
-    static const size_t pad = [] {
-        const char* e = getenv("AUR_VOC_LDS_PAD");
-        return e ? (size_t)atol(e) : (size_t)0;
-    }();
-    return pad;
-}
-
 template <int KS, int DIL, bool XH, bool PF, bool WIDE>
 static void launch_conv_f16_pf(const ConvArgs& a, hipStream_t st) {
     AUR_REQUIRE(a.Cin % 16 == 0 && a.wp16, "conv f16: Cin % 16, packed fp16 weights");
@@ -482,12 +471,12 @@ static void launch_conv_f16_pf(const ConvArgs& a, hipStream_t st) {
     if (a.Mtot % 64 == 0) {
         constexpr int NT64 = WIDE ? 512 : 256;
         dim3 grid((n_q + NT64 - 1) / NT64, a.Mtot / 64, a.B);
-        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 64, XH, PF, WIDE>), grid, dim3(256), conv_lds_pad(), st, a);
+        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 64, XH, PF, WIDE>), grid, dim3(256), 0, st, a);
     } else {
         AUR_REQUIRE(a.Mtot % 32 == 0, "conv f16: Mtot % 32");
         constexpr int NT32 = 512;
         dim3 grid((n_q + NT32 - 1) / NT32, a.Mtot / 32, a.B);
-        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 32, XH, PF, false>), grid, dim3(256), conv_lds_pad(), st, a);
+        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 32, XH, PF, false>), grid, dim3(256), 0, st, a);
     }
 }
 

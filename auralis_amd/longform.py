@@ -112,15 +112,18 @@ def stream_sharded(tts, requests: Sequence[TTSRequest], window: int = 8, paragra
     _END = object()
 
     def produce():
+        """(paragraph, pcm) per chunk and (paragraph, None) once per OWNED paragraph, in index order, also for a paragraph that
+        produced no chunk at all; an exception travels through the queue"""
         try:
-            last = None
+            done = 0                                               # paragraphs of `mine` already terminated
             for local_i, chunk in stream_longform(tts, [requests[i] for i in mine], window):
-                if last is not None and mine[local_i] != last:
-                    local_q.put((last, None))                      # paragraph `last` is complete
-                last = mine[local_i]
-                local_q.put((last, np.ascontiguousarray(chunk.array, dtype=np.float32)))
-            if last is not None:
-                local_q.put((last, None))
+                while done < local_i:
+                    local_q.put((mine[done], None))
+                    done += 1
+                local_q.put((mine[local_i], np.ascontiguousarray(chunk.array, dtype=np.float32)))
+            while done < len(mine):
+                local_q.put((mine[done], None))
+                done += 1
             local_q.put(_END)
         except BaseException as e:                                 # surfaces in the consumer
             local_q.put(e)
@@ -134,41 +137,91 @@ def stream_sharded(tts, requests: Sequence[TTSRequest], window: int = 8, paragra
             raise item
         return item
 
+    # Wire protocol, point to point, per message: header int64[3] = [paragraph, status, payload length] then the payload.
+    #   status >= 0 : a chunk of `status` samples (0 samples is a legitimate, empty chunk), payload = float32 PCM
+    #   _DONE       : the paragraph is complete, no payload
+    #   _ERROR      : synthesis failed on the sending rank, payload = utf-8 text of the exception; the stream of that rank ends
+    _DONE, _ERROR = -1, -2
+
+    def send_hdr(i, status, length):
+        dist.send(torch.tensor([i, status, length], dtype=torch.int64, device=dev), dst=dst)
+
     if rank != dst:
-        # header = [paragraph index, samples in this chunk (0 = paragraph complete)]
-        while True:
-            item = next_local()
-            if item is _END:
-                break
-            i, pcm = item
-            n = 0 if pcm is None else int(pcm.shape[0])
-            dist.send(torch.tensor([i, n], dtype=torch.int64, device=dev), dst=dst)
-            if n:
-                dist.send(torch.from_numpy(pcm).to(dev), dst=dst)
-        th.join()
-        return
-    for i in range(len(requests)):
-        src = owner[i]
-        while True:
-            if src == rank:
+        try:
+            while True:
                 item = next_local()
-                assert item is not _END and item[0] == i, "local paragraphs arrive in index order"
-                pcm = item[1]
-            else:
-                hdr = torch.empty(2, dtype=torch.int64, device=dev)
-                dist.recv(hdr, src=src)
-                pi, n = int(hdr[0]), int(hdr[1])
-                assert pi == i, f"rank {src} sent paragraph {pi}, expected {i}"
-                pcm = None
-                if n:
-                    buf = torch.empty(n, dtype=torch.float32, device=dev)
-                    dist.recv(buf, src=src)
-                    pcm = buf.cpu().numpy()
-            if pcm is None:
-                break
-            yield i, pcm
-    assert next_local() is _END
-    th.join()
+                if item is _END:
+                    break
+                i, pcm = item
+                if pcm is None:
+                    send_hdr(i, _DONE, 0)
+                else:
+                    send_hdr(i, int(pcm.shape[0]), int(pcm.shape[0]))
+                    if pcm.shape[0]:
+                        dist.send(torch.from_numpy(pcm).to(dev), dst=dst)
+        except BaseException as e:                                 # tell dst instead of leaving it in recv forever
+            msg = f"rank {rank}: {type(e).__name__}: {e}".encode("utf-8", "replace")[:4096]
+            send_hdr(-1, _ERROR, len(msg))
+            dist.send(torch.frombuffer(bytearray(msg), dtype=torch.uint8).to(dev), dst=dst)
+            raise
+        finally:
+            th.join(timeout=5.0)
+        return
+
+    ended = set()          # source ranks whose stream is over (error seen)
+
+    def recv_msg(src):
+        hdr = torch.empty(3, dtype=torch.int64, device=dev)
+        dist.recv(hdr, src=src)
+        pi, status, length = int(hdr[0]), int(hdr[1]), int(hdr[2])
+        if status == _ERROR:
+            buf = torch.empty(length, dtype=torch.uint8, device=dev)
+            if length:
+                dist.recv(buf, src=src)
+            ended.add(src)
+            raise RuntimeError("long-form synthesis failed on " + bytes(buf.cpu().numpy().tobytes()).decode("utf-8", "replace"))
+        if status == _DONE:
+            return pi, None
+        buf = torch.empty(status, dtype=torch.float32, device=dev)
+        if status:
+            dist.recv(buf, src=src)
+        return pi, buf.cpu().numpy()
+
+    i = 0
+    in_paragraph = False   # headers of paragraph i have been consumed but not its terminator
+    try:
+        for i in range(len(requests)):
+            src = owner[i]
+            in_paragraph = True
+            while True:
+                if src == rank:
+                    item = next_local()
+                    assert item is not _END and item[0] == i, "local paragraphs arrive in index order"
+                    pcm = item[1]
+                else:
+                    pi, pcm = recv_msg(src)
+                    assert pi == i, f"rank {src} sent paragraph {pi}, expected {i}"
+                if pcm is None:
+                    in_paragraph = False
+                    break
+                yield i, pcm
+        i = len(requests)
+        assert next_local() is _END
+    finally:
+        # The consumer stopped early (closed the iterator, raised, or a rank reported an error): the other ranks are still
+        # sending and would block in dist.send forever.  Receive and discard what they have left, paragraph by paragraph.
+        for j in range(i, len(requests)):
+            src = owner[j]
+            if src == rank or src in ended:
+                continue
+            try:
+                while True:
+                    _, pcm = recv_msg(src)
+                    if pcm is None:
+                        break
+            except RuntimeError:
+                pass                                               # that rank's stream has ended with its own error
+        th.join(timeout=5.0)
 
 
 def synthesize_sharded(tts, requests: Sequence[TTSRequest], window: int = 8, paragraphs_per_block: int = 8,

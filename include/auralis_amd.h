@@ -55,6 +55,9 @@ typedef struct aur_config {
                                  into three bf16 terms and a product runs as six bf16 MFMAs with fp32 accumulation (the accuracy of
                                  an fp32 dot product at 2.7x less matrix-pipe time); 1 = v_mfma_f32_16x16x4_f32, bitwise an fp32
                                  fma chain.  Prompt rows always run on exact-f32 MFMA */
+    int32_t gelu_erf;         /* MLP activation: 0 = tanh form ("gelu_new", what checkpoint_converter.py:197 writes), 1 = erf form
+                                 ("gelu", the XTTSGPTConfig class default, xttsv2_gpt_config.py:184); from the checkpoint's
+                                 gpt/config.json "activation_function" */
 } aur_config;
 
 /* One named fp32 tensor.  Names are the packed names produced by auralis_amd/weights.py from the
@@ -161,6 +164,11 @@ int aur_set_conditioning_device(aur_engine* e, uint64_t speaker_key, const float
 int aur_comm_unique_id(uint8_t* out128);
 int aur_comm_init(aur_engine* e, const uint8_t* id128, int32_t rank, int32_t world_size);
 int aur_broadcast_conditioning(aur_engine* e, uint64_t speaker_key, int32_t root);
+/* What the communicator itself reports (ncclCommCount / ncclCommUserRank): *n_ranks = 0 before aur_comm_init. */
+int aur_comm_info(aur_engine* e, int32_t* n_ranks, int32_t* rank);
+/* 64-bit FNV-1a checksum over the registered conditioning of a voice as it sits in device memory (gpt_cond_latent [32][1024]
+ * then speaker embedding [512], fp32 bytes): lets the ranks of a job verify that a broadcast delivered identical bytes. */
+int aur_conditioning_checksum(aur_engine* e, uint64_t speaker_key, uint64_t* out);
 
 /* *out = 1 if speaker_key is registered (and marks it most recently used), else 0.  The table holds
  * aur_config.max_speakers voices; when it is full, registering a new key evicts the least recently used voice that has
@@ -205,19 +213,15 @@ int aur_get_stats(aur_engine* e, aur_stats* out);
 int aur_reset_stats(aur_engine* e);
 
 /* ---- per-kernel entry points used by the parity tests (host pointers) ------------------------------- */
-/* out[M][N] = X[M][K] @ W[K][N] via the split-K MFMA kernel + slab sum (kw = 0 picks the default). */
-int aur_dbg_gemm(aur_engine* e, const float* X, const float* W, float* out, int32_t M, int32_t N, int32_t K,
-                 int32_t kw);
+/* Prefill-regime GEMM (gemm_tile_kernel, exact-f32 MFMA, the kernel every prompt-row linear of vLLM's GPT2Block runs on
+ * here, vllm_mm_gpt.py:757-761 at M = prompt rows): out[M][N] = X[M][K] @ W[K][N]. */
+int aur_dbg_gemm(aur_engine* e, const float* X, const float* W, float* out, int32_t M, int32_t N, int32_t K);
 /* Decode-regime GEMM (gemm_rows_kernel: full-K workgroups, fused LayerNorm prologue and bias / gelu / residual epilogue;
  * replaces one GPT2Block linear of vLLM's GPT2Attention / GPT2MLP at M = live sequences, vllm_mm_gpt.py:757-761):
  * out[M][N] = epi(LN?(X[M][K]) @ W[K][N] + bias), epi 0 = bias, 1 = bias + gelu_new, 2 = out += (.. + bias).
  * ln != 0 applies LayerNorm(gamma, beta, eps 1e-5) to the rows of X first (K must be 1024).  K in {1024, 4096}. */
 int aur_dbg_gemm_rows(aur_engine* e, const float* X, const float* W, const float* bias, const float* gamma,
                       const float* beta, float* out, int32_t M, int32_t N, int32_t K, int32_t epi, int32_t ln);
-/* Host-side evaluation of the GEMM kernel's workgroup -> (column tile, K-slice, M-tile) map for a (gx, gy, gz) grid
- * (gpt_kernels.h gemm_tile_map; needs no GPU): out3[3*L + {0,1,2}] for L in [0, gx*gy*gz).  Lets the CPU tests check
- * that every tile order in use is a bijection. */
-int aur_dbg_gemm_tile_map(int32_t gx, int32_t gy, int32_t gz, int32_t group, int32_t* out3);
 /* out[M][1024] = LayerNorm(h) rows */
 int aur_dbg_layernorm(aur_engine* e, const float* h, const float* gamma, const float* beta, float* out,
                       int32_t M);

@@ -48,6 +48,12 @@ def gelu_new(x: Tensor) -> Tensor:
     return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
 
 
+def gelu_erf(x: Tensor) -> Tensor:
+    """erf-form GELU (config.json "activation_function": "gelu", the XTTSGPTConfig class default,
+    src/auralis/models/xttsv2/config/xttsv2_gpt_config.py:184; transformers ACT2FN["gelu"])."""
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
 def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
@@ -68,14 +74,16 @@ def _lowbias32(x: np.ndarray) -> np.ndarray:
 def exp_noise(seed: int, step: int, vocab: int) -> np.ndarray:
     """Exp(1) noise e[v] for sampling step `step` of a sequence seeded with `seed`.
 
-    u = (hash >> 8 + 1) / 2^24 in (0, 1];  e = -log(u)   (float32).  Mirrors csrc/sampler.hip.
-    """
+    u = (hash >> 8 + 1) / 2^24 in (0, 1];  e = max(-log(u), 2^-25)   (float32).  Mirrors exp_noise in csrc/gpt_kernels.hip.
+    The floor only acts on u == 1 (one draw in 2^24), where -log(u) is -0.0: vLLM's `probs.div_(q).argmax()` would turn a
+    masked-out id (p = 0) into 0 / 0 = NaN there and select it; a strictly positive e keeps q = p / e finite and zero for every
+    masked id (found by the all-64-seeds fixture: seed 50, step 274)."""
     with np.errstate(over="ignore"):
         v = np.arange(vocab, dtype=np.uint32)
         a = _lowbias32(v * np.uint32(0x9E3779B1) + np.uint32(seed & 0xFFFFFFFF))
         b = _lowbias32(a ^ (np.uint32(step & 0xFFFFFFFF) * np.uint32(0x85EBCA77) + np.uint32(0x165667B1)))
     u = ((b >> np.uint32(8)).astype(np.float32) + np.float32(1.0)) * np.float32(1.0 / 16777216.0)
-    return (-np.log(u.astype(np.float32))).astype(np.float32)
+    return np.maximum(-np.log(u.astype(np.float32)), np.float32(2.0 ** -25)).astype(np.float32)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -148,7 +156,10 @@ class GPTOracle:
     """
 
     def __init__(self, gpt_sd: Dict[str, Tensor], xtts_sd: Optional[Dict[str, Tensor]] = None,
-                 n_head: int = 16, eps: float = 1e-5, start_token: int = 1024, stop_token: int = 1025):
+                 n_head: int = 16, eps: float = 1e-5, start_token: int = 1024, stop_token: int = 1025,
+                 activation: str = "gelu_new"):
+        assert activation in ("gelu_new", "gelu"), activation
+        self.act = gelu_new if activation == "gelu_new" else gelu_erf
         self.w = {k: v.to(torch.float32) for k, v in gpt_sd.items()}
         self.x = None if xtts_sd is None else xtts_sd
         self.n_layer = 1 + max(int(k.split(".")[2]) for k in self.w if k.startswith("gpt.h."))
@@ -199,7 +210,7 @@ class GPTOracle:
         att = att.transpose(0, 1).reshape(T, self.hidden)
         x = x + att @ w[p + "attn.c_proj.weight"] + w[p + "attn.c_proj.bias"]
         m = layer_norm(x, w[p + "ln_2.weight"], w[p + "ln_2.bias"], self.eps)
-        f = gelu_new(m @ w[p + "mlp.c_fc.weight"] + w[p + "mlp.c_fc.bias"])
+        f = self.act(m @ w[p + "mlp.c_fc.weight"] + w[p + "mlp.c_fc.bias"])
         x = x + f @ w[p + "mlp.c_proj.weight"] + w[p + "mlp.c_proj.bias"]
         return x, (k, v)
 

@@ -117,3 +117,15 @@ def test_reference_audio_may_be_flac():
     if codecs.external_backend() is None:
         with pytest.raises(ValueError, match="torchaudio or an"):
             Cn.read_wav(b"ID3\x04" + bytes(100))
+
+
+def test_pcm_24_bit_is_three_little_endian_bytes_per_sample():
+    """encode(fmt="pcm", sample_width=3) emitted the int32 carrier (4 bytes per sample)."""
+    from auralis_amd.api import codecs
+    x = np.array([0.0, 0.5, -0.5, 1.0, -1.0, 1e-3], np.float32)
+    raw = codecs.encode(x, 24000, "pcm", sample_width=3)
+    assert len(raw) == 3 * len(x)
+    back = [int.from_bytes(raw[3 * i: 3 * i + 3], "little", signed=True) for i in range(len(x))]
+    assert back == [int(np.rint(float(v) * 8388607.0)) for v in x]
+    assert len(codecs.encode(x, 24000, "pcm", sample_width=2)) == 2 * len(x)
+    assert len(codecs.encode(x, 24000, "pcm", sample_width=4)) == 4 * len(x)

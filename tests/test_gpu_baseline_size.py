@@ -79,6 +79,92 @@ def test_c3_64_way_sampled_equals_oracle_and_solo(bench_engine):
         assert np.array_equal(solo["wav"], batch[s]["wav"]), s
 
 
+def test_c2_two_more_prompts_bit_exact(bench_engine):
+    """C2 on two further prompts (text seeds 12, 13; tests/golden/c2w_L30_T280.npz from oracle/make_golden_wide.py): 280 greedy
+    ids bit-exact each, stash latents within 5e-3 of the literal second pass, waveform of prompt 12 within 1e-3 RMS / 1 %."""
+    g = np.load(os.path.join(GOLD, "c2w_L30_T280.npz"))
+    e = bench_engine
+    for ts in (12, 13):
+        e.submit(g[f"text_ids_{ts}"].tolist(), SPK_KEY, temperature=0.0, max_tokens=280, ignore_stop=True)
+        got = e.run_until_done()[0]
+        ref = g[f"tokens_{ts}"].tolist()
+        d = _first_diff(got["tokens"].tolist(), ref)
+        m = g[f"margins_{ts}"]
+        assert d is None, (f"text seed {ts}: first differing step {d}: got {int(got['tokens'][d])} want {ref[d]}; oracle top-2 "
+                           f"margin there {float(m[d]):.3e} (min over the run {float(m.min()):.3e})")
+        lat_err = float(np.abs(got["latents"] - g[f"latents_{ts}"]).max())
+        assert lat_err < 5e-3, (ts, lat_err)
+        if ts == 12:
+            err, sig = rms(got["wav"] - g["wav_12"]), rms(g["wav_12"])
+            assert err <= 1e-3 and err <= 1e-2 * sig, (err, sig)
+
+
+def test_c3_all_64_seeds_equal_the_oracle(bench_engine):
+    """C3 with EVERY one of the 64 concurrent sampled sequences compared with the oracle (tests/golden/c3w_L30_T280.npz): all
+    280 ids of all 64 seeds under the shared counter-hash noise; a mismatch reports the oracle's race ratio at that step."""
+    g = np.load(os.path.join(GOLD, "c3w_L30_T280.npz"))
+    e = bench_engine
+    ids = g["text_ids"].tolist()
+    T = int(g["tokens"].shape[1])
+    sid = {e.submit(ids, SPK_KEY, max_tokens=T, seed=int(s), ignore_stop=True, **SAMPLING): int(s) for s in g["seeds"]}
+    batch = {sid[o["seq_id"]]: o for o in e.run_until_done()}
+    assert len(batch) == 64
+    bad = []
+    for k, s in enumerate(g["seeds"].tolist()):
+        d = _first_diff(batch[s]["tokens"].tolist(), g["tokens"][k].tolist())
+        if d is not None:
+            bad.append((s, d, int(batch[s]["tokens"][d]), int(g["tokens"][k][d]), float(g["race_ratio"][k][d])))
+    assert not bad, f"(seed, first differing step, got, want, oracle race ratio there): {bad}; closest ratio of the whole fixture {float(g['race_ratio'].max()):.7f}"
+
+
+def test_ragged_oversubscribed_natural_stop_at_30_layers():
+    """80 sequences with 6..120 text ids, max_tokens 20..150, a third greedy and the rest sampled with their own seeds, natural
+    stop (the stop id ends a sequence and stays in its ids, XTTSv2.py:737), all submitted at once to the 64-slot engine
+    (over-subscribed: the last 16 wait for slots): every sequence's ids equal the oracle's (tests/golden/ragged_L30.npz).
+    The synthetic checkpoint never emits the stop id by itself; as in the fixture, mel_head.bias[1025] is raised."""
+    from auralis_amd._lib import NativeEngine
+    from auralis_amd.checkpoint import make_synthetic_conditioning, make_synthetic_text_ids
+    from auralis_amd.config import XTTSDims
+    from tests.gpu_util import packed_weights
+    g = np.load(os.path.join(GOLD, "ragged_L30.npz"))
+    dims = XTTSDims()
+    packed, _, _ = packed_weights(30)
+    packed = dict(packed)
+    hb = packed["mel_head.b"].copy()
+    hb[1025] = float(g["stop_bias"])
+    packed["mel_head.b"] = hb
+    e = NativeEngine(n_layer=30, max_seqs=64, vocoder_fp16=True, return_latents=False)
+    try:
+        e.load_weights(packed)
+        cond, spk = make_synthetic_conditioning(dims)
+        e.set_conditioning(SPK_KEY, cond.numpy(), spk.numpy())
+        sid = {}
+        for i, (n_text, mt, greedy, seed, tseed) in enumerate(g["specs"].tolist()):
+            ids = make_synthetic_text_ids(dims, n_text=n_text, seed=tseed)
+            if greedy:
+                sid[e.submit(ids, SPK_KEY, temperature=0.0, max_tokens=mt)] = i
+            else:
+                sid[e.submit(ids, SPK_KEY, max_tokens=mt, seed=seed, **SAMPLING)] = i
+        outs = e.run_until_done()
+        assert len(outs) == len(sid) == 80
+        bad = []
+        for o in outs:
+            i = sid[o["seq_id"]]
+            n = int(g["lengths"][i])
+            ref = g["tokens"][i][:n].tolist()
+            got = o["tokens"].tolist()
+            if got != ref:
+                bad.append((i, _first_diff(got, ref), len(got), n))
+            else:
+                assert (got[-1] == 1025) == bool(g["stopped"][i])
+                assert len(o["wav"]) == dims.voc.samples_for_latents(n) and np.isfinite(o["wav"]).all()
+        assert not bad, f"(sequence, first differing step, got length, want length): {bad}"
+        st = e.stats()
+        assert st["kv_blocks_total"] - st["kv_blocks_free"] == 2
+    finally:
+        e.close()
+
+
 def test_kv_fp16_throughput_mode_exactness_report():
     """aur_config.kv_fp16 = 1 (fp16 K/V pool, fp32 scores / softmax / P.V) is a THROUGHPUT mode, not the parity mode: this
     test states its tolerance and writes the measured mismatch against the C2 / C3 goldens to gpurun_out/kv_fp16_report.json.
@@ -112,6 +198,20 @@ def test_kv_fp16_throughput_mode_exactness_report():
             firsts.append(dd)
         rep["c3_sampled_8_seeds"] = {"first_differing_step_per_seed": firsts,
                                      "sequences_fully_equal": sum(1 for x in firsts if x is None)}
+        gw = np.load(os.path.join(GOLD, "c3w_L30_T280.npz"))
+        sid = {e.submit(ids, SPK_KEY, max_tokens=T, seed=int(s), ignore_stop=True, **SAMPLING): int(s) for s in gw["seeds"]}
+        outs = {sid[o["seq_id"]]: o for o in e.run_until_done()}
+        fw = [_first_diff(outs[int(s)]["tokens"].tolist(), gw["tokens"][k].tolist()) for k, s in enumerate(gw["seeds"])]
+        rep["c3_sampled_64_seeds"] = {"sequences_fully_equal": sum(1 for x in fw if x is None),
+                                      "first_differing_steps": [x for x in fw if x is not None]}
+        g2w = np.load(os.path.join(GOLD, "c2w_L30_T280.npz"))
+        rep["c2_more_prompts"] = {}
+        for ts in (12, 13):
+            e.submit(g2w[f"text_ids_{ts}"].tolist(), SPK_KEY, temperature=0.0, max_tokens=280, ignore_stop=True)
+            o = e.run_until_done()[0]
+            dd = _first_diff(o["tokens"].tolist(), g2w[f"tokens_{ts}"].tolist())
+            rep["c2_more_prompts"][str(ts)] = {"first_differing_step": dd,
+                                               "oracle_margin_there": None if dd is None else float(g2w[f"margins_{ts}"][dd])}
         print("kv_fp16 report:", json.dumps(rep))
         if os.path.isdir("gpurun_out"):
             json.dump(rep, open(os.path.join("gpurun_out", "kv_fp16_report.json"), "w"), indent=1)

@@ -170,6 +170,41 @@ def test_failed_step_releases_slots_blocks_and_engine_stays_usable(dims, monkeyp
         e.close()
 
 
+def test_throw_inside_vocoder_launch_fails_its_batch_and_releases_everything(dims, monkeypatch):
+    """a throw inside voc_launch AFTER the sequences left the vocoder queue (here injected: AUR_TEST_FAIL_VOC) used to
+    drop the batch without failing it: callers waited forever, latent-pool entries, speaker references and the pinned result
+    block leaked.  Now every sequence of the batch is failed, and the engine keeps producing the fresh engine's output."""
+    ids = [make_synthetic_text_ids(dims, n_text=10 + k, seed=70 + k) for k in range(2)]
+    monkeypatch.delenv("AUR_TEST_FAIL_VOC", raising=False)
+    monkeypatch.delenv("AUR_TEST_FAIL_STEP", raising=False)
+    ref_e, *_ = make_engine(2, max_seqs=2)
+    try:
+        ref_e.submit(ids[1], SPK_KEY, temperature=0.0, max_tokens=9, ignore_stop=True)
+        ref = ref_e.run_until_done()[0]
+    finally:
+        ref_e.close()
+    monkeypatch.setenv("AUR_TEST_FAIL_VOC", "1")
+    e, *_ = make_engine(2, max_seqs=2)
+    try:
+        sids = [e.submit(i, SPK_KEY, temperature=0.0, max_tokens=6, ignore_stop=True) for i in ids]
+        with pytest.raises(AurError) as ei:
+            for _ in range(40):
+                e.step()
+        assert ei.value.code == -2 and "AUR_TEST_FAIL_VOC" in str(ei.value)
+        failed = e.poll()
+        assert sorted(o["seq_id"] for o in failed) == sids
+        assert all(o["error"] == -2 and len(o["wav"]) == 0 for o in failed)
+        st = e.stats()
+        assert st["kv_blocks_total"] - st["kv_blocks_free"] == 2        # only the speaker's shared prefix blocks
+        for _ in range(3):                                               # pool entries / speaker refs / result block came back
+            e.submit(ids[1], SPK_KEY, temperature=0.0, max_tokens=9, ignore_stop=True)
+            out = e.run_until_done()[0]
+            assert out["error"] == 0 and out["tokens"].tolist() == ref["tokens"].tolist() and np.array_equal(out["wav"], ref["wav"])
+        e.set_conditioning(4242, np.zeros((1, 32, 1024), np.float32), np.ones((1, 512, 1), np.float32))   # a new voice still fits
+    finally:
+        e.close()
+
+
 def test_speaker_table_evicts_lru_idle_voice_and_pins_busy_ones(dims):
     """aur_config.max_speakers voices at most; a new key evicts the least recently used voice without undelivered
     sequences (its prefix KV blocks are recycled), never a busy one; an evicted key must be registered again."""
@@ -252,9 +287,18 @@ def test_in_library_rccl_communicator_and_broadcast_world1(dims):
         assert isinstance(uid, bytes) and len(uid) == 128 and any(uid)
         with pytest.raises(AurError):
             e.comm_init(uid, 1, 1)                       # rank out of range
+        assert e.comm_info() == (0, -1)
         e.comm_init(uid, 0, 1)
+        assert e.comm_info() == (1, 0)                   # ncclCommCount / ncclCommUserRank of the communicator itself
         with pytest.raises(AurError, match="already"):
             e.comm_init(uid, 0, 1)
+        # checksum of the voice as registered in device memory == FNV-1a of the bytes that were handed in
+        x = 1469598103934665603
+        for byte in cond.numpy().astype("<f4").tobytes() + spk.numpy().astype("<f4").tobytes():
+            x = ((x ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        assert e.conditioning_checksum(SPK_KEY) == x
+        with pytest.raises(AurError):
+            e.conditioning_checksum(999999)
         ids = make_synthetic_text_ids(dims, n_text=15, seed=8)
         e.submit(ids, SPK_KEY, temperature=0.0, max_tokens=10, ignore_stop=True)
         before = e.run_until_done()[0]

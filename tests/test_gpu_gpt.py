@@ -159,3 +159,28 @@ def test_literal_second_pass_mode_matches_stash_and_oracle(dims):
     finally:
         e1.close()
         e2.close()
+
+
+def test_erf_gelu_checkpoint_runs_the_erf_kernels(dims):
+    """gpt/config.json "activation_function": "gelu" -> aur_config.gelu_erf: prompt rows (gemm_tile epilogue) and decode rows
+    (gemm_rows epilogue) both apply the erf form; ids bit-exact against the oracle built with the same activation, and
+    different from what the tanh-form engine emits on the same prompt (the test can tell the two apart)."""
+    from oracle import xtts_oracle as O
+    e, gpt_sd, xtts_sd, cond, spk = make_engine(3, max_seqs=2, gelu_erf=True)
+    e_tanh, *_ = make_engine(3, max_seqs=2)
+    try:
+        gpt = O.GPTOracle(gpt_sd, xtts_sd, activation="gelu")
+        ids = make_synthetic_text_ids(dims, n_text=18, seed=31)
+        c = gpt.build_cond(cond, ids)
+        ref = gpt.generate(c, O.SamplingCfg(temperature=0.0, max_tokens=32, ignore_stop=True), return_debug=True)
+        e.submit(ids, SPK_KEY, temperature=0.0, max_tokens=32, ignore_stop=True)
+        got = e.run_until_done()[0]
+        assert got["tokens"].tolist() == ref["tokens"], min(ref["margins"])
+        lat_ref = gpt.latents_from_decode_rows(ref["decode_rows"], len(ref["tokens"]))[0].numpy()
+        assert np.abs(got["latents"] - lat_ref).max() < 2e-3
+        e_tanh.submit(ids, SPK_KEY, temperature=0.0, max_tokens=32, ignore_stop=True)
+        other = e_tanh.run_until_done()[0]
+        assert np.abs(other["latents"] - got["latents"]).max() > 1e-3
+    finally:
+        e.close()
+        e_tanh.close()

@@ -363,3 +363,48 @@ def test_split_sentence_follows_the_reference_algorithm():
     # strong markers win over nearer weak ones; with no marker in the window the cut is exactly at the target
     assert find_best_split_point("a" * 235 + ". " + "b" * 100, 250) == 237
     assert find_best_split_point("z" * 400, 250) == 250
+
+
+def test_submit_is_repeated_once_after_reregistering_an_evicted_voice():
+    """between the facade's presence check and aur_submit another request can evict the voice (the speaker table is
+    bounded, a voice is pinned from submit on); the driver then re-registers it and submits again instead of failing."""
+    import asyncio
+
+    from auralis_amd.api.driver import EngineDriver
+
+    class Eng:
+        def __init__(self):
+            self.known, self.calls, self.reg = False, 0, 0
+
+        def submit(self, **kw):
+            self.calls += 1
+            if not self.known:
+                raise RuntimeError("auralis_amd error -1: requirement failed: unknown speaker_key (call aur_set_conditioning first)")
+            return 7
+
+        def step(self):
+            return 0, 0
+
+        def poll(self):
+            return []
+
+    eng = Eng()
+    d = EngineDriver(eng)
+    loop = asyncio.new_event_loop()
+    try:
+        def rereg():
+            eng.reg += 1
+            eng.known = True
+        fut = d.submit(loop, reregister=rereg, text_ids=[1, 2], speaker_key=5)
+        assert eng.calls == 2 and eng.reg == 1 and not fut.done()
+        eng.known = False
+        with pytest.raises(RuntimeError, match="unknown speaker_key"):
+            d.submit(loop, text_ids=[1], speaker_key=5)              # no callback: the error surfaces
+        with pytest.raises(RuntimeError, match="boom"):
+            class Bad(Eng):
+                def submit(self, **kw):
+                    raise RuntimeError("boom")
+            EngineDriver(Bad()).submit(loop, reregister=rereg, text_ids=[1], speaker_key=5)   # other errors are not retried
+    finally:
+        d.shutdown()
+        loop.close()

@@ -142,3 +142,61 @@ def test_sharded_book_on_two_ranks_gloo(tmp_path):
     assert idx == sorted(idx) and sorted(set(idx)) == list(range(len(paras))) and len(r1["idx"]) == 0
     assert len(idx) == sum(_expected_chunks(reqs)) and int(r0["streamed"]) == len(single.array)
     assert r0["stamps"][0] < 0.5 * float(r0["t_end"])
+
+
+def _sharded_failure_worker(rank, world, port, out_dir, mode):
+    """mode "remote_error": rank 1's engine fails after a few steps; mode "early_stop": rank 0 stops consuming after 3 chunks"""
+    import os
+
+    import torch.distributed as dist
+
+    from auralis_amd.longform import stream_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    paras = [EN, FR, DE] * 6
+    reqs = build_requests(paras, [VOICE], seed=1)
+    fake = FakeNativeEngine(max_seqs=4, fail_on_step=(12 if (mode == "remote_error" and rank == 1) else None))
+    tts = TTS(scheduler_max_concurrency=4).with_engine(XTTSv2Engine(fake, XTTSTokenizer(None, synthetic=True)))
+    got, err = 0, ""
+    try:
+        it = stream_sharded(tts, reqs, window=3, paragraphs_per_block=2)
+        try:
+            for _ in it:
+                got += 1
+                if mode == "early_stop" and rank == 0 and got == 3:
+                    break
+        finally:
+            it.close()                      # a consumer that walks away: the generator's cleanup must release the other ranks
+    except BaseException as e:
+        err = f"{type(e).__name__}: {e}"
+    finally:
+        tts.close()
+    with open(os.path.join(out_dir, f"r{rank}.txt"), "w") as f:
+        f.write(f"{got}\n{err}\n")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["remote_error", "early_stop"])
+def test_sharded_stream_never_hangs_on_a_failing_rank_or_a_consumer_that_stops(tmp_path, mode):
+    """the point-to-point protocol had no error message (a failing non-dst rank left dst in recv forever) and no way
+    out for senders when the consumer on dst stopped (they blocked in send).  Both cases must END, with the remote error
+    text arriving on dst."""
+    import socket
+
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.spawn(_sharded_failure_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=False)
+    import time
+    t0 = time.time()
+    while not ctx.join(timeout=1.0):
+        assert time.time() - t0 < 90, "the sharded stream hung"
+    r0 = open(tmp_path / "r0.txt").read().split("\n")
+    r1 = open(tmp_path / "r1.txt").read().split("\n")
+    if mode == "remote_error":
+        assert "RuntimeError" in r0[1] and "rank 1" in r0[1] and "injected engine failure" in r0[1], r0
+        assert "injected engine failure" in r1[1], r1          # the failing rank re-raises its own error
+    else:
+        assert int(r0[0]) == 3 and r0[1] == "" and r1[1] == "", (r0, r1)

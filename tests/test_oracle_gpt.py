@@ -8,10 +8,10 @@ from auralis_amd.checkpoint import make_synthetic_text_ids
 from oracle import xtts_oracle as O
 
 
-def _hf_gpt2(gpt_sd, n_layer):
+def _hf_gpt2(gpt_sd, n_layer, activation="gelu_new"):
     from transformers import GPT2Config, GPT2Model
     cfg = GPT2Config(vocab_size=8, n_positions=1100, n_embd=1024, n_layer=n_layer, n_head=16, n_inner=4096,
-                     activation_function="gelu_new", resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
+                     activation_function=activation, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0,
                      layer_norm_epsilon=1e-5)
     m = GPT2Model(cfg).eval()
     sd = m.state_dict()
@@ -35,6 +35,22 @@ def test_block_stack_matches_hf_gpt2(gpt_sd_small, xtts_sd, dims, conditioning):
     with torch.no_grad():
         ref = hf(inputs_embeds=x[None]).last_hidden_state[0]
     assert (h - ref).abs().max().item() < 2e-4
+
+
+def test_erf_gelu_block_stack_matches_hf_gpt2(gpt_sd_small, xtts_sd, dims, conditioning):
+    """config.json "activation_function": "gelu" (the XTTSGPTConfig class default, xttsv2_gpt_config.py:184) = the erf form:
+    the oracle's variant against transformers' GPT2Model built with activation_function="gelu", and it must differ from the
+    tanh form by more than the comparison tolerance (else the test could not tell them apart)."""
+    gpt = O.GPTOracle(gpt_sd_small, xtts_sd, activation="gelu")
+    ids = make_synthetic_text_ids(dims, n_text=20)
+    cond = gpt.build_cond(conditioning[0], ids)
+    x = torch.cat([cond, gpt.mel_embed([1024], [0])], dim=0)
+    h, _ = gpt.forward_rows(x, None)
+    with torch.no_grad():
+        ref = _hf_gpt2(gpt_sd_small, 3, "gelu")(inputs_embeds=x[None]).last_hidden_state[0]
+    assert (h - ref).abs().max().item() < 2e-4
+    t = torch.linspace(-4, 4, 1001)
+    assert (O.gelu_erf(t) - O.gelu_new(t)).abs().max().item() > 1e-4
 
 
 def test_incremental_decode_equals_full_prefill(gpt_sd_small, xtts_sd, dims, conditioning):
