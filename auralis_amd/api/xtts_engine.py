@@ -131,8 +131,6 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
                 raise NotImplementedError(
                     "this checkpoint carries no conditioning_encoder / perceiver / speaker_encoder weights: pass "
                     "precomputed conditioning (.npz or dict with gpt_cond_latent [1,32,1024], speaker_embedding [1,512,1])")
-            import torch
-
             from .. import conditioning as Cn
             # cache key = full content of every reference (a path is keyed by the bytes it holds now, not by its name) + every
             # parameter that changes the result
@@ -151,24 +149,21 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
                 self._cond_cache.move_to_end(key)
             else:
                 hip = getattr(self.native, "compute_conditioning", None)
-                if hip is not None:
-                    # loader on the host (decode, mono, resample to 22 050 Hz, clip: utilities.py:74-98), networks in HIP
-                    def _run():
-                        pcm = []
-                        for r in refs:
-                            a = Cn.load_audio(r, load_sr)
-                            if load_sr != 22050:
-                                a = Cn.resample(a, load_sr, 22050)
-                            pcm.append(a[0].numpy())
-                        return hip(pcm, max_ref_length=max_ref_length, gpt_cond_len=gpt_cond_len,
-                                   gpt_cond_chunk_len=gpt_cond_chunk_len, sound_norm_refs=sound_norm_refs)
-                    self._cond_cache[key] = await asyncio.to_thread(_run)
-                else:   # engines without the entry point (CPU test doubles): the PyTorch restatement
-                    dev = "cuda" if torch.cuda.is_available() else "cpu"
-                    g_t, s_t = await asyncio.to_thread(Cn.get_conditioning_latents, self.conditioning_weights, refs,
-                                                       max_ref_length, gpt_cond_len, gpt_cond_chunk_len, sound_norm_refs,
-                                                       load_sr, dev)
-                    self._cond_cache[key] = (g_t.float().cpu().numpy(), s_t.float().cpu().numpy())
+                if hip is None:
+                    raise RuntimeError("the engine has no compute_conditioning entry point: speaker conditioning from reference "
+                                       "audio runs in HIP (aur_compute_conditioning); there is no PyTorch fallback in the product")
+
+                # loader on the host (decode, mono, resample to 22 050 Hz, clip: utilities.py:74-98), networks in HIP
+                def _run():
+                    pcm = []
+                    for r in refs:
+                        a = Cn.load_audio(r, load_sr)
+                        if load_sr != 22050:
+                            a = Cn.resample(a, load_sr, 22050)
+                        pcm.append(a[0].numpy())
+                    return hip(pcm, max_ref_length=max_ref_length, gpt_cond_len=gpt_cond_len,
+                               gpt_cond_chunk_len=gpt_cond_chunk_len, sound_norm_refs=sound_norm_refs)
+                self._cond_cache[key] = await asyncio.to_thread(_run)
                 while len(self._cond_cache) > self._cond_cache_max:
                     self._cond_cache.popitem(last=False)
             g, s = self._cond_cache[key]

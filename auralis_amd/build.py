@@ -16,17 +16,36 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
-def _stale() -> bool:
-    if not os.path.isfile(LIB):
+HASH_FILE = LIB + ".srchash"
+
+
+def source_hash() -> str:
+    """sha256 over every translation unit, every header (csrc/ and include/) and the compiler flags: what the binary is keyed on
+    (file times say nothing once a tree has been copied to another machine)."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    for rel in sorted(SOURCES + HEADERS):
+        path = os.path.normpath(os.path.join(CSRC, rel))
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(want: str) -> bool:
+    if not os.path.isfile(LIB) or not os.path.isfile(HASH_FILE):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(HASH_FILE) as f:
+        return f.read().strip() != want
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP translation unit for gfx950 and link the C-ABI library. Returns its path."""
-    if not force and not _stale():
+    """Compile every HIP translation unit for gfx950 and link the C-ABI library, unless the library on disk was built from
+    exactly these sources.  Prints which of the two happened.  Returns the library's path."""
+    want = source_hash()
+    if not force and not _stale(want):
+        print(f"[auralis_amd.build] reused {os.path.relpath(LIB, os.path.dirname(HERE))} (source hash {want[:16]})", flush=True)
         return LIB
     os.makedirs(OUT_DIR, exist_ok=True)
 
@@ -46,6 +65,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    with open(HASH_FILE, "w") as f:
+        f.write(want + "\n")
+    print(f"[auralis_amd.build] compiled {len(SOURCES)} translation units with hipcc for gfx950 -> "
+          f"{os.path.relpath(LIB, os.path.dirname(HERE))} (source hash {want[:16]})", flush=True)
     return LIB
 
 

@@ -109,10 +109,17 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, f32x16 (&
     }
 }
 
-// polyphase transposed conv: virtual row v = co*s + phase lands at t = q*s + phase - p (no residual / MRF on these layers)
+// polyphase transposed conv: virtual row v = co*s + phase lands at t = q*s + phase - p (no residual / MRF on these layers).
+// A lane's registers 4g .. 4g+3 are four CONSECUTIVE virtual rows at one position q:
+//   s = 8 (k 16, p 4): four consecutive phases of one output channel -> times 8q + 4*hi - 4 .. +3, one aligned 16-byte store;
+//       the two half-waves of a position cover 32 contiguous bytes, a wave instruction 1 KiB per channel group
+//   s = 2 (k 4, p 1): two channels x two phases -> times 2q - 1, 2q of each, one 8-byte store per channel
+// (round 2 scattered single floats at a stride of s elements: 1.1 TB/s on these four layers).  Vectors that straddle the
+// ends of the utterance (s = 2: q = 0 and q = len_in) fall back to scalar stores.
 template <int WM, int WN, int MT, int NTW>
 __device__ __forceinline__ void conv_epilogue_ups(const ConvArgs& a, f32x16 (&acc)[WM][WN], int b, int mtile, int q0, int wv,
                                                   int l31, int hi, int len_in, int n_q) {
+    typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));   // times 2q - 1, 2q: 4-byte aligned only
     const long ob = (long)b * a.o_bstride;
     const int len_out = len_in * a.ups_s;
 #pragma unroll
@@ -120,15 +127,40 @@ __device__ __forceinline__ void conv_epilogue_ups(const ConvArgs& a, f32x16 (&ac
         float add[16];
         conv_row_adds<MT, true>(a, add, b, mtile, m, hi);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int v = mtile * MT + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const int co = v / a.ups_s;
-            const int toff = (v - co * a.ups_s) - a.ups_p;
+        for (int g = 0; g < 4; ++g) {
+            const int v0 = mtile * MT + m * 32 + 8 * g + 4 * hi;   // first of the lane's four consecutive virtual rows
 #pragma unroll
             for (int n = 0; n < WN; ++n) {
                 const int q = q0 + wv * NTW + n * 32 + l31;
-                const int t = q * a.ups_s + toff;
-                if (q < n_q && t >= 0 && t < len_out) a.out[ob + (long)co * a.o_stride + t] = acc[m][n][r] + add[r];
+                if (q >= n_q) continue;
+                if (a.ups_s == 8 && a.ups_p == 4) {
+                    const int co = v0 >> 3, t0 = q * 8 + (v0 & 7) - 4;   // (v0 & 7) is 0 or 4: the vector is all inside or all outside
+                    if (t0 >= 0 && t0 + 3 < len_out) {
+                        const f32x4 o = {acc[m][n][4 * g] + add[4 * g], acc[m][n][4 * g + 1] + add[4 * g + 1],
+                                         acc[m][n][4 * g + 2] + add[4 * g + 2], acc[m][n][4 * g + 3] + add[4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(a.out + ob + (long)co * a.o_stride + t0) = o;
+                    }
+                } else if (a.ups_s == 2 && a.ups_p == 1) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int co = (v0 >> 1) + c, t0 = 2 * q - 1;
+                        float* dst = a.out + ob + (long)co * a.o_stride;
+                        const float x0 = acc[m][n][4 * g + 2 * c] + add[4 * g + 2 * c], x1 = acc[m][n][4 * g + 2 * c + 1] + add[4 * g + 2 * c + 1];
+                        if (t0 >= 0 && t0 + 1 < len_out) {
+                            *reinterpret_cast<f32x2u*>(dst + t0) = f32x2u{x0, x1};
+                        } else {
+                            if (t0 >= 0 && t0 < len_out) dst[t0] = x0;
+                            if (t0 + 1 >= 0 && t0 + 1 < len_out) dst[t0 + 1] = x1;
+                        }
+                    }
+                } else {   // any other (stride, padding): element by element
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int v = v0 + r, co = v / a.ups_s;
+                        const int t = q * a.ups_s + (v - co * a.ups_s) - a.ups_p;
+                        if (t >= 0 && t < len_out) a.out[ob + (long)co * a.o_stride + t] = acc[m][n][4 * g + r] + add[4 * g + r];
+                    }
+                }
             }
         }
     }

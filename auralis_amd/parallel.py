@@ -61,6 +61,15 @@ def broadcast_conditioning_native(engine, speaker_key: int, gpt_cond_latent: Opt
     engine.broadcast_conditioning(speaker_key, src)
 
 
+def all_ranks_equal(value) -> bool:
+    """True on every rank iff every rank passed the same (picklable) value: the cross-rank check bench.py prints after the
+    conditioning broadcast and after a fixed-seed verification batch.  Collective."""
+    import torch.distributed as dist
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, value)
+    return all(v == got[0] for v in got)
+
+
 def shard_units(n_units: int, world: int, rank: int, per_gpu_batch: int = 64) -> List[int]:
     """Indices of the units (utterance chunks) owned by `rank`: blocks of `per_gpu_batch` dealt round-robin,
     so that C4 (512 utterances, 64/GPU x 8) gives every GPU one full batch and long-form streams stay ordered

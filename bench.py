@@ -298,6 +298,10 @@ def main():
                     help="arithmetic of the decode-regime GEMMs: bf16x3 = exact 3-way bf16 split of the fp32 operands, 6 bf16 MFMAs per "
                          "product, fp32 accumulate (default, the configuration the parity tests run); f32 = v_mfma_f32_16x16x4_f32 "
                          "(aur_config.gemm_f32_exact)")
+    ap.add_argument("--bcast", choices=["native", "torch"], default="native",
+                    help="multi-GPU launches: native = the ncclBroadcast inside the library on the engine's own RCCL communicator "
+                         "(aur_comm_init / aur_broadcast_conditioning, default); torch = torch.distributed.broadcast into a device "
+                         "buffer registered with aur_set_conditioning_device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-throughput-mode", action="store_true", help="skip the extra fp16-K/V measurement after the timed run")
     ap.add_argument("--pipeline", action="store_true",
@@ -348,17 +352,36 @@ def main():
     # speaker conditioning: computed on rank 0, RCCL-broadcast over xGMI, registered from the device buffer
     cond, spk = make_synthetic_conditioning(dims)
     SPK = 1
-    if use_dist and os.environ.get("AUR_NATIVE_BCAST", "0") == "1":
-        # the collective inside the library (aur_comm_init / aur_broadcast_conditioning); opt-in: it could only be exercised
-        # with world_size 1 in the build environment, the default below has run under torchrun
+    multi = {}
+    if use_dist and args.bcast == "native":
+        # the collective inside the library: one ncclBroadcast of 133 120 B on the engine's own RCCL communicator
         from auralis_amd.parallel import broadcast_conditioning_native
         broadcast_conditioning_native(eng, SPK, cond if rank == 0 else None, spk if rank == 0 else None, src=0)
+        multi["rccl_ranks"], multi["rccl_rank_of_rank0"] = eng.comm_info()   # what the communicator itself reports
     elif use_dist:
         broadcast_conditioning(eng, SPK, cond if rank == 0 else None, spk if rank == 0 else None, src=0,
                                device=torch.device("cuda", local_rank))
+        multi["rccl_ranks"] = torch.distributed.get_world_size()
     else:
         eng.set_conditioning(SPK, cond.numpy(), spk.numpy())
     text_ids = make_synthetic_text_ids(dims, n_text=70, seed=11)
+    if use_dist:
+        # self-verification of the multi-GPU path, outside the timed region: (1) the voice every rank holds in device memory is
+        # byte-identical to rank 0's; (2) the SAME small workload (same prompts, same seeds, greedy and sampled) produces
+        # byte-identical ids and PCM on every rank (batch invariance makes that a requirement, not a hope)
+        from auralis_amd.parallel import all_ranks_equal
+        multi["bcast_route"] = args.bcast
+        multi["conditioning_hash_equal_across_ranks"] = all_ranks_equal(eng.conditioning_checksum(SPK))
+        import hashlib
+        for k in range(4):
+            eng.submit(make_synthetic_text_ids(dims, n_text=20 + 5 * k, seed=900 + k), SPK, temperature=(0.0 if k < 2 else 0.75),
+                       top_p=0.85, top_k=50, repetition_penalty=5.0, max_tokens=24, seed=4242 + k, ignore_stop=True)
+        outs = sorted(eng.run_until_done(), key=lambda o: o["seq_id"])
+        hh = hashlib.blake2b(digest_size=16)
+        for o in outs:
+            hh.update(np.asarray(o["tokens"], np.int32).tobytes())
+            hh.update(np.asarray(o["wav"], np.float32).tobytes())
+        multi["output_hash_equal_across_ranks"] = all_ranks_equal(hh.hexdigest())
 
     def run_steps(first: int, n: int):
         """n steps = n batches of `batch` utterances, one after the other.  With --pipeline all n batches are queued at
@@ -395,6 +418,9 @@ def main():
     st = eng.stats()
 
     if use_dist:
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, dt / args.steps * 1e3)
+        multi["per_rank_ms_per_step"] = per_rank
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -405,6 +431,8 @@ def main():
     if rank == 0:
         audio_s = samples / 24000.0
         line = build_report(args, st, dims, world, samples, dt, audio_s)
+        if use_dist:
+            line["multi_gpu"] = multi
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, args.cpu_tokens)
         else:
@@ -424,7 +452,7 @@ def main():
             sc = {"ms_per_6s_reference": (time.perf_counter() - t0) / 5 * 1e3, "what": "aur_compute_conditioning: mel front-ends, "
                   "ConditioningEncoder, PerceiverResampler, ResNet-SE speaker encoder (fp32, host copies included)"}
             if not args.no_cpu_baseline:
-                from auralis_amd import conditioning as Cn
+                from oracle import conditioning_oracle as Cn
                 sd_c = {k: v for k, v in xtts_sd.items() if k.startswith(("conditioning_", "hifigan_decoder.speaker_encoder.", "mel_stats"))}
                 t0 = time.perf_counter()
                 Cn.get_conditioning_latents(sd_c, [_f32_wav(clip)], max_ref_length=30, gpt_cond_len=6, gpt_cond_chunk_len=6)

@@ -5,7 +5,8 @@ import numpy as np
 class FakeNativeEngine:
     n_layer = 1
 
-    def __init__(self, max_seqs=4, fail_on_step=None):
+    def __init__(self, max_seqs=4, fail_on_step=None, conditioning_weights=None):
+        self.conditioning_weights = conditioning_weights   # xtts-v2.safetensors tensors: enables compute_conditioning below
         self.max_seqs = max_seqs
         self.next_id = 1
         self.waiting, self.running, self.done = [], [], []
@@ -13,6 +14,24 @@ class FakeNativeEngine:
         self.submitted = []
         self.fail_on_step = fail_on_step
         self.steps = 0
+
+    def compute_conditioning(self, pcm, max_ref_length=30, gpt_cond_len=6, gpt_cond_chunk_len=6, sound_norm_refs=False):
+        """Stand-in for aur_compute_conditioning (mono float32 PCM at 22 050 Hz per reference): the PyTorch restatement of the
+        conditioning networks in oracle/conditioning_oracle.py (XTTSv2.py:409-468).  Lives here, not in the product."""
+        import torch
+
+        from oracle import conditioning_oracle as Cn
+        assert self.conditioning_weights is not None, "FakeNativeEngine(conditioning_weights=...) needed"
+        sd = {k: v.float() for k, v in self.conditioning_weights.items()}
+        embs, audios = [], []
+        for x in pcm:
+            a = torch.from_numpy(np.asarray(x, np.float32))[None, : 22050 * max_ref_length]
+            if sound_norm_refs:
+                a = (a / torch.abs(a).max()) * 0.75
+            embs.append(Cn.speaker_embedding(sd, a, 22050))
+            audios.append(a)
+        cond = Cn.gpt_cond_latents(sd, torch.cat(audios, dim=-1), 22050, length=gpt_cond_len, chunk_length=gpt_cond_chunk_len)
+        return cond.numpy(), torch.stack(embs).mean(dim=0).numpy()
 
     def set_conditioning(self, key, g, s):
         self.speakers[key] = (np.array(g), np.array(s))

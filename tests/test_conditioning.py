@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from auralis_amd import conditioning as Cn
+from oracle import conditioning_oracle as Cn
 from auralis_amd.checkpoint import conditioning_param_shapes, make_synthetic_conditioning_weights
 from oracle.ref_import import reference_available
 

@@ -179,14 +179,15 @@ def test_audio_reference_without_conditioning_weights_is_rejected_loudly():
 
 
 def test_wav_reference_goes_through_conditioning_encoders(tmp_path, dims):
-    """speaker_files = real wav path / bytes -> conditioning.py -> engine.set_conditioning (cached per reference)."""
+    """speaker_files = real wav path / bytes -> host loader (conditioning.py) -> the engine's compute_conditioning entry point
+    (here the fake's PyTorch stand-in) -> engine.set_conditioning (cached per reference)."""
     from auralis_amd.checkpoint import make_synthetic_conditioning_weights
     sr = 22050
     t = np.arange(int(1.5 * sr)) / sr
     TTSOutput(array=(0.3 * np.sin(2 * np.pi * 330 * t)).astype(np.float32), sample_rate=sr).save(tmp_path / "v.wav")
     w = make_synthetic_conditioning_weights(dims, seed=5)
     w["mel_stats"] = __import__("torch").ones(80)
-    fake = FakeNativeEngine(max_seqs=3)
+    fake = FakeNativeEngine(max_seqs=3, conditioning_weights=w)
     eng = XTTSv2Engine(fake, XTTSTokenizer(None, synthetic=True), max_concurrency=3, conditioning_weights=w)
     tts = TTS(scheduler_max_concurrency=3).with_engine(eng)
     try:
@@ -265,13 +266,15 @@ def test_conditioning_cache_keys_on_full_content_and_parameters(tmp_path, dims, 
 
     from auralis_amd import conditioning as Cn
     calls = []
+    monkeypatch.setattr(Cn, "load_audio", lambda ref, sr: torch.zeros(1, 2205))   # the loader is not what this test is about
 
-    def fake_latents(w, refs, max_ref_length, gpt_cond_len, gpt_cond_chunk_len, sound_norm_refs, load_sr, dev):
-        calls.append((len(refs), gpt_cond_len, sound_norm_refs))
+    def fake_hip(pcm, max_ref_length=30, gpt_cond_len=6, gpt_cond_chunk_len=6, sound_norm_refs=False):
+        calls.append((len(pcm), gpt_cond_len, sound_norm_refs))
         k = float(len(calls))
-        return torch.full((1, 32, 1024), k), torch.full((1, 512, 1), k)
-    monkeypatch.setattr(Cn, "get_conditioning_latents", fake_latents)
-    eng = XTTSv2Engine(FakeNativeEngine(max_seqs=2), XTTSTokenizer(None, synthetic=True), conditioning_weights={"x": 1})
+        return np.full((1, 32, 1024), k, np.float32), np.full((1, 512, 1), k, np.float32)
+    fake = FakeNativeEngine(max_seqs=2)
+    fake.compute_conditioning = fake_hip                                # the engine's aur_compute_conditioning entry point
+    eng = XTTSv2Engine(fake, XTTSTokenizer(None, synthetic=True), conditioning_weights={"x": 1})
     try:
         head = b"RIFF" + bytes(8000)
         a, b = head + b"\\x01" * 4000, head + b"\\x02" * 4000           # same length, same first 8 KB

@@ -41,8 +41,11 @@ def _worker(rank, world, port, out_dir):
     mine = [(i, f"r{rank}") for i in shard_units(10, world, rank, per_gpu_batch=2)]
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
+    from auralis_amd.parallel import all_ranks_equal
+    same = all_ranks_equal(got_g.tobytes())                 # every rank holds the broadcast bytes
+    differ = all_ranks_equal(f"rank {rank}")                # ... and the check can fail
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), g=got_g, s=got_s,
-             order=np.array([i for i, _ in merge_ordered(gathered)]))
+             order=np.array([i for i, _ in merge_ordered(gathered)]), same=np.bool_(same), differ=np.bool_(differ))
     dist.destroy_process_group()
 
 
@@ -56,3 +59,4 @@ def test_broadcast_conditioning_gloo_world2(tmp_path):
         assert np.array_equal(z["g"].reshape(-1), np.arange(32 * 1024, dtype=np.float32))
         assert np.allclose(z["s"].reshape(-1), np.linspace(0, 1, 512, dtype=np.float32))
         assert z["order"].tolist() == list(range(10))
+        assert bool(z["same"]) and not bool(z["differ"])
