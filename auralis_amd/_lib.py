@@ -61,7 +61,9 @@ class aur_stats(C.Structure):
                 ("gemm_kind_launches", C.c_int64 * 5), ("gemm_kind_ms", C.c_double * 5), ("gemm_kind_bytes", C.c_double * 5),
                 ("gemm_kind_flops", C.c_double * 5), ("attn_launches", C.c_int64), ("attn_ms", C.c_double),
                 ("attn_bytes", C.c_double), ("decode_steps", C.c_int64), ("decode_ms", C.c_double), ("prefill_ms", C.c_double),
-                ("decode_weight_bytes", C.c_double), ("decode_kv_bytes", C.c_double)]
+                ("decode_weight_bytes", C.c_double), ("decode_kv_bytes", C.c_double),
+                ("conv_class_launches", C.c_int64 * 5), ("conv_class_ms", C.c_double * 5), ("conv_class_bytes", C.c_double * 5),
+                ("conv_class_flops", C.c_double * 5)]
 
     def as_dict(self) -> Dict[str, float]:
         out = {}

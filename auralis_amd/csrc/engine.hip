@@ -1601,6 +1601,9 @@ private:
                 conv_events_.push_back(e);
             }
             ev = &conv_events_[n_conv_events_++];
+            // class for the per-stage roofline: ResBlock convs by channel count (256 / 128 / 64 / 32 -> 0..3), everything
+            // else (conv_pre, the four transposed convs) -> 4
+            ev->kind = (a.ups_s == 0 && a.Cin == a.Cout) ? (a.Cout == 256 ? 0 : a.Cout == 128 ? 1 : a.Cout == 64 ? 2 : a.Cout == 32 ? 3 : 4) : 4;
             ev->flops = 2.0 * a.Cin * KS * a.Mtot * tot_in;
             // bytes in the dtype each tensor is actually stored in (the c1 -> c2 intermediate may be fp16)
             ev->bytes = (a.x_f16 ? 2.0 : 4.0) * a.Cin * tot_in +
@@ -1622,6 +1625,13 @@ private:
             stats_.conv_flops += conv_events_[i].flops;
             stats_.conv_bytes += conv_events_[i].bytes;
             stats_.conv_launches++;
+            const int k = conv_events_[i].kind;
+            if (k >= 0 && k < 5) {
+                stats_.conv_class_ms[k] += ms;
+                stats_.conv_class_flops[k] += conv_events_[i].flops;
+                stats_.conv_class_bytes[k] += conv_events_[i].bytes;
+                stats_.conv_class_launches[k]++;
+            }
         }
         n_conv_events_ = 0;
         if (voc_timed_) {

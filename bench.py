@@ -187,6 +187,21 @@ def build_report(args, st, dims, world, samples, dt, audio_s):
     if st["conv_ms"] > 0:
         g = 21301.0 * samples / world / (st["conv_ms"] * 1e-3) / 1e9
         roof_conv["survey_8d_fp32_bytes"] = {"bytes_per_sample": 21301, "achieved": g, "frac": g / HBM_PEAK_GBPS}
+    # per class: the wide stages are bounded by the fp16 matrix pipe / LDS, the narrow ones by HBM
+    conv_classes = []
+    names = ["ResBlock convs, 256 channels x 9 752 positions", "ResBlock convs, 128 channels x 78 016", "ResBlock convs, 64 channels x 156 032",
+             "ResBlock convs, 32 channels x 312 064", "conv_pre + 4 polyphase transposed convs"]
+    for k in range(5):
+        n, ms = st["conv_class_launches"][k], st["conv_class_ms"][k]
+        if n and ms > 0:
+            gb = st["conv_class_bytes"][k] / (ms * 1e-3) / 1e9
+            tf = st["conv_class_flops"][k] / (ms * 1e-3) / 1e12
+            pk = FP32_MFMA_PEAK_TFLOPS if args.vocoder == "fp32" else BF16_MFMA_PEAK_TFLOPS
+            t_h, t_m = st["conv_class_bytes"][k] / (HBM_PEAK_GBPS * 1e9), st["conv_class_flops"][k] / (pk * 1e12)
+            conv_classes.append({"class": names[k], "launches": n, "ms": ms, "hbm": {"achieved": gb, "frac": gb / HBM_PEAK_GBPS},
+                                 "mfma": {"achieved": tf, "frac": tf / pk}, "binding_roof": "hbm" if t_h >= t_m else "mfma",
+                                 "frac_of_binding_floor": max(t_h, t_m) / (ms * 1e-3)})
+    roof_conv["by_class"] = conv_classes
     roof_attn = roof("paged_attention_kernel (decode: one query row per sequence against its paged K/V)",
                      st["attn_ms"], st["attn_launches"], st["attn_bytes"], 0.0, 1.0, r"paged_attention_kernel<", "attention",
                      "algorithmic bytes = K and V rows of every live sequence's context (8 KiB per token per layer) + q + out")

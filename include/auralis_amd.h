@@ -136,6 +136,13 @@ typedef struct aur_stats {
     double prefill_ms;
     double decode_weight_bytes;    /* block + head weights, once per step, fp32 as stored */
     double decode_kv_bytes;        /* K/V rows read by attention, all layers, fp32 as stored */
+    /* vocoder conv launches by class (profile mode): 0..3 = ResBlock convs of the 256- / 128- / 64- / 32-channel stage,
+     * 4 = conv_pre and the four polyphase transposed convs.  The stages are bounded differently (the wide ones by the fp16
+     * matrix pipe and LDS, the narrow ones by HBM), so the bench reports a roofline per class. */
+    int64_t conv_class_launches[5];
+    double conv_class_ms[5];
+    double conv_class_bytes[5];
+    double conv_class_flops[5];
 } aur_stats;
 
 const char* aur_last_error(void);
