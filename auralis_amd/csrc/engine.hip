@@ -212,7 +212,7 @@ public:
         for (int i = 2 * S - 1; i >= 0; --i) latpool_free_.push_back(i);
         ws_[0].st = st_;
         ws_[1].st = st2_;
-        xt_f16_ = cfg_.vocoder_fp16 != 0;   // fp16 storage of the ResBlock c1 -> c2 intermediate (bit-identical, see ConvArgs)
+        xt_f16_ = cfg_.vocoder_fp16 != 0;   // fp16 storage of the ResBlock intermediates and residual stream (see ConvArgs)
         if (const char* e = getenv("AUR_XT_F16")) xt_f16_ = xt_f16_ && atoi(e) != 0;
         if (const char* e = getenv("AUR_DECODE_PIPELINE")) pipeline_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_SAMPLER_FULL_SORT")) sampler_full_sort_ = atoi(e) != 0;
@@ -1607,8 +1607,8 @@ private:
             ev->flops = 2.0 * a.Cin * KS * a.Mtot * tot_in;
             // bytes in the dtype each tensor is actually stored in (the c1 -> c2 intermediate may be fp16)
             ev->bytes = (a.x_f16 ? 2.0 : 4.0) * a.Cin * tot_in +
-                        a.Cout * tot_out * ((a.out_act_f16 ? 2.0 : 4.0) + (a.act2 ? 2.0 : 0.0) +
-                                            4.0 * ((a.res ? 1.0 : 0.0) + (a.mrf_mode >= 2 ? 1.0 : 0.0)));
+                        a.Cout * tot_out * ((a.out_act_f16 ? 2.0 : 4.0) +
+                                            (a.res ? (a.res_f16 ? 2.0 : 4.0) : 0.0) + (a.mrf_mode >= 2 ? 4.0 : 0.0));
             HIP_CHECK(hipEventRecord(ev->a, st_voc_));
         }
         if (cfg_.vocoder_fp16)
@@ -1688,7 +1688,7 @@ private:
         const float* in = v_s0_.as<float>();
         int Cin = 512, mul = 1, cond_off = 512;
         float *A = v_A_.as<float>(), *Bb = v_B_.as<float>(), *Cb = v_C_.as<float>(), *D = v_D_.as<float>(), *E = v_E_.as<float>();
-        void* Ch = v_Ch_.p;   // fp16(lrelu(Cb)), interleaved: written by the second conv of rounds 0 / 1, read by the next first conv
+        void* Ch = v_Ch_.p;   // fp16 vocoder: the ResBlock residual stream after rounds 0 / 1 (raw interleaved halves)
         for (int i = 0; i < 4; ++i) {
             const int s = rates[i], C = chans[i], mul_out = mul * s;
             const long Lin = (long)T * mul, Lout = (long)T * mul_out;
@@ -1703,24 +1703,28 @@ private:
             cond_off += C;
             for (int j = 0; j < 3; ++j)
                 for (int c = 0; c < 3; ++c) {
-                    const float* r = (c == 0) ? A : Cb;
-                    // rounds 1 and 2: the first conv reads the fp16 activated copy the previous round's second conv left in Ch
-                    const bool c1_h = xt_f16_ && c > 0;
+                    // fp16 vocoder: the residual stream of a ResBlock lives in Ch as raw (unactivated) interleaved halves after
+                    // round 0 -- read back as the residual (res_f16) and, through lrelu in the staging (x_f16_raw), as the next
+                    // first conv's input; round 0 itself reads the transposed conv's fp32 output A.  fp32 vocoder: Cb, fp32.
+                    const bool h_in = xt_f16_ && c > 0;
+                    const float* r = (c == 0) ? A : h_in ? reinterpret_cast<const float*>(Ch) : Cb;
                     ConvArgs b1{};
                     b1.base_len = d_len; b1.B = B;
-                    b1.x = c1_h ? reinterpret_cast<const float*>(Ch) : r; b1.x_f16 = c1_h ? 1 : 0; b1.wp = v_c1_[i][j][c].wp; b1.wp16 = v_c1_[i][j][c].wp16; b1.bias = v_c1_[i][j][c].bias; b1.out = Bb;
+                    b1.x = r; b1.x_f16 = h_in ? 1 : 0; b1.x_f16_raw = h_in ? 1 : 0;
+                    b1.wp = v_c1_[i][j][c].wp; b1.wp16 = v_c1_[i][j][c].wp16; b1.bias = v_c1_[i][j][c].bias; b1.out = Bb;
                     b1.len_mul = mul_out; b1.Cin = C; b1.Mtot = C; b1.Cout = C;
                     b1.x_stride = Lout; b1.o_stride = Lout; b1.x_bstride = (long)C * Lout; b1.o_bstride = (long)C * Lout;
                     b1.padl = (rk[j] - 1) / 2 * rd[c]; b1.slope = 0.1f; b1.max_len = maxT * mul_out;
-                    if (xt_f16_) { b1.out_act_f16 = 1; b1.out_slope = 0.1f; }
+                    if (xt_f16_) { b1.out_act_f16 = 1; b1.out_slope = 0.1f; }   // c1 -> c2 intermediate: fp16(lrelu(.)), what c2 stages anyway
                     conv(b1, rk[j], rd[c], totT * mul_out, totT * mul_out);
                     ConvArgs b2 = b1;
-                    b2.out_act_f16 = 0; b2.x_f16 = xt_f16_ ? 1 : 0;
-                    if (xt_f16_ && c < 2) { b2.act2 = Ch; b2.act2_slope = 0.1f; }
-                    b2.x = Bb; b2.wp = v_c2_[i][j][c].wp; b2.wp16 = v_c2_[i][j][c].wp16; b2.bias = v_c2_[i][j][c].bias; b2.res = r;
+                    b2.out_act_f16 = 0; b2.x_f16 = xt_f16_ ? 1 : 0; b2.x_f16_raw = 0;
+                    b2.x = Bb; b2.wp = v_c2_[i][j][c].wp; b2.wp16 = v_c2_[i][j][c].wp16; b2.bias = v_c2_[i][j][c].bias;
+                    b2.res = r; b2.res_f16 = h_in ? 1 : 0;
                     b2.padl = (rk[j] - 1) / 2;
                     if (c < 2) {
-                        b2.out = Cb;
+                        if (xt_f16_) { b2.out = reinterpret_cast<float*>(Ch); b2.out_act_f16 = 1; b2.out_slope = 1.0f; }
+                        else b2.out = Cb;
                     } else {
                         b2.mrf = D; b2.out = E; b2.mrf_mode = (j == 0) ? 1 : (j == 1) ? 2 : 3;
                     }

@@ -41,11 +41,13 @@ struct ConvArgs {
     // of 16 two-byte ones; the producer stores 4 channels = 8 bytes at a time instead of single halves).
     int x_f16, out_act_f16;
     float out_slope;
-    // Second output of a residual conv: act2 = fp16(lrelu(out, act2_slope)) of the fp32 value it stores in `out`, in the same
-    // interleaved layout (strides o_stride / o_bstride), consumed by the next round's first conv with x_f16 — that conv then
-    // stages 2 B per element without conversion instead of 4 B + lrelu + cvt.  nullptr = off.
-    void* act2;
-    float act2_slope;
+    // fp16 residual stream inside a ResBlock (round 3): with out_act_f16 and out_slope == 1 a residual conv stores the
+    // UNACTIVATED sum x + conv(..) as interleaved halves; the next round's first conv reads it with x_f16 + x_f16_raw (its
+    // staging applies lrelu(slope) to the halves: max(x, slope * x), two packed instructions per 16 bytes) and the next
+    // residual conv reads it back with res_f16 (8-byte loads of 4 channels).  res and out may alias (each element is read and
+    // then written by the same lane).  This is the precision of the reference's own GPU path, which runs the ResBlocks
+    // under fp16 autocast (hifigan_decoder.py:242); the MRF sums stay fp32.
+    int x_f16_raw, res_f16;
 };
 
 void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st);

@@ -65,7 +65,17 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, f32x16 (&
             float rv[16], mv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-            if (has_res) {
+            if (has_res && a.res_f16) {   // interleaved halves: registers 4g .. 4g+3 are 8 contiguous bytes
+                const _Float16* rb = reinterpret_cast<const _Float16*>(a.res) + ob;
+                const int c0 = mtile * MT + m * 32 + 4 * hi;
+                const int qc = min(q, n_q - 1);
+                h16x4v hv[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    hv[g] = *reinterpret_cast<const h16x4v*>(rb + ((long)((c0 + 8 * g) >> 4) * a.o_stride + qc) * 16 + ((c0 + 8 * g) & 15));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = (float)hv[r >> 2][r & 3];
+            } else if (has_res) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) rv[r] = a.res[base + (long)((r & 3) + 8 * (r >> 2)) * a.o_stride];
             }
@@ -102,7 +112,6 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, f32x16 (&
                         else if (MODE == 2) a.mrf[off] = mv[r] + val[r];
                         else a.out[off] = (mv[r] + val[r]) / 3.0f;
                     }
-                    if (MODE == 0 && a.act2) store_h(a.act2, a.act2_slope);
                 }
             }
         }
@@ -364,7 +373,8 @@ void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
 //   B[k][n = lane&31]                 = x[ci0 + k][t]     (LDS rows [t][16 ch], 48-B row pitch => conflict-free b128)
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
-// XH: the input tensor is fp16 in HBM and already activated (ConvArgs::x_f16), staged without conversion.
+// XH: the input tensor is fp16 in HBM (ConvArgs::x_f16): already activated and staged as is, or raw (x_f16_raw) with the
+// leaky ReLU applied to the halves on the way into LDS.
 // PF: software-pipelined staging — the global loads of chunk i+1 are issued before the MFMAs of chunk i and parked in
 // registers (2 waves per SIMD: ~200 VGPRs, no spills); !PF: synchronous staging at 3 waves per SIMD (under the 168-VGPR cap of
 // 3 waves the prefetch registers spilled, which is why round 1 measured it slower).
@@ -407,6 +417,7 @@ __global__ __launch_bounds__(256, ((PF && !XH) || WIDE) ? 2 : 3) void conv1d_mfm
     const float* xb = a.x + (long)b * a.x_bstride;
     const _Float16* xhb = reinterpret_cast<const _Float16*>(a.x) + (long)b * a.x_bstride;
     const float slope = a.slope;
+    const _Float16 hslope = (_Float16)((XH && a.x_f16_raw) ? a.slope : 1.0f);
     const uint4* wsrc_tile = reinterpret_cast<const uint4*>(a.wp16) + (long)mtile * (a.Cin / CK) * NW;
 
     float xv[XH ? 1 : XI][XH ? 1 : CK];
@@ -461,6 +472,8 @@ __global__ __launch_bounds__(256, ((PF && !XH) || WIDE) ? 2 : 3) void conv1d_mfm
                 const h16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
                 lo = ok ? xlo[it] : zero;
                 hh = ok ? xhh[it] : zero;
+                lo = __builtin_elementwise_max(lo, lo * hslope);   // lrelu on raw inputs (x_f16_raw), identity (slope 1) otherwise
+                hh = __builtin_elementwise_max(hh, hh * hslope);
             } else {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
@@ -520,8 +533,9 @@ template <int KS, int DIL, bool XH, bool PF, bool WIDE>
 static void launch_conv_f16_pf(const ConvArgs& a, hipStream_t st) {
     AUR_REQUIRE(a.Cin % 16 == 0 && a.wp16, "conv f16: Cin % 16, packed fp16 weights");
     AUR_REQUIRE(!a.out_act_f16 || (a.mrf_mode == 0 && a.ups_s == 0), "conv f16: fp16 output only for plain convs");
-    AUR_REQUIRE(!a.act2 || (a.mrf_mode == 0 && a.ups_s == 0 && !a.out_act_f16), "conv f16: act2 only next to a plain fp32 output");
-    AUR_REQUIRE((!a.x_f16 && !a.out_act_f16 && !a.act2) || (a.Cin % 16 == 0 && a.Cout % 16 == 0), "conv f16: interleaved tensors need 16-channel chunks");
+    AUR_REQUIRE((!a.x_f16 && !a.out_act_f16 && !a.res_f16) || (a.Cin % 16 == 0 && a.Cout % 16 == 0), "conv f16: interleaved tensors need 16-channel chunks");
+    AUR_REQUIRE(!a.x_f16_raw || a.x_f16, "conv f16: x_f16_raw needs x_f16");
+    AUR_REQUIRE(!a.res_f16 || (a.res && a.ups_s == 0), "conv f16: fp16 residual only on plain convs");
     const int n_q = a.ups_s ? a.max_len + 1 : a.max_len;
     trace_launch("conv1d_mfma_f16_kernel");
     if (a.Mtot % 64 == 0) {

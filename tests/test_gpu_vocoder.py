@@ -106,9 +106,10 @@ def test_vocoder_fp16_full_length(ctx16, ctx, dims):
     assert np.array_equal(w16[0], e16.vocode(lat[:1], None, SPK_KEY)[0])       # deterministic, batch invariant
 
 
-def test_vocoder_fp16_intermediate_storage_is_bit_identical(ctx16, monkeypatch):
-    """The ResBlock c1 -> c2 intermediate is stored as fp16(lrelu(x)) in HBM (what the consumer's staging computes
-    anyway); AUR_XT_F16=0 keeps it fp32.  Both engines must produce the same bits."""
+def test_vocoder_fp16_storage_of_resblock_tensors(ctx16, monkeypatch):
+    """fp16 vocoder: the ResBlock c1 -> c2 intermediate and the residual stream between rounds live in HBM as halves (the
+    reference's GPU path runs these blocks under fp16 autocast, hifigan_decoder.py:242); AUR_XT_F16=0 keeps both fp32 with
+    the same fp16 MFMA inputs.  The two must agree far inside the north_star tolerance."""
     e16, _, _ = ctx16
     monkeypatch.setenv("AUR_XT_F16", "0")
     e_ref, *_ = make_engine(1, max_seqs=2, vocoder_fp16=True)
@@ -118,6 +119,8 @@ def test_vocoder_fp16_intermediate_storage_is_bit_identical(ctx16, monkeypatch):
         a = e16.vocode(lat, [57, 20], SPK_KEY)
         b = e_ref.vocode(lat, [57, 20], SPK_KEY)
         for x, y in zip(a, b):
-            assert np.array_equal(x, y)
+            err, sig = rms(x - y), rms(y)
+            print(f"fp16 residual stream vs fp32 storage: rms err {err:.3e} signal rms {sig:.3e}")
+            assert x.shape == y.shape and err <= 1e-4 and err <= 2e-3 * sig, (err, sig)
     finally:
         e_ref.close()
