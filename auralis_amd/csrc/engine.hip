@@ -1606,9 +1606,9 @@ private:
             ev->kind = (a.ups_s == 0 && a.Cin == a.Cout) ? (a.Cout == 256 ? 0 : a.Cout == 128 ? 1 : a.Cout == 64 ? 2 : a.Cout == 32 ? 3 : 4) : 4;
             ev->flops = 2.0 * a.Cin * KS * a.Mtot * tot_in;
             // bytes in the dtype each tensor is actually stored in (the c1 -> c2 intermediate may be fp16)
-            ev->bytes = (a.x_f16 ? 2.0 : 4.0) * a.Cin * tot_in +
-                        a.Cout * tot_out * ((a.out_act_f16 ? 2.0 : 4.0) +
-                                            (a.res ? (a.res_f16 ? 2.0 : 4.0) : 0.0) + (a.mrf_mode >= 2 ? 4.0 : 0.0));
+            const double mrf_b = a.mrf_f16 ? 2.0 : 4.0;
+            const double out_b = a.mrf_mode == 0 ? (a.out_act_f16 ? 2.0 : 4.0) : a.mrf_mode == 1 ? mrf_b : a.mrf_mode == 2 ? 2.0 * mrf_b : mrf_b + 4.0;
+            ev->bytes = (a.x_f16 ? 2.0 : 4.0) * a.Cin * tot_in + a.Cout * tot_out * (out_b + (a.res ? (a.res_f16 ? 2.0 : 4.0) : 0.0));
             HIP_CHECK(hipEventRecord(ev->a, st_voc_));
         }
         if (cfg_.vocoder_fp16)
@@ -1670,8 +1670,14 @@ private:
         const size_t T = (size_t)maxT, Bz = (size_t)B;
         v_z_.ensure(Bz * 1024 * T * 4);
         v_s0_.ensure(Bz * 512 * T * 4);
-        for (auto* b : {&v_A_, &v_B_, &v_C_, &v_D_, &v_E_}) b->ensure(Bz * 8192 * T * 4);
-        v_Ch_.ensure(Bz * 8192 * T * 2);
+        for (auto* b : {&v_B_, &v_D_, &v_E_}) b->ensure(Bz * 8192 * T * 4);
+        if (xt_f16_) {   // the residual stream as activated halves (stage input, running value)
+            v_Ah_.ensure(Bz * 8192 * T * 2);
+            v_Ch_.ensure(Bz * 8192 * T * 2);
+        } else {
+            v_A_.ensure(Bz * 8192 * T * 4);
+            v_C_.ensure(Bz * 8192 * T * 4);
+        }
         HIP_CHECK(hipEventRecord(ev_va_, st_voc_));
         launch_interp2(d_lat, lat_bstride, d_latrow, d_nlat, d_len, v_z_.as<float>(), (long)T, (long)(1024 * T), 1024, B, maxT, st_voc_);
         const float* condt = voc_cond_.as<float>();
@@ -1688,7 +1694,7 @@ private:
         const float* in = v_s0_.as<float>();
         int Cin = 512, mul = 1, cond_off = 512;
         float *A = v_A_.as<float>(), *Bb = v_B_.as<float>(), *Cb = v_C_.as<float>(), *D = v_D_.as<float>(), *E = v_E_.as<float>();
-        void* Ch = v_Ch_.p;   // fp16 vocoder: the ResBlock residual stream after rounds 0 / 1 (raw interleaved halves)
+        void *Ah = v_Ah_.p, *Ch = v_Ch_.p;   // fp16 vocoder: the activated residual stream (stage input / after rounds 0, 1)
         for (int i = 0; i < 4; ++i) {
             const int s = rates[i], C = chans[i], mul_out = mul * s;
             const long Lin = (long)T * mul, Lout = (long)T * mul_out;
@@ -1699,18 +1705,19 @@ private:
             a.len_mul = mul; a.Cin = Cin; a.Mtot = C * s; a.Cout = C;
             a.x_stride = Lin; a.x_bstride = (long)Cin * Lin; a.o_stride = Lout; a.o_bstride = (long)C * Lout;
             a.padl = 1; a.slope = 0.1f; a.ups_s = s; a.ups_p = (kern[i] - s) / 2; a.mrf_mode = 0; a.max_len = maxT * mul;
+            if (xt_f16_) { a.out = reinterpret_cast<float*>(Ah); a.out_act_f16 = 1; a.out_slope = 0.1f; }
             conv(a, 2, 1, totT * mul, totT * mul_out);
             cond_off += C;
             for (int j = 0; j < 3; ++j)
                 for (int c = 0; c < 3; ++c) {
-                    // fp16 vocoder: the residual stream of a ResBlock lives in Ch as raw (unactivated) interleaved halves after
-                    // round 0 -- read back as the residual (res_f16) and, through lrelu in the staging (x_f16_raw), as the next
-                    // first conv's input; round 0 itself reads the transposed conv's fp32 output A.  fp32 vocoder: Cb, fp32.
-                    const bool h_in = xt_f16_ && c > 0;
-                    const float* r = (c == 0) ? A : h_in ? reinterpret_cast<const float*>(Ch) : Cb;
+                    // fp16 vocoder: the residual stream of a ResBlock lives in HBM as activated interleaved halves, fp16(lrelu(x)):
+                    // Ah (the transposed conv's output, shared by the stage's three ResBlocks) in round 0, Ch (updated in place by
+                    // the residual convs) afterwards.  First convs stage it as is; residual convs read it back and undo the
+                    // activation (ConvArgs::res_f16).  fp32 vocoder: A / Cb, fp32.
+                    const float* r = xt_f16_ ? reinterpret_cast<const float*>(c == 0 ? Ah : Ch) : (c == 0 ? A : Cb);
                     ConvArgs b1{};
                     b1.base_len = d_len; b1.B = B;
-                    b1.x = r; b1.x_f16 = h_in ? 1 : 0; b1.x_f16_raw = h_in ? 1 : 0;
+                    b1.x = r; b1.x_f16 = xt_f16_ ? 1 : 0;
                     b1.wp = v_c1_[i][j][c].wp; b1.wp16 = v_c1_[i][j][c].wp16; b1.bias = v_c1_[i][j][c].bias; b1.out = Bb;
                     b1.len_mul = mul_out; b1.Cin = C; b1.Mtot = C; b1.Cout = C;
                     b1.x_stride = Lout; b1.o_stride = Lout; b1.x_bstride = (long)C * Lout; b1.o_bstride = (long)C * Lout;
@@ -1718,15 +1725,17 @@ private:
                     if (xt_f16_) { b1.out_act_f16 = 1; b1.out_slope = 0.1f; }   // c1 -> c2 intermediate: fp16(lrelu(.)), what c2 stages anyway
                     conv(b1, rk[j], rd[c], totT * mul_out, totT * mul_out);
                     ConvArgs b2 = b1;
-                    b2.out_act_f16 = 0; b2.x_f16 = xt_f16_ ? 1 : 0; b2.x_f16_raw = 0;
+                    b2.out_act_f16 = 0;
                     b2.x = Bb; b2.wp = v_c2_[i][j][c].wp; b2.wp16 = v_c2_[i][j][c].wp16; b2.bias = v_c2_[i][j][c].bias;
-                    b2.res = r; b2.res_f16 = h_in ? 1 : 0;
+                    b2.res = r;
+                    if (xt_f16_) { b2.res_f16 = 1; b2.res_unact = 1.0f / 0.1f; }
                     b2.padl = (rk[j] - 1) / 2;
                     if (c < 2) {
-                        if (xt_f16_) { b2.out = reinterpret_cast<float*>(Ch); b2.out_act_f16 = 1; b2.out_slope = 1.0f; }
+                        if (xt_f16_) { b2.out = reinterpret_cast<float*>(Ch); b2.out_act_f16 = 1; b2.out_slope = 0.1f; }
                         else b2.out = Cb;
                     } else {
                         b2.mrf = D; b2.out = E; b2.mrf_mode = (j == 0) ? 1 : (j == 1) ? 2 : 3;
+                        b2.mrf_f16 = xt_f16_ ? 1 : 0;   // D: running sum of the three ResBlock outputs (halves in fp16 mode)
                     }
                     conv(b2, rk[j], 1, totT * mul_out, totT * mul_out);
                 }
@@ -1900,7 +1909,7 @@ private:
     // vocoder
     ConvLayer v_pre_, v_ups_[4], v_c1_[4][3][3], v_c2_[4][3][3];
     const float* v_post_ = nullptr;
-    DevBuf v_meta_, v_z_, v_s0_, v_A_, v_B_, v_C_, v_D_, v_E_, v_Ch_, tmp_lat_, tmp_wav_;
+    DevBuf v_meta_, v_z_, v_s0_, v_A_, v_B_, v_C_, v_D_, v_E_, v_Ch_, v_Ah_, tmp_lat_, tmp_wav_;
     std::vector<ConvEvent> conv_events_;
     std::vector<ConvEvent> gemm_events_;
     size_t n_gemm_events_ = 0;

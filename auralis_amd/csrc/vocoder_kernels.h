@@ -35,19 +35,23 @@ struct ConvArgs {
     // fp16 kernel only: the c1 -> c2 intermediate of a ResBlock can live in HBM as fp16.  out_act_f16: the epilogue
     // stores (_Float16)lrelu(value, out_slope) -- exactly what the consumer's staging would have produced from the fp32
     // value -- and the consumer sets x_f16 (input rows are halves, already activated; its `slope` is ignored).
-    // Strides stay in elements.  Bit-identical results, half the bytes for that tensor.
+    // Strides stay in elements.
     // The fp16 activated tensors are CHANNEL-CHUNK INTERLEAVED: [B][C/16][stride positions][16 channels] halves, i.e. the 16
     // input channels a staging chunk needs for one position are 32 contiguous bytes (two 16-byte loads per position instead
     // of 16 two-byte ones; the producer stores 4 channels = 8 bytes at a time instead of single halves).
     int x_f16, out_act_f16;
     float out_slope;
-    // fp16 residual stream inside a ResBlock (round 3): with out_act_f16 and out_slope == 1 a residual conv stores the
-    // UNACTIVATED sum x + conv(..) as interleaved halves; the next round's first conv reads it with x_f16 + x_f16_raw (its
-    // staging applies lrelu(slope) to the halves: max(x, slope * x), two packed instructions per 16 bytes) and the next
-    // residual conv reads it back with res_f16 (8-byte loads of 4 channels).  res and out may alias (each element is read and
-    // then written by the same lane).  This is the precision of the reference's own GPU path, which runs the ResBlocks
-    // under fp16 autocast (hifigan_decoder.py:242); the MRF sums stay fp32.
-    int x_f16_raw, res_f16;
+    // fp16 residual stream inside a ResBlock (round 3).  The stream is stored ACTIVATED: y = fp16(lrelu(x, 0.1)) in the
+    // interleaved layout (out_act_f16 + out_slope on the producer: the polyphase transposed conv that opens a stage, and the
+    // residual convs of rounds 0 / 1).  The first conv of a round stages y as is (x_f16); the residual conv of the round reads
+    // it back with res_f16 and undoes the activation, x = y >= 0 ? y : y * res_unact (res_unact = 1 / slope; the leaky ReLU is
+    // invertible, so one 2-byte tensor serves both uses).  res and out may alias (each element is read and then written by the
+    // same lane).  This is the precision of the reference's own GPU path, which runs the ResBlocks under fp16 autocast
+    // (hifigan_decoder.py:242).  mrf_f16: the running MRF sum (mrf_mode 1 / 2 write it, 2 / 3 read it) is interleaved halves
+    // too; the stage output of mrf_mode 3 stays fp32.
+    int res_f16;
+    float res_unact;
+    int mrf_f16;
 };
 
 void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st);

@@ -46,6 +46,7 @@ __device__ __forceinline__ void conv_row_adds(const ConvArgs& a, float (&add)[16
 }
 
 typedef _Float16 h16x4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 // plain conv (ups_s == 0): t == q, len_out == n_q
 template <int WM, int WN, int MT, int NTW, int MODE>
@@ -57,40 +58,54 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, f32x16 (&
     for (int m = 0; m < WM; ++m) {
         float add[16];
         conv_row_adds<MT, false>(a, add, b, mtile, m, hi);
+        // interleaved fp16 tensors: this lane's registers 4g .. 4g+3 are channels c0 + 8g .. +3 of one position, i.e. 8
+        // contiguous bytes at [chunk (c0 + 8g)/16][q][(c0 + 8g) % 16]
+        const int c0 = mtile * MT + m * 32 + 4 * hi;
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
             const int q = q0 + wv * NTW + n * 32 + l31;
             const bool ok = q < n_q;
-            const long base = ob + (long)(mtile * MT + m * 32 + 4 * hi) * a.o_stride + min(q, n_q - 1);
-            float rv[16], mv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-            if (has_res && a.res_f16) {   // interleaved halves: registers 4g .. 4g+3 are 8 contiguous bytes
-                const _Float16* rb = reinterpret_cast<const _Float16*>(a.res) + ob;
-                const int c0 = mtile * MT + m * 32 + 4 * hi;
-                const int qc = min(q, n_q - 1);
+            const int qc = min(q, n_q - 1);
+            const long base = ob + (long)c0 * a.o_stride + qc;
+            auto load_h = [&](const void* src, float (&v)[16]) {
+                const _Float16* hb = reinterpret_cast<const _Float16*>(src) + ob;
                 h16x4v hv[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    hv[g] = *reinterpret_cast<const h16x4v*>(rb + ((long)((c0 + 8 * g) >> 4) * a.o_stride + qc) * 16 + ((c0 + 8 * g) & 15));
+                    hv[g] = *reinterpret_cast<const h16x4v*>(hb + ((long)((c0 + 8 * g) >> 4) * a.o_stride + qc) * 16 + ((c0 + 8 * g) & 15));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) rv[r] = (float)hv[r >> 2][r & 3];
+                for (int r = 0; r < 16; ++r) v[r] = (float)hv[r >> 2][r & 3];
+            };
+            float rv[16], mv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            if (has_res && a.res_f16) {
+                load_h(a.res, rv);
             } else if (has_res) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) rv[r] = a.res[base + (long)((r & 3) + 8 * (r >> 2)) * a.o_stride];
             }
             if (MODE >= 2) {
+                if (a.mrf_f16) {
+                    load_h(a.mrf, mv);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mv[r] = a.mrf[base + (long)((r & 3) + 8 * (r >> 2)) * a.o_stride];
+                    for (int r = 0; r < 16; ++r) mv[r] = a.mrf[base + (long)((r & 3) + 8 * (r >> 2)) * a.o_stride];
+                }
             }
             __builtin_amdgcn_sched_barrier(0);   // all loads of this 32x32 tile are in flight before the first use
             if (ok) {
+                if (has_res && a.res_f16) {   // the stream is stored activated: undo the (invertible) leaky ReLU
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = rv[r] < 0.f ? rv[r] * a.res_unact : rv[r];
+                }
                 float val[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) val[r] = acc[m][n][r] + add[r] + rv[r];
-                // interleaved fp16 tensors: this lane's registers 4g .. 4g+3 are channels c0 + 8g .. +3 of position q, i.e. 8
-                // contiguous bytes at [chunk (c0 + 8g)/16][q][(c0 + 8g) % 16]
-                const int c0 = mtile * MT + m * 32 + 4 * hi;
+                if (MODE == 2) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) val[r] += mv[r];
+                }
                 auto store_h = [&](void* dst, float sl) {
                     _Float16* hb = reinterpret_cast<_Float16*>(dst) + ob;
 #pragma unroll
@@ -103,13 +118,14 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, f32x16 (&
                 };
                 if (MODE == 0 && a.out_act_f16) {
                     store_h(a.out, a.out_slope);
+                } else if ((MODE == 1 || MODE == 2) && a.mrf_f16) {
+                    store_h(a.mrf, 1.0f);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const long off = base + (long)((r & 3) + 8 * (r >> 2)) * a.o_stride;
                         if (MODE == 0) a.out[off] = val[r];
-                        else if (MODE == 1) a.mrf[off] = val[r];
-                        else if (MODE == 2) a.mrf[off] = mv[r] + val[r];
+                        else if (MODE == 1 || MODE == 2) a.mrf[off] = val[r];
                         else a.out[off] = (mv[r] + val[r]) / 3.0f;
                     }
                 }
@@ -131,6 +147,80 @@ __device__ __forceinline__ void conv_epilogue_ups(const ConvArgs& a, f32x16 (&ac
     typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));   // times 2q - 1, 2q: 4-byte aligned only
     const long ob = (long)b * a.o_bstride;
     const int len_out = len_in * a.ups_s;
+    if (a.out_act_f16) {
+        // fp16(lrelu(.)) into the interleaved layout [C/16][t][16]: the lane's 4 * WM register groups are 4 * WM adjacent
+        // channels (s = 8) or, together with the lane 32 places away, 16 adjacent channels (s = 2) of one output time
+        _Float16* hb = reinterpret_cast<_Float16*>(a.out) + ob;
+        float add[WM][16];
+#pragma unroll
+        for (int m = 0; m < WM; ++m) conv_row_adds<MT, true>(a, add[m], b, mtile, m, hi);
+        const float sl = a.out_slope;
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const int q = q0 + wv * NTW + n * 32 + l31;
+            if (q >= n_q) continue;   // (both lanes of an exchange pair share q)
+            if (a.ups_s == 8 && a.ups_p == 4) {
+                // rows 8g + 4hi + r of the 32-row tile m: channel mtile*MT/8 + 4m + g, time 8q + 4hi - 4 + r
+                const int cb = mtile * (MT / 8);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = 8 * q + 4 * hi - 4 + r;
+                    if (t < 0 || t >= len_out) continue;
+                    _Float16* dst = hb + ((long)(cb >> 4) * a.o_stride + t) * 16 + (cb & 15);
+#pragma unroll
+                    for (int m = 0; m < WM; ++m) {
+                        const h16x4v hv = {(_Float16)lrelu(acc[m][n][r] + add[m][r], sl), (_Float16)lrelu(acc[m][n][4 + r] + add[m][4 + r], sl),
+                                           (_Float16)lrelu(acc[m][n][8 + r] + add[m][8 + r], sl), (_Float16)lrelu(acc[m][n][12 + r] + add[m][12 + r], sl)};
+                        *reinterpret_cast<h16x4v*>(dst + 4 * m) = hv;
+                    }
+                }
+            } else if (a.ups_s == 2 && a.ups_p == 1) {
+                // rows 8g + 4hi + 2c + ph: channel mtile*MT/2 + 16m + 4g + 2hi + c, time 2q - 1 + ph.  The half-wave hi keeps
+                // phase hi of all four channels 4g .. 4g+3 and trades its other phase with lane ^ 32.
+                const int t = 2 * q - 1 + hi;
+                const bool tok = t >= 0 && t < len_out;
+#pragma unroll
+                for (int m = 0; m < WM; ++m) {
+                    typedef _Float16 h16x2v __attribute__((ext_vector_type(2)));
+                    h16x8 o[2];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        h16x2v mine, give;   // channels c = 0, 1 at my phase / at the partner's phase
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const float v0 = lrelu(acc[m][n][4 * g + 2 * c] + add[m][4 * g + 2 * c], sl);
+                            const float v1 = lrelu(acc[m][n][4 * g + 2 * c + 1] + add[m][4 * g + 2 * c + 1], sl);
+                            mine[c] = (_Float16)(hi ? v1 : v0);
+                            give[c] = (_Float16)(hi ? v0 : v1);
+                        }
+                        const int got_i = __shfl_xor(__builtin_bit_cast(int, give), 32);
+                        const h16x2v got = __builtin_bit_cast(h16x2v, got_i);
+                        // channels 4g + {0,1} come from the hi = 0 lane, 4g + {2,3} from the hi = 1 lane
+                        const h16x2v lo2 = hi ? got : mine, hi2 = hi ? mine : got;
+                        o[g >> 1][4 * (g & 1) + 0] = lo2[0]; o[g >> 1][4 * (g & 1) + 1] = lo2[1];
+                        o[g >> 1][4 * (g & 1) + 2] = hi2[0]; o[g >> 1][4 * (g & 1) + 3] = hi2[1];
+                    }
+                    if (tok) {
+                        const int cb = mtile * (MT / 2) + 16 * m;
+                        _Float16* dst = hb + ((long)(cb >> 4) * a.o_stride + t) * 16;
+                        *reinterpret_cast<h16x8*>(dst) = o[0];
+                        *reinterpret_cast<h16x8*>(dst + 8) = o[1];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int v = mtile * MT + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, co = v / a.ups_s;
+                        const int t = q * a.ups_s + (v - co * a.ups_s) - a.ups_p;
+                        if (t >= 0 && t < len_out)
+                            hb[((long)(co >> 4) * a.o_stride + t) * 16 + (co & 15)] = (_Float16)lrelu(acc[m][n][r] + add[m][r], sl);
+                    }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
         float add[16];
@@ -371,10 +461,8 @@ void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
 // HBM and are rounded to fp16 (RN) when they are staged into LDS.  One MFMA consumes 16 input channels of one tap:
 //   A[i = lane&31][k = 8*(lane>>5)+e] = W[co][ci0 + k]   (LDS rows [tap*MT + co][16 ch], 48-B row pitch)
 //   B[k][n = lane&31]                 = x[ci0 + k][t]     (LDS rows [t][16 ch], 48-B row pitch => conflict-free b128)
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
-// XH: the input tensor is fp16 in HBM (ConvArgs::x_f16): already activated and staged as is, or raw (x_f16_raw) with the
-// leaky ReLU applied to the halves on the way into LDS.
+// XH: the input tensor is fp16 in HBM and already activated (ConvArgs::x_f16), staged without conversion.
 // PF: software-pipelined staging — the global loads of chunk i+1 are issued before the MFMAs of chunk i and parked in
 // registers (2 waves per SIMD: ~200 VGPRs, no spills); !PF: synchronous staging at 3 waves per SIMD (under the 168-VGPR cap of
 // 3 waves the prefetch registers spilled, which is why round 1 measured it slower).
@@ -417,7 +505,6 @@ __global__ __launch_bounds__(256, ((PF && !XH) || WIDE) ? 2 : 3) void conv1d_mfm
     const float* xb = a.x + (long)b * a.x_bstride;
     const _Float16* xhb = reinterpret_cast<const _Float16*>(a.x) + (long)b * a.x_bstride;
     const float slope = a.slope;
-    const _Float16 hslope = (_Float16)((XH && a.x_f16_raw) ? a.slope : 1.0f);
     const uint4* wsrc_tile = reinterpret_cast<const uint4*>(a.wp16) + (long)mtile * (a.Cin / CK) * NW;
 
     float xv[XH ? 1 : XI][XH ? 1 : CK];
@@ -472,8 +559,6 @@ __global__ __launch_bounds__(256, ((PF && !XH) || WIDE) ? 2 : 3) void conv1d_mfm
                 const h16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
                 lo = ok ? xlo[it] : zero;
                 hh = ok ? xhh[it] : zero;
-                lo = __builtin_elementwise_max(lo, lo * hslope);   // lrelu on raw inputs (x_f16_raw), identity (slope 1) otherwise
-                hh = __builtin_elementwise_max(hh, hh * hslope);
             } else {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
@@ -532,9 +617,9 @@ __global__ __launch_bounds__(256, ((PF && !XH) || WIDE) ? 2 : 3) void conv1d_mfm
 template <int KS, int DIL, bool XH, bool PF, bool WIDE>
 static void launch_conv_f16_pf(const ConvArgs& a, hipStream_t st) {
     AUR_REQUIRE(a.Cin % 16 == 0 && a.wp16, "conv f16: Cin % 16, packed fp16 weights");
-    AUR_REQUIRE(!a.out_act_f16 || (a.mrf_mode == 0 && a.ups_s == 0), "conv f16: fp16 output only for plain convs");
-    AUR_REQUIRE((!a.x_f16 && !a.out_act_f16 && !a.res_f16) || (a.Cin % 16 == 0 && a.Cout % 16 == 0), "conv f16: interleaved tensors need 16-channel chunks");
-    AUR_REQUIRE(!a.x_f16_raw || a.x_f16, "conv f16: x_f16_raw needs x_f16");
+    AUR_REQUIRE(!a.out_act_f16 || a.mrf_mode == 0, "conv f16: fp16 output not next to an MRF accumulator");
+    AUR_REQUIRE(!a.mrf_f16 || a.mrf_mode != 0, "conv f16: mrf_f16 without an MRF mode");
+    AUR_REQUIRE((!a.x_f16 && !a.out_act_f16 && !a.res_f16 && !a.mrf_f16) || (a.Cin % 16 == 0 && a.Cout % 16 == 0), "conv f16: interleaved tensors need 16-channel chunks");
     AUR_REQUIRE(!a.res_f16 || (a.res && a.ups_s == 0), "conv f16: fp16 residual only on plain convs");
     const int n_q = a.ups_s ? a.max_len + 1 : a.max_len;
     trace_launch("conv1d_mfma_f16_kernel");
