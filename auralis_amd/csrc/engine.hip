@@ -214,6 +214,7 @@ public:
         ws_[1].st = st2_;
         xt_f16_ = cfg_.vocoder_fp16 != 0;   // fp16 storage of the ResBlock intermediates and residual stream (see ConvArgs)
         if (const char* e = getenv("AUR_XT_F16")) xt_f16_ = xt_f16_ && atoi(e) != 0;
+        if (const char* e = getenv("AUR_CONV_DMA")) conv_dma_ = atoi(e) != 0;   // 0: register-staged ResBlock convs (A/B only)
         if (const char* e = getenv("AUR_DECODE_PIPELINE")) pipeline_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_SAMPLER_FULL_SORT")) sampler_full_sort_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_TEST_FAIL_STEP")) fail_at_step_ = atoi(e);
@@ -1671,6 +1672,10 @@ private:
         v_z_.ensure(Bz * 1024 * T * 4);
         v_s0_.ensure(Bz * 512 * T * 4);
         for (auto* b : {&v_B_, &v_D_, &v_E_}) b->ensure(Bz * 8192 * T * 4);
+        if (!v_zero_.p) {
+            v_zero_.ensure(256);
+            HIP_CHECK(hipMemsetAsync(v_zero_.p, 0, 256, st_voc_));
+        }
         if (xt_f16_) {   // the residual stream as activated halves (stage input, running value)
             v_Ah_.ensure(Bz * 8192 * T * 2);
             v_Ch_.ensure(Bz * 8192 * T * 2);
@@ -1717,7 +1722,7 @@ private:
                     const float* r = xt_f16_ ? reinterpret_cast<const float*>(c == 0 ? Ah : Ch) : (c == 0 ? A : Cb);
                     ConvArgs b1{};
                     b1.base_len = d_len; b1.B = B;
-                    b1.x = r; b1.x_f16 = xt_f16_ ? 1 : 0;
+                    b1.x = r; b1.x_f16 = xt_f16_ ? 1 : 0; b1.zeros = conv_dma_ ? v_zero_.p : nullptr;
                     b1.wp = v_c1_[i][j][c].wp; b1.wp16 = v_c1_[i][j][c].wp16; b1.bias = v_c1_[i][j][c].bias; b1.out = Bb;
                     b1.len_mul = mul_out; b1.Cin = C; b1.Mtot = C; b1.Cout = C;
                     b1.x_stride = Lout; b1.o_stride = Lout; b1.x_bstride = (long)C * Lout; b1.o_bstride = (long)C * Lout;
@@ -1900,6 +1905,7 @@ private:
     int rb_next_ = 0;
     bool sampler_full_sort_ = false;    // AUR_SAMPLER_FULL_SORT=1: disable the sampler's top-k fast path (A/B)
     bool pipeline_ = true;              // AUR_DECODE_PIPELINE=0: wait for every read-back before launching the next step
+    bool conv_dma_ = true;              // ResBlock convs of the fp16 vocoder on the LDS-DMA staged kernel
     bool xt_f16_ = false;               // set in the constructor: fp16 vocoder => fp16 c1 -> c2 intermediate (AUR_XT_F16=0 disables)
     std::vector<int> last_active_;      // live slots whose row indices are resident in the decode chain's index buffers
     hipStream_t st2_ = nullptr;
@@ -1909,7 +1915,7 @@ private:
     // vocoder
     ConvLayer v_pre_, v_ups_[4], v_c1_[4][3][3], v_c2_[4][3][3];
     const float* v_post_ = nullptr;
-    DevBuf v_meta_, v_z_, v_s0_, v_A_, v_B_, v_C_, v_D_, v_E_, v_Ch_, v_Ah_, tmp_lat_, tmp_wav_;
+    DevBuf v_meta_, v_z_, v_s0_, v_A_, v_B_, v_C_, v_D_, v_E_, v_Ch_, v_Ah_, v_zero_, tmp_lat_, tmp_wav_;
     std::vector<ConvEvent> conv_events_;
     std::vector<ConvEvent> gemm_events_;
     size_t n_gemm_events_ = 0;

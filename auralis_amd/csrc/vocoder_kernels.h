@@ -52,6 +52,9 @@ struct ConvArgs {
     int res_f16;
     float res_unact;
     int mrf_f16;
+    // >= 16 zero bytes (16-byte aligned).  With x_f16 it selects the LDS-DMA staged kernel, whose copies read this page for
+    // positions outside the utterance.
+    const void* zeros;
 };
 
 void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st);

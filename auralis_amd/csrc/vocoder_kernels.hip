@@ -614,6 +614,140 @@ __global__ __launch_bounds__(256, ((PF && !XH) || WIDE) ? 2 : 3) void conv1d_mfm
     conv_epilogue<WM, WN, MT, NTW>(a, acc, b, mtile, q0, wv, l31, hi, len_in, n_q);
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA staged variant for the fp16 interleaved inputs (every ResBlock conv of the fp16 vocoder).  Same tiling, fragments
+// and epilogue as conv1d_mfma_f16_kernel<.., XH = true, ..>; what changes is how a 16-channel chunk gets into LDS:
+//   * `global_load_lds_dwordx4`: each wave instruction copies 64 x 16 B straight from global memory to 1 KiB of LDS (no staging
+//     registers, no ds_write pass -- `ds_write_b128` costs 13 cycles per wave instruction against 4 for the matching read);
+//   * NBUF chunk buffers: the copies of chunk c + NBUF - 1 are in flight while the MFMAs of chunk c run, one barrier per chunk
+//     (the register-staged kernel runs load -> barrier -> LDS write -> barrier -> MFMA per chunk, and tools/conv_diag shows
+//     the three phases adding up instead of overlapping);
+//   * a DMA lands lane-linear, so the LDS rows are unpadded 32-byte rows ([tap][channel] for the weights, [position] for the
+//     input window) and the two 16-byte halves of row i are swapped when bit 3 of i is set -- on the SOURCE address of the copy
+//     and on the fragment read -- which keeps `ds_read_b128` conflict-free (rows 8 apart share banks; each b128 lane group
+//     holds rows 8 or 24 apart);
+//   * positions outside the utterance read a.zeros (a 16-byte zero page) instead of being predicated.
+// Ordering (cdna_hip_programming.md, LDS-DMA): every wave waits for its own copies of chunk c with a counted vmcnt, then the
+// workgroup barrier, then the fragment reads; the buffer of chunk c - 1 is refilled after that barrier, which every wave
+// reaches with its fragment reads retired (lgkmcnt(0)).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;   // M0 carries the LDS destination; hipcc owns M0, so save / restore it inside the statement
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int KS, int DIL, int MT, int NBUF>
+__global__ __launch_bounds__(256, 2) void conv1d_dma_f16_kernel(ConvArgs a) {
+    constexpr int CK = 16;
+    constexpr int WM = MT / 32;
+    constexpr int WN = (MT == 64) ? 2 : 4;
+    constexpr int NTW = 32 * WN;
+    constexpr int NT = 4 * NTW;
+    constexpr int HALO = (KS - 1) * DIL;
+    constexpr int XROW = NT + HALO;
+    constexpr int WI = KS * MT * 2 / 64;                   // weight copies (1 KiB each) per chunk
+    constexpr int XI0 = (2 * XROW + 63) / 64;
+    constexpr int XI = XI0 + (4 - (WI + XI0) % 4) % 4;     // input-window copies, padded so that every wave issues IPW of them
+    constexpr int IPW = (WI + XI) / 4;
+    constexpr int BUF = (WI + XI) * 1024;
+    static_assert((KS * MT * 2) % 64 == 0 && IPW * (NBUF - 2) < 64, "DMA bookkeeping");
+    __shared__ __attribute__((aligned(1024))) char smem[NBUF * BUF];
+
+    const int b = blockIdx.z;
+    int mtile, ttile;
+    conv_tile_order(mtile, ttile);
+    const int q0 = ttile * NT;
+    const int len_in = a.base_len[b] * a.len_mul;
+    const int n_q = len_in;
+    if (q0 >= n_q) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const char* wsrc_tile = reinterpret_cast<const char*>(a.wp16) + (long)mtile * (a.Cin / CK) * (WI * 1024);
+    const _Float16* xhb = reinterpret_cast<const _Float16*>(a.x) + (long)b * a.x_bstride;
+    const unsigned sbase = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+    const int nch = a.Cin / CK;
+
+    auto issue = [&](int c) {   // the copies of chunk c into buffer c % NBUF; this wave's share: ii = wave, wave + 4, ..
+        const unsigned dst0 = sbase + (unsigned)(c % NBUF) * BUF;
+#pragma unroll
+        for (int k = 0; k < IPW; ++k) {
+            const int ii = wvs + 4 * k;
+            const bool is_w = ii < WI;   // wave-uniform; selects instead of branches keep the copy sequence straight-line
+            const int s = (is_w ? ii : ii - WI) * 64 + lane, row = s >> 1, h = (s & 1) ^ ((row >> 3) & 1);
+            const int t = q0 - a.padl + row;
+            const char* wsrc = wsrc_tile + (long)c * (WI * 1024) + (row * 2 + h) * 16;
+            const char* xsrc = reinterpret_cast<const char*>(xhb + ((long)c * a.x_stride + t) * 16 + 8 * h);
+            const char* src = is_w ? wsrc : (t >= 0 && t < len_in) ? xsrc : reinterpret_cast<const char*>(a.zeros);
+            glds16(src, __builtin_amdgcn_readfirstlane(dst0 + (unsigned)ii * 1024));
+        }
+    };
+
+#pragma unroll
+    for (int c = 0; c < NBUF - 1; ++c)
+        if (c < nch) issue(c);
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+        // this wave's copies of chunk c have landed once at most IPW * (chunks issued after c) of its copies are outstanding
+        const int after = min(NBUF - 2, nch - 1 - c);
+        if (NBUF >= 4 && after == 2) wait_vmcnt<2 * IPW>();
+        else if (NBUF >= 3 && after == 1) wait_vmcnt<IPW>();
+        else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (c + NBUF - 1 < nch) issue(c + NBUF - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const char* bufp = smem + (c % NBUF) * BUF;
+        const char* wb = bufp + l31 * 32 + 16 * (hi ^ ((l31 >> 3) & 1));
+        const char* xb = bufp + WI * 1024 + (wv * NTW) * 32;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            h16x8 av[WM], bv[WN];
+#pragma unroll
+            for (int m = 0; m < WM; ++m) av[m] = *reinterpret_cast<const h16x8*>(wb + (j * MT + m * 32) * 32);
+            const int i0 = l31 + j * DIL;
+            const char* xp = xb + i0 * 32 + 16 * (hi ^ ((i0 >> 3) & 1));
+#pragma unroll
+            for (int n = 0; n < WN; ++n) bv[n] = *reinterpret_cast<const h16x8*>(xp + n * 32 * 32);
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int n = 0; n < WN; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[m], bv[n], acc[m][n], 0, 0, 0);
+        }
+    }
+    // plain convs only (the polyphase transposed convs read fp32 and stay on the register-staged kernel)
+    if (a.mrf_mode == 0) conv_epilogue_plain<WM, WN, MT, NTW, 0>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
+    else if (a.mrf_mode == 1) conv_epilogue_plain<WM, WN, MT, NTW, 1>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
+    else if (a.mrf_mode == 2) conv_epilogue_plain<WM, WN, MT, NTW, 2>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
+    else conv_epilogue_plain<WM, WN, MT, NTW, 3>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
+}
+
+template <int KS, int DIL>
+static void launch_conv_dma(const ConvArgs& a, hipStream_t st) {
+    constexpr int NBUF = KS >= 11 ? 2 : 3;
+    AUR_REQUIRE(a.x_f16 && a.zeros && a.ups_s == 0 && a.Cin % 16 == 0 && a.Cout % 16 == 0 && a.wp16, "conv dma: fp16 interleaved input, zero page");
+    trace_launch("conv1d_dma_f16_kernel");
+    if (a.Mtot % 64 == 0) {
+        dim3 grid((a.max_len + 255) / 256, a.Mtot / 64, a.B);
+        hipLaunchKernelGGL((conv1d_dma_f16_kernel<KS, DIL, 64, NBUF>), grid, dim3(256), 0, st, a);
+    } else {
+        AUR_REQUIRE(a.Mtot % 32 == 0, "conv dma: Mtot % 32");
+        dim3 grid((a.max_len + 511) / 512, a.Mtot / 32, a.B);
+        hipLaunchKernelGGL((conv1d_dma_f16_kernel<KS, DIL, 32, NBUF>), grid, dim3(256), 0, st, a);
+    }
+}
+
 template <int KS, int DIL, bool XH, bool PF, bool WIDE>
 static void launch_conv_f16_pf(const ConvArgs& a, hipStream_t st) {
     AUR_REQUIRE(a.Cin % 16 == 0 && a.wp16, "conv f16: Cin % 16, packed fp16 weights");
@@ -649,7 +783,23 @@ static void launch_conv_f16_t(const ConvArgs& a, hipStream_t st) {
 }
 
 void launch_conv1d_f16(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
-    if (a.x_f16) {   // fp16 activated inputs: the second conv of every ResBlock pair, and the first conv of rounds 1 and 2
+    if (a.x_f16 && a.zeros) {   // fp16 interleaved inputs (every ResBlock conv): LDS-DMA staged, multi-buffered
+        switch (KS * 16 + DIL) {
+            case 3 * 16 + 1: launch_conv_dma<3, 1>(a, st); break;
+            case 3 * 16 + 3: launch_conv_dma<3, 3>(a, st); break;
+            case 3 * 16 + 5: launch_conv_dma<3, 5>(a, st); break;
+            case 7 * 16 + 1: launch_conv_dma<7, 1>(a, st); break;
+            case 7 * 16 + 3: launch_conv_dma<7, 3>(a, st); break;
+            case 7 * 16 + 5: launch_conv_dma<7, 5>(a, st); break;
+            case 11 * 16 + 1: launch_conv_dma<11, 1>(a, st); break;
+            case 11 * 16 + 3: launch_conv_dma<11, 3>(a, st); break;
+            case 11 * 16 + 5: launch_conv_dma<11, 5>(a, st); break;
+            default: throw InvalidArgument("launch_conv1d_f16: fp16 input only for k in {3,7,11}, dilation in {1,3,5}");
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    if (a.x_f16) {   // same inputs, register-staged (no zero page given: tools/conv_diag's reference point)
         switch (KS * 16 + DIL) {
             case 3 * 16 + 1: launch_conv_f16_t<3, 1, true>(a, st); break;
             case 3 * 16 + 3: launch_conv_f16_t<3, 3, true>(a, st); break;

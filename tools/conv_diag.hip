@@ -32,11 +32,21 @@ static float run(const ConvArgs& a, hipStream_t st) {
     return time_ms(st, 5, [&] { hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 64, true, false, false, DBG>), grid, dim3(256), 0, st, a); });
 }
 
+template <int KS, int DIL, int NBUF>
+static float run_dma(const ConvArgs& a, hipStream_t st) {
+    dim3 grid((a.max_len + 255) / 256, a.Mtot / 64, a.B);
+    return time_ms(st, 5, [&] { hipLaunchKernelGGL((conv1d_dma_f16_kernel<KS, DIL, 64, NBUF>), grid, dim3(256), 0, st, a); });
+}
+
 template <int KS, int DIL>
 static void sweep(const char* what, const ConvArgs& a, hipStream_t st) {
     printf("%s k=%2d d=%d :  full %.3f | no loads %.3f | no mfma %.3f | no epilogue %.3f | no loads+mfma %.3f | no mfma+epilogue (staging only) %.3f | "
            "barriers + LDS writes only %.3f  ms\n", what, KS, DIL, run<KS, DIL, 0>(a, st), run<KS, DIL, 1>(a, st), run<KS, DIL, 4>(a, st),
            run<KS, DIL, 8>(a, st), run<KS, DIL, 5>(a, st), run<KS, DIL, 12>(a, st), run<KS, DIL, 13>(a, st));
+    printf("%s k=%2d d=%d :  LDS-DMA staged, 2 buffers %.3f", what, KS, DIL, run_dma<KS, DIL, 2>(a, st));
+    if constexpr (KS < 11) printf(" | 3 buffers %.3f", run_dma<KS, DIL, 3>(a, st));
+    if constexpr (KS < 7) printf(" | 4 buffers %.3f", run_dma<KS, DIL, 4>(a, st));
+    printf("  ms\n");
     fflush(stdout);
 }
 
@@ -64,7 +74,11 @@ int main() {
     HIP_CHECK(hipMemset(wp16, 0x22, (size_t)C * C * 11 * 2));   // ~ 0.012
     std::vector<int> hl(B, L);
     HIP_CHECK(hipMemcpy(len, hl.data(), B * 4, hipMemcpyHostToDevice));
+    void* zeros;
+    HIP_CHECK(hipMalloc(&zeros, 256));
+    HIP_CHECK(hipMemset(zeros, 0, 256));
     ConvArgs a{};
+    a.zeros = zeros;
     a.x = reinterpret_cast<const float*>(xh); a.wp16 = wp16; a.bias = bias; a.base_len = len; a.len_mul = 1; a.Cin = C; a.Mtot = C; a.Cout = C;
     a.x_stride = L; a.o_stride = L; a.x_bstride = (long)C * L; a.o_bstride = (long)C * L; a.slope = 0.1f; a.max_len = L; a.B = B; a.x_f16 = 1;
     // residual conv, rounds 0 / 1: fp16 activated input, activated fp16 residual stream updated in place (6 B per element)
