@@ -174,11 +174,13 @@ def build_report(args, st, dims, world, samples, dt, audio_s):
             r["rocprof"] = {"avg_launch_us": us, "achieved": g2, "frac": g2 / HBM_PEAK_GBPS, "source": prof_path}
         return r
 
-    conv_kernel = "conv1d_mfma_f16_kernel" if args.vocoder == "fp16" else "conv1d_mfma_kernel"
+    # fp16 vocoder: the ResBlock convs with 64-channel output tiles run the LDS-DMA staged kernel, the rest the register-staged one
+    conv_kernel = "conv1d_dma_f16_kernel + conv1d_mfma_f16_kernel" if args.vocoder == "fp16" else "conv1d_mfma_kernel"
+    conv_re = r"conv1d_(dma|mfma)_f16_kernel<" if args.vocoder == "fp16" else r"conv1d_mfma_kernel<"
     # SURVEY 8(d) counts the vocoder's layer-granular activation traffic in fp32 (21 301 B per output sample); conv_bytes is the
     # same accounting in the dtype each tensor is really stored in
     roof_conv = roof(f"{conv_kernel} (HiFi-GAN convs, all instantiations)", st["conv_ms"], st["conv_launches"], st["conv_bytes"],
-                     st["conv_flops"], FP32_MFMA_PEAK_TFLOPS if args.vocoder == "fp32" else BF16_MFMA_PEAK_TFLOPS, conv_kernel, None,
+                     st["conv_flops"], FP32_MFMA_PEAK_TFLOPS if args.vocoder == "fp32" else BF16_MFMA_PEAK_TFLOPS, conv_re, None,
                      "bytes counted as stored")
     conv_pmc = tj.get("r03_conv", {}).get(f"conv_{args.vocoder}")
     if conv_pmc:   # PMC passes of the CURRENT layouts (profiles/hbm_traffic.json["r03_conv"]); absent = not measured this round
@@ -202,6 +204,8 @@ def build_report(args, st, dims, world, samples, dt, audio_s):
                                  "mfma": {"achieved": tf, "frac": tf / pk}, "binding_roof": "hbm" if t_h >= t_m else "mfma",
                                  "frac_of_binding_floor": max(t_h, t_m) / (ms * 1e-3)})
     roof_conv["by_class"] = conv_classes
+    if conv_classes:   # the whole vocoder against the roof that binds each class: sum of the class floors / measured time
+        roof_conv["frac_of_binding_floors"] = sum(c["frac_of_binding_floor"] * c["ms"] for c in conv_classes) / sum(c["ms"] for c in conv_classes)
     roof_attn = roof("paged_attention_kernel (decode: one query row per sequence against its paged K/V)",
                      st["attn_ms"], st["attn_launches"], st["attn_bytes"], 0.0, 1.0, r"paged_attention_kernel<", "attention",
                      "algorithmic bytes = K and V rows of every live sequence's context (8 KiB per token per layer) + q + out")

@@ -1,18 +1,17 @@
 """Fold the rocprofv3 PMC passes of the default bench command into profiles/hbm_traffic.json["r03_decode"] / ["r03_conv"].
 
   PMC_PASSES='fetch write' PMC_KERNELS='paged_attention_kernel|gemm_rows_kernel' PMC_BENCH_ARGS='--tokens 40' tools/pmc.sh r03dec
-  PMC_PASSES='fetch write' PMC_KERNELS='conv1d_mfma' tools/pmc.sh r03conv
+  PMC_PASSES='fetch write' PMC_KERNELS='conv1d_' tools/pmc.sh r03conv
   python tools/pmc_r03_summary.py gpurun_out/pmc_r03dec 40 gpurun_out/pmc_r03conv
 
 Units and corrections (MI355X_MICROARCH.md §HBM): Counter_Value is KiB per dispatch; FETCH_SIZE reports 1/2 of the bytes of a
 wide coalesced streaming read (16 B per lane), other access widths are uncalibrated, WRITE_SIZE is taken as reported.
 * decode kernels: every load is a 16-B-per-lane float4 stream -> fetch = 2 x raw.
-* conv kernels: three access mixes, each calibrated on the stage-4 (32-channel, one co-tile) launch of its class whose compulsory
-  traffic is known exactly (64 utterances x 32 channels x 312 064 samples: fp32 tensor 2.556 GB, fp16 tensor 1.278 GB):
-    class A  first convs of ResBlock rounds 1, 2 (<k, d > 1, .., XH = true>): read one fp16 tensor with 16-B loads
-    class B  second convs (<k, 1, .., XH = true>): fp16 tensor with 16-B loads + fp32 residual with 4-B loads
-    class C  fp32-input convs (XH = false: conv_pre, transposed convs, first conv of round 0): 4-B loads
-  every launch's FETCH_SIZE is divided by its class factor (raw / known of the calibration launch)."""
+* conv kernels: two input families, each calibrated on launches whose compulsory read traffic is known exactly
+    fp16 interleaved inputs (ResBlock convs: 16-B loads or LDS-DMA copies + 8-B residual loads): the 18 launches of the 32-channel
+      stage, one co-tile each, 29 fp16 tensors of 64 x 32 x 312 064 halves
+    fp32 inputs (conv_pre, the four polyphase transposed convs: 4-B loads): the transposed convs' input tensors
+  every launch's FETCH_SIZE is divided by its family's factor (raw / known)."""
 import collections
 import csv
 import json
@@ -71,50 +70,43 @@ def conv_summary(d):
     f = load(os.path.join(d, "fetch", "pmc_counter_collection.csv"), "FETCH_SIZE")
     w = load(os.path.join(d, "write", "pmc_counter_collection.csv"), "WRITE_SIZE")
 
-    def cls(name):
+    def family(name):   # "h": fp16 interleaved inputs (16-B loads / LDS-DMA copies, 8-B residual loads); "f": fp32 inputs (4-B loads)
+        if name.startswith("conv1d_dma_f16_kernel<"):
+            return "h"
         m = re.search(r"conv1d_mfma_f16_kernel<(\d+), (\d+), (\d+), (true|false)", name)
-        if not m:
-            return None
-        xh, dil = m.group(4) == "true", int(m.group(2))
-        return "A" if (xh and dil > 1) else ("B" if xh else "C")
-    t32 = 64 * 32 * 312064 * 4.0
-    known = {"A": ("conv1d_mfma_f16_kernel<3, 3, 32, true", t32 / 2), "B": ("conv1d_mfma_f16_kernel<3, 1, 32, true", t32 / 2 + t32),
-             "C": ("conv1d_mfma_f16_kernel<3, 1, 32, false", t32)}
-    factor, cal = {}, {}
-    for c, (prefix, kb) in known.items():
-        ks = [k for k in f if k.startswith(prefix)]
-        if not ks:
-            continue
-        v = f[ks[0]]
-        # class B's calibration kernel runs 9 times per batch, 3 of them with the MRF accumulator in the epilogue: take the
-        # smallest launches (plain residual) for the known-traffic comparison
-        raw = sorted(v)[: max(1, len(v) // 3)] if c == "B" else v
-        raw_mean = sum(raw) / len(raw)
-        factor[c] = raw_mean / kb
-        cal[c] = {"kernel": ks[0], "known_read_bytes": kb, "fetch_raw_mean": raw_mean, "fetch_raw_over_known": factor[c]}
+        return None if not m else ("h" if m.group(4) == "true" else "f")
+    half = 64 * 32 * 312064 * 2.0   # one fp16 tensor of the 32-channel stage, 64 utterances at full length: 1.278 GB
+    # known compulsory reads (one co-tile per launch, so nothing is read twice):
+    #  h: the 18 ResBlock launches of the 32-channel stage: 9 first convs read the stream (1 tensor), 9 residual convs read the
+    #     c1 -> c2 intermediate and the stream (2), the MRF convs of ResBlocks 1 and 2 also the running sum (1 each) = 29 tensors
+    #  f: the four transposed convs read their fp32 input once per 64-row co-tile group; compulsory = the input tensors
+    known_h = 29 * half
+    known_f = 64 * 4.0 * (512 * 1219 + 256 * 9752 + 128 * 78016 + 64 * 156032)
+    raw_h = sum(sum(v) for k, v in f.items() if re.match(r"conv1d_mfma_f16_kernel<\d+, \d+, 32, true", k))
+    raw_f = sum(sum(v) for k, v in f.items() if re.match(r"conv1d_mfma_f16_kernel<2, 1, \d+, false", k))
+    factor = {"h": raw_h / known_h if raw_h else 0.5, "f": raw_f / known_f if raw_f else 0.5}
+    cal = {"fp16_inputs": {"launches": "conv1d_mfma_f16_kernel<*, *, 32, true> (the 32-channel stage)", "known_read_bytes": known_h,
+                           "fetch_raw": raw_h, "fetch_raw_over_known": factor["h"]},
+           "fp32_inputs": {"launches": "conv1d_mfma_f16_kernel<2, 1, *, false> (the four transposed convs)", "known_read_bytes": known_f,
+                           "fetch_raw": raw_f, "fetch_raw_over_known": factor["f"]}}
     n = tot_f = tot_w = 0.0
-    by_class = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    by_kernel = {}
     for k, v in f.items():
-        c = cls(k)
+        c = family(k)
         if c is None:
             continue
-        corr = factor.get(c, 0.5)
-        fb = sum(v) / corr
+        fb = sum(v) / factor[c]
         wb = sum(w.get(k, []))
         n += len(v)
         tot_f += fb
         tot_w += wb
-        by_class[c][0] += len(v)
-        by_class[c][1] += fb
-        by_class[c][2] += wb
-    return {"command": "PMC_PASSES='fetch write' PMC_KERNELS='conv1d_mfma' tools/pmc.sh r03conv; python tools/pmc_r03_summary.py ...",
+        by_kernel[k] = {"launches": len(v), "fetch_bytes_per_launch": fb / len(v), "write_bytes_per_launch": wb / len(v)}
+    return {"command": "PMC_PASSES='fetch write' PMC_KERNELS='conv1d_' tools/pmc.sh r03conv; python tools/pmc_r03_summary.py ...",
             "conv_fp16": {"launches": int(n), "fetch_bytes_per_launch": tot_f / max(1, n), "write_bytes_per_launch": tot_w / max(1, n),
                           "bytes_per_launch": (tot_f + tot_w) / max(1, n)},
-            "calibration": cal,
-            "by_class": {c: {"launches": v[0], "fetch_bytes_per_launch": v[1] / max(1, v[0]), "write_bytes_per_launch": v[2] / max(1, v[0])}
-                         for c, v in by_class.items()},
-            "note": "FETCH_SIZE divided by the class factor measured on a launch of known compulsory traffic (module docstring); "
-                    "WRITE_SIZE as reported (exact for 4-B/lane fp32 stores, over-counts 2-B/lane fp16 stores by ~1.19x in round 1)"}
+            "calibration": cal, "by_kernel": by_kernel,
+            "note": "FETCH_SIZE divided by the factor measured on launches of known compulsory traffic, per input family (module "
+                    "docstring); WRITE_SIZE as reported"}
 
 
 def main():
