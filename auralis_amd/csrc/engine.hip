@@ -798,7 +798,7 @@ public:
     }
 
     // ------------------------------------------------------------------ debug entry points
-    // prefill-regime GEMM (gemm_tile_kernel) on host data: out = X @ W
+    // prefill-regime GEMM (gemm_tile_kernel / gemm_tile_split_kernel, the arithmetic the engine was configured with) on host data: out = X @ W
     void dbg_gemm(const float* X, const float* Wm, float* out, int M, int N, int K) {
         use();
         DevBuf dx, dw, dp;
@@ -807,7 +807,7 @@ public:
         dp.ensure((size_t)M * N * 4);
         HIP_CHECK(hipMemcpy(dx.p, X, (size_t)M * K * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(dw.p, Wm, (size_t)K * N * 4, hipMemcpyHostToDevice));
-        launch_gemm_tile(dx.as<float>(), K, dw.as<float>(), dp.as<float>(), M, N, K, st_);
+        launch_gemm_tile(dx.as<float>(), K, dw.as<float>(), dp.as<float>(), M, N, K, st_, nullptr, gemm_prec_);
         HIP_CHECK(hipStreamSynchronize(st_));
         HIP_CHECK(hipMemcpy(out, dp.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     }
@@ -1239,14 +1239,14 @@ private:
         for (int l = 0; l < cfg_.n_layer; ++l) {
             const LayerW& L = layers_[l];
             void* kvl = kv_layer(l);
-            launch_gemm_tile(xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, w.st);
+            launch_gemm_tile(xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, w.st, nullptr, gemm_prec_);
             launch_qkv_epilogue(P, 1, L.bqkv, w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, w.st, kv_half_);
             launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, 0, kv_half_);
-            launch_gemm_tile(w.att.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, w.st);
+            launch_gemm_tile(w.att.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, w.st, nullptr, gemm_prec_);
             launch_rows_ln(P, 1, L.bproj, h, L.ln2w, L.ln2b, xn, M, 1e-5f, w.st);
             const GemmGelu ge{L.bfc, w.act.as<float>(), cfg_.gelu_erf ? 1 : 0};
-            launch_gemm_tile(xn, kHidden, L.wfc, P, M, 4 * kHidden, kHidden, w.st, &ge);
-            launch_gemm_tile(w.act.as<float>(), 4 * kHidden, L.wproj2, P, M, kHidden, 4 * kHidden, w.st);
+            launch_gemm_tile(xn, kHidden, L.wfc, P, M, 4 * kHidden, kHidden, w.st, &ge, gemm_prec_);
+            launch_gemm_tile(w.act.as<float>(), 4 * kHidden, L.wproj2, P, M, kHidden, 4 * kHidden, w.st, nullptr, gemm_prec_);
             const bool last = (l + 1 == cfg_.n_layer);
             launch_rows_ln(P, 1, L.bproj2, h, last ? lnfw_ : layers_[l + 1].ln1w, last ? lnfb_ : layers_[l + 1].ln1b,
                            xn, M, 1e-5f, w.st);
@@ -1290,7 +1290,7 @@ private:
     void sample_kernels(RowWs& w, int Ms, bool has_next_kvpos) {
         launch_final_norm(w.xn.as<float>(), w.i_sample_row.as<int>(), w.i_sample_slot.as<int>(), fnw_, fnb_, w.ybuf.as<float>(),
                           latents_.as<float>(), (long)kMaxLatRows * kHidden, slot_ngen_.as<int>(), kMaxLatRows, Ms, 1e-5f, w.st);
-        launch_gemm_tile(w.ybuf.as<float>(), kHidden, headT_, w.P2.as<float>(), Ms, kHeadPad, kHidden, w.st);
+        launch_gemm_tile(w.ybuf.as<float>(), kHidden, headT_, w.P2.as<float>(), Ms, kHeadPad, kHidden, w.st, nullptr, gemm_prec_);
         SamplerArgs a = sampler_args(w, w.P2.as<float>(), 1, Ms, kHeadPad, headb_, has_next_kvpos ? w.i_next_kvpos.as<int>() : nullptr);
         launch_sampler(a, w.st);
     }

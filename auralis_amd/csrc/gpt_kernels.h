@@ -94,8 +94,10 @@ void launch_final_rows(const float* h, int mtt, const int* sample_slot, const fl
 // double-buffered LDS stage, exact-f32 v_mfma_f32_32x32x2_f32 (each wave a 64 x 64 sub-tile); W in the file's [K][N] layout.
 // Every output element sums k in ascending order whatever M is, so prefill results do not depend on what else was admitted
 // in the same step (all prefill-type calls use this kernel, small M included).  N % 64 == 0, K % 16 == 0.
+// prec = 1: the decode GEMMs' three-way bf16 split arithmetic (gemm_tile_split_kernel, v_mfma_f32_32x32x16_bf16, the operands
+// split on their way into LDS) — same tiles, same k order per output element; prec = 0: exact-f32 MFMA.
 void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, int N, int K, hipStream_t st,
-                      const GemmGelu* gelu = nullptr);
+                      const GemmGelu* gelu = nullptr, int prec = 0);
 
 // h[m] += sum_s P[s][m] + bias (if S > 0); out[m] = LayerNorm(h[m]; gamma, beta, eps).  Rows of 1024.
 void launch_rows_ln(const float* P, int S, const float* bias, float* h, const float* gamma, const float* beta,

@@ -145,23 +145,173 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const float* __restri
         }
 }
 
+// The same GEMM in the decode GEMMs' split arithmetic (gemm_rows_kernel, PREC = 1): every fp32 operand is h + m + l exactly
+// (three bf16), a product keeps the six terms down to 2^-24 of it, on v_mfma_f32_32x32x16_bf16 with an accumulator for the h*h
+// term and one for the cross terms — 6 MFMAs of 32 cycles per 32 x 32 x 16 block against 8 x 64 for v_mfma_f32_32x32x2_f32.
+// The operands are split once per tile, on the way into LDS: both tiles are staged k-contiguous ([row][16 k] bf16 rows, 48-B
+// pitch: conflict-free ds_read_b128 fragments), the activations from float4 loads along k, the weights ([K][N] in memory) from
+// four coalesced dword loads k .. k+3 of one column.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split3_bf16x4(const f32x4& x, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 hh = (__bf16)x[i];
+        const float r = x[i] - (float)hh;
+        const __bf16 mm = (__bf16)r;
+        h[i] = hh;
+        m[i] = mm;
+        l[i] = (__bf16)(r - (float)mm);
+    }
+}
+
+template <int BM, int BN, bool GELU>
+__global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W,
+                                                                 float* __restrict__ P, int M, int N, int K, GemmGelu ep) {
+    static_assert((BM == 128 || BM == 64) && (BN == 128 || BN == 64), "tile shapes");
+    constexpr int BK = 16, RS = 24;              // bf16 per LDS row: 16 k + 8 pad
+    constexpr int MI = BM / 64, NI = BN / 64;    // 32 x 32 MFMA tiles per wave (waves form a 2 x 2 grid over the tile)
+    constexpr int LA = BM / 64;                  // float4 loads (4 k of one row) per thread and K step
+    constexpr int LB = BN / 64;                  // k-quads of one column per thread and K step (4 dword loads each)
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][3][BM * RS];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][3][BN * RS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5, wm = wv >> 1, wn = wv & 1;
+    const int n_nt = N / BN, n_mt = (M + BM - 1) / BM;
+    int ntile, mtile;
+    {   // XCD-aware order, as gemm_tile_kernel
+        const int L = blockIdx.x;
+        if ((n_nt & 7) == 0) {
+            const int xcd = L & 7, slot = L >> 3;
+            mtile = slot % n_mt;
+            ntile = (slot / n_mt) * 8 + xcd;
+        } else {
+            mtile = L % n_mt;
+            ntile = L / n_mt;
+        }
+    }
+    const int m0 = mtile * BM, n0 = ntile * BN;
+    const int a_row = tid >> 2, a_kq = tid & 3;          // A: rows a_row (+64), k-quad a_kq
+    const int b_n = tid % BN, b_kq = tid / BN;           // B: column b_n, k-quads b_kq (+ 256 / BN)
+    const float* ap[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int r = m0 + a_row + 64 * i;
+        ap[i] = X + (long)(r < M ? r : M - 1) * ldx + 4 * a_kq;   // rows >= M alias the last row: never stored
+    }
+    const float* bp = W + n0 + b_n;
+    // Two register sets: the global loads of step s + 2 are issued before the MFMAs of step s and parked until step s + 1 has
+    // been computed -- two steps of cover for the operand latency (the activation panel streams from HBM / Infinity Cache and a
+    // step's 24 MFMAs last only ~0.3 us; with one step of cover the kernel ran at a quarter of the matrix pipe).
+    f32x4 ga[2][LA], gb[2][LB];
+    auto g_load = [&](f32x4 (&a4)[LA], f32x4 (&b4)[LB], int k0) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) a4[i] = *reinterpret_cast<const f32x4*>(ap[i] + k0);
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b4[i][c] = bp[(long)(k0 + 4 * (b_kq + (256 / BN) * i) + c) * N];
+    };
+    auto s_store = [&](const f32x4 (&a4)[LA], const f32x4 (&b4)[LB], int buf) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            bf16x4 h, m, l;
+            split3_bf16x4(a4[i], h, m, l);
+            const int o = (a_row + 64 * i) * RS + 4 * a_kq;
+            *reinterpret_cast<bf16x4*>(&As[buf][0][o]) = h;
+            *reinterpret_cast<bf16x4*>(&As[buf][1][o]) = m;
+            *reinterpret_cast<bf16x4*>(&As[buf][2][o]) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            bf16x4 h, m, l;
+            split3_bf16x4(b4[i], h, m, l);
+            const int o = b_n * RS + 4 * (b_kq + (256 / BN) * i);
+            *reinterpret_cast<bf16x4*>(&Bs[buf][0][o]) = h;
+            *reinterpret_cast<bf16x4*>(&Bs[buf][1][o]) = m;
+            *reinterpret_cast<bf16x4*>(&Bs[buf][2][o]) = l;
+        }
+    };
+    f32x16 acc[MI][NI], lo[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = lo[mi][ni][r] = 0.f;
+    const int n_steps = K / BK;
+    g_load(ga[0], gb[0], 0);
+    if (n_steps > 1) g_load(ga[1], gb[1], BK);
+    s_store(ga[0], gb[0], 0);
+    __syncthreads();
+    const int ao = (wm * (BM / 2) + l31) * RS + 8 * hi, bo = (wn * (BN / 2) + l31) * RS + 8 * hi;
+    // step st: LDS buffer st & 1 holds it, register set (st + 1) & 1 holds step st + 1, set st & 1 is free for step st + 2
+    auto step = [&](auto PAR, int st) {
+        constexpr int par = decltype(PAR)::value;
+        if (st + 2 < n_steps) g_load(ga[par], gb[par], (st + 2) * BK);
+        __builtin_amdgcn_sched_barrier(0);   // those loads are in flight before this step's MFMAs
+        bf16x8 a[3][MI], b[3][NI];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a[p][mi] = *reinterpret_cast<const bf16x8*>(&As[par][p][ao + 32 * mi * RS]);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b[p][ni] = *reinterpret_cast<const bf16x8*>(&Bs[par][p][bo + 32 * ni * RS]);
+        }
+        // term order per accumulator as in gemm_rows_kernel (l*h.. first, h*h into its own accumulator); the tiles are the
+        // inner loop so that back-to-back MFMAs never share an accumulator
+#define AUR_TERM(DST, PA, PB)                                                                                           \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                  \
+        DST[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][mi], b[PB][ni], DST[mi][ni], 0, 0, 0);
+        AUR_TERM(lo, 0, 2) AUR_TERM(lo, 2, 0) AUR_TERM(lo, 1, 1) AUR_TERM(lo, 0, 1) AUR_TERM(lo, 1, 0) AUR_TERM(acc, 0, 0)
+#undef AUR_TERM
+        if (st + 1 < n_steps) s_store(ga[par ^ 1], gb[par ^ 1], par ^ 1);
+        __syncthreads();
+    };
+    for (int st = 0; st < n_steps; st += 2) {
+        step(std::integral_constant<int, 0>{}, st);
+        if (st + 1 < n_steps) step(std::integral_constant<int, 1>{}, st + 1);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = n0 + wn * (BN / 2) + ni * 32 + l31;
+            float bv = 0.f;
+            if (GELU) bv = ep.bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float v = acc[mi][ni][r] + lo[mi][ni][r];
+                if (row < M) {
+                    if (GELU) ep.act[(long)row * N + col] = ep.erf ? gelu_erf(v + bv) : gelu_new(v + bv);
+                    else P[(long)row * N + col] = v;
+                }
+            }
+        }
+}
+
 void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, int N, int K, hipStream_t st,
-                      const GemmGelu* gelu) {
+                      const GemmGelu* gelu, int prec) {
     AUR_REQUIRE(N % 64 == 0 && K % 16 == 0 && ldx % 4 == 0 && M >= 1, "gemm_tile: shape");
     trace_launch("gemm_tile_kernel");
     const GemmGelu none{nullptr, nullptr, 0};
+    const GemmGelu& g = gelu ? *gelu : none;
     // N = 1024 GEMMs (attention and MLP projections): 128 x 128 tiles give 8 x ceil(M/128) workgroups — 288 for a 64-prompt
     // prefill, 1.1 per CU, half the chip idle in the second round — so they run on 64 x 64 tiles (1136 workgroups).  The k order
     // of every output element is the same for both shapes.
-    if (N <= 1024 || N % 128 != 0) {
-        const dim3 grid((unsigned)((N / 64) * ((M + 63) / 64)));
-        if (gelu) hipLaunchKernelGGL((gemm_tile_kernel<64, 64, true>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, K, *gelu);
-        else hipLaunchKernelGGL((gemm_tile_kernel<64, 64, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, K, none);
+    const bool small = N <= 1024 || N % 128 != 0;
+#define AUR_GT(KERN, BM_, BN_, GE) \
+    hipLaunchKernelGGL((KERN<BM_, BN_, GE>), dim3((unsigned)((N / BN_) * ((M + BM_ - 1) / BM_))), dim3(256), 0, st, X, ldx, W, P, M, N, K, g)
+    if (prec) {   // split arithmetic: the narrow GEMMs on 128 x 64 tiles once there are rows for them (12 instead of 6 MFMAs per staged step)
+        if (small && M <= 64) { if (gelu) AUR_GT(gemm_tile_split_kernel, 64, 64, true); else AUR_GT(gemm_tile_split_kernel, 64, 64, false); }
+        else if (small) { if (gelu) AUR_GT(gemm_tile_split_kernel, 128, 64, true); else AUR_GT(gemm_tile_split_kernel, 128, 64, false); }
+        else { if (gelu) AUR_GT(gemm_tile_split_kernel, 128, 128, true); else AUR_GT(gemm_tile_split_kernel, 128, 128, false); }
     } else {
-        const dim3 grid((unsigned)((N / 128) * ((M + 127) / 128)));
-        if (gelu) hipLaunchKernelGGL((gemm_tile_kernel<128, 128, true>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, K, *gelu);
-        else hipLaunchKernelGGL((gemm_tile_kernel<128, 128, false>), grid, dim3(256), 0, st, X, ldx, W, P, M, N, K, none);
+        if (small) { if (gelu) AUR_GT(gemm_tile_kernel, 64, 64, true); else AUR_GT(gemm_tile_kernel, 64, 64, false); }
+        else { if (gelu) AUR_GT(gemm_tile_kernel, 128, 128, true); else AUR_GT(gemm_tile_kernel, 128, 128, false); }
     }
+#undef AUR_GT
     HIP_CHECK(hipGetLastError());
 }
 
@@ -229,7 +379,6 @@ void launch_pack_wt16(const float* W, int ldw, float* Wt, int K, int N, hipStrea
 // terms are below 2^-25 of the product): 6 x 17 cycles per 16 x 16 x 32 block instead of 8 x 32 for v_mfma_f32_16x16x4_f32.
 // The two float4 a lane holds for K blocks (2p, 2p + 1) form its 8-element fragment; A and B use the same assignment, so the
 // packed layouts stay as they are.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split3_bf16(const f32x4& x0, const f32x4& x1, bf16x8& h, bf16x8& m, bf16x8& l) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {

@@ -30,6 +30,24 @@ def test_gemm_tile(eng, M, N, K):
     assert err < 2e-4 * max(1.0, np.abs(ref).max()), err
 
 
+def test_gemm_tile_split_arithmetic_matches_exact_f32(eng):
+    """Default engines run the prompt-row GEMMs in the three-way bf16 split arithmetic (gemm_tile_split_kernel); with
+    aur_config.gemm_f32_exact they run on exact-f32 MFMA.  Both against float64."""
+    e32, *_ = make_engine(1, max_seqs=8, gemm_f32_exact=True)
+    try:
+        g = torch.Generator().manual_seed(77)
+        for M, N, K in [(300, 3072, 1024), (200, 1024, 4096)]:
+            X = torch.randn(M, K, generator=g)
+            W = torch.randn(K, N, generator=g) * 0.05
+            ref = (X.double() @ W.double()).numpy()
+            a, b = eng.dbg_gemm(X.numpy(), W.numpy()), e32.dbg_gemm(X.numpy(), W.numpy())
+            ea, eb = np.abs(a - ref).max(), np.abs(b - ref).max()
+            print(f"M={M} N={N} K={K}: split max err {ea:.3e}, exact-f32 max err {eb:.3e}, max|ref| {np.abs(ref).max():.2f}")
+            assert ea < 4.0 * eb + 1e-6, (ea, eb)
+    finally:
+        e32.close()
+
+
 def test_gemm_tile_is_batch_invariant_bitwise(eng):
     """A prompt's rows must not depend on how many other rows were admitted in the same prefill step."""
     g = torch.Generator().manual_seed(9)
