@@ -1608,7 +1608,8 @@ private:
             ev->flops = 2.0 * a.Cin * KS * a.Mtot * tot_in;
             // bytes in the dtype each tensor is actually stored in (the c1 -> c2 intermediate may be fp16)
             const double mrf_b = a.mrf_f16 ? 2.0 : 4.0;
-            const double out_b = a.mrf_mode == 0 ? (a.out_act_f16 ? 2.0 : 4.0) : a.mrf_mode == 1 ? mrf_b : a.mrf_mode == 2 ? 2.0 * mrf_b : mrf_b + 4.0;
+            const double o_b = a.out_act_f16 ? 2.0 : 4.0;
+            const double out_b = a.mrf_mode == 0 ? o_b : a.mrf_mode == 1 ? mrf_b : a.mrf_mode == 2 ? 2.0 * mrf_b : mrf_b + o_b;
             ev->bytes = (a.x_f16 ? 2.0 : 4.0) * a.Cin * tot_in + a.Cout * tot_out * (out_b + (a.res ? (a.res_f16 ? 2.0 : 4.0) : 0.0));
             HIP_CHECK(hipEventRecord(ev->a, st_voc_));
         }
@@ -1693,6 +1694,9 @@ private:
         a.out = v_s0_.as<float>(); a.len_mul = 1; a.Cin = 1024; a.Mtot = 512; a.Cout = 512;
         a.x_stride = (long)T; a.o_stride = (long)T; a.x_bstride = (long)(1024 * T); a.o_bstride = (long)(512 * T);
         a.padl = 3; a.slope = 1.0f; a.ups_s = 0; a.ups_p = 0; a.mrf_mode = 0; a.max_len = maxT;
+        // fp16 vocoder: every stage input (conv_pre's output, the MRF means) is stored the way its consumer stages it,
+        // fp16(lrelu(x, 0.1)) interleaved -- 0.01 for the last one, which feeds conv_post
+        if (xt_f16_) { a.out_act_f16 = 1; a.out_slope = 0.1f; }
         conv(a, 7, 1, totT, totT);
         const int rates[4] = {8, 8, 2, 2}, kern[4] = {16, 16, 4, 4}, chans[4] = {256, 128, 64, 32};
         const int rk[3] = {3, 7, 11}, rd[3] = {1, 3, 5};
@@ -1706,7 +1710,7 @@ private:
             // transposed conv as 2-tap polyphase conv over virtual channels co*s + r
             a = ConvArgs{};
             a.base_len = d_len; a.B = B; a.cond_row = d_cond; a.cond_stride = kCondStride;
-            a.x = in; a.wp = v_ups_[i].wp; a.wp16 = v_ups_[i].wp16; a.bias = v_ups_[i].bias; a.cond = condt + cond_off; a.out = A;
+            a.x = in; a.x_f16 = xt_f16_ ? 1 : 0; a.zeros = (xt_f16_ && conv_dma_) ? v_zero_.p : nullptr; a.wp = v_ups_[i].wp; a.wp16 = v_ups_[i].wp16; a.bias = v_ups_[i].bias; a.cond = condt + cond_off; a.out = A;
             a.len_mul = mul; a.Cin = Cin; a.Mtot = C * s; a.Cout = C;
             a.x_stride = Lin; a.x_bstride = (long)Cin * Lin; a.o_stride = Lout; a.o_bstride = (long)C * Lout;
             a.padl = 1; a.slope = 0.1f; a.ups_s = s; a.ups_p = (kern[i] - s) / 2; a.mrf_mode = 0; a.max_len = maxT * mul;
@@ -1741,12 +1745,13 @@ private:
                     } else {
                         b2.mrf = D; b2.out = E; b2.mrf_mode = (j == 0) ? 1 : (j == 1) ? 2 : 3;
                         b2.mrf_f16 = xt_f16_ ? 1 : 0;   // D: running sum of the three ResBlock outputs (halves in fp16 mode)
+                        if (xt_f16_ && j == 2) { b2.out_act_f16 = 1; b2.out_slope = (i == 3) ? 0.01f : 0.1f; }   // E: the next stage's input
                     }
                     conv(b2, rk[j], 1, totT * mul_out, totT * mul_out);
                 }
             in = E; Cin = C; mul = mul_out;
         }
-        launch_conv_post(E, v_post_, d_wav, d_len, 256, 32, (long)T * 256, (long)32 * T * 256, wav_bstride, 0.01f, B, maxT * 256, st_voc_);
+        launch_conv_post(E, v_post_, d_wav, d_len, 256, 32, (long)T * 256, (long)32 * T * 256, wav_bstride, 0.01f, B, maxT * 256, st_voc_, xt_f16_);
         HIP_CHECK(hipEventRecord(ev_vb_, st_voc_));
         voc_timed_ = true;
         stats_.vocoder_batches++;

@@ -48,7 +48,8 @@ struct ConvArgs {
     // invertible, so one 2-byte tensor serves both uses).  res and out may alias (each element is read and then written by the
     // same lane).  This is the precision of the reference's own GPU path, which runs the ResBlocks under fp16 autocast
     // (hifigan_decoder.py:242).  mrf_f16: the running MRF sum (mrf_mode 1 / 2 write it, 2 / 3 read it) is interleaved halves
-    // too; the stage output of mrf_mode 3 stays fp32.
+    // too.  With out_act_f16 the stage output of mrf_mode 3 is stored as fp16(lrelu(mean, out_slope)) as well (what the next
+    // stage's transposed conv, or conv_post, stages anyway), otherwise fp32.
     int res_f16;
     float res_unact;
     int mrf_f16;
@@ -68,7 +69,7 @@ void launch_interp2(const float* lat, long lat_bstride, const int* lat_row, cons
 // wav[b][t] = tanh(sum_{ci,j} w[ci][j] * lrelu(x[b][ci][t+j-3], slope))   (conv_post, no bias)
 void launch_conv_post(const float* x, const float* w, float* wav, const int* base_len, int len_mul, int Cin,
                       long x_stride, long x_bstride, long wav_bstride, float slope, int B, int max_len,
-                      hipStream_t st);
+                      hipStream_t st, bool x_f16_act = false);   // x_f16_act: x = fp16(lrelu(.)) already, interleaved halves
 
 // y[b][r] = bias[r] + sum_k W[r][k] * g[b][k]      (1x1 conditioning convs on the speaker embedding)
 void launch_gemv_rows(const float* W, const float* bias, const float* g, float* y, int R, int K, int B,

@@ -116,7 +116,11 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, f32x16 (&
                         *reinterpret_cast<h16x4v*>(hb + ((long)(c >> 4) * a.o_stride + q) * 16 + (c & 15)) = hv;
                     }
                 };
-                if (MODE == 0 && a.out_act_f16) {
+                if (MODE == 3) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) val[r] = (mv[r] + val[r]) / 3.0f;
+                }
+                if ((MODE == 0 || MODE == 3) && a.out_act_f16) {
                     store_h(a.out, a.out_slope);
                 } else if ((MODE == 1 || MODE == 2) && a.mrf_f16) {
                     store_h(a.mrf, 1.0f);
@@ -126,7 +130,7 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, f32x16 (&
                         const long off = base + (long)((r & 3) + 8 * (r >> 2)) * a.o_stride;
                         if (MODE == 0) a.out[off] = val[r];
                         else if (MODE == 1 || MODE == 2) a.mrf[off] = val[r];
-                        else a.out[off] = (mv[r] + val[r]) / 3.0f;
+                        else a.out[off] = val[r];
                     }
                 }
             }
@@ -660,7 +664,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_dma_f16_kernel(ConvArgs a) {
     conv_tile_order(mtile, ttile);
     const int q0 = ttile * NT;
     const int len_in = a.base_len[b] * a.len_mul;
-    const int n_q = len_in;
+    const int n_q = a.ups_s ? len_in + 1 : len_in;   // polyphase transposed conv: one more input position than output frames / s
     if (q0 >= n_q) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -726,8 +730,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_dma_f16_kernel(ConvArgs a) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[m], bv[n], acc[m][n], 0, 0, 0);
         }
     }
-    // plain convs only (the polyphase transposed convs read fp32 and stay on the register-staged kernel)
-    if (a.mrf_mode == 0) conv_epilogue_plain<WM, WN, MT, NTW, 0>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
+    if (a.ups_s) conv_epilogue_ups<WM, WN, MT, NTW>(a, acc, b, mtile, q0, wv, l31, hi, len_in, n_q);
+    else if (a.mrf_mode == 0) conv_epilogue_plain<WM, WN, MT, NTW, 0>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
     else if (a.mrf_mode == 1) conv_epilogue_plain<WM, WN, MT, NTW, 1>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
     else if (a.mrf_mode == 2) conv_epilogue_plain<WM, WN, MT, NTW, 2>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
     else conv_epilogue_plain<WM, WN, MT, NTW, 3>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
@@ -735,15 +739,17 @@ __global__ __launch_bounds__(256, 2) void conv1d_dma_f16_kernel(ConvArgs a) {
 
 template <int KS, int DIL>
 static void launch_conv_dma(const ConvArgs& a, hipStream_t st) {
-    constexpr int NBUF = KS >= 11 ? 2 : 3;
-    AUR_REQUIRE(a.x_f16 && a.zeros && a.ups_s == 0 && a.Cin % 16 == 0 && a.Cout % 16 == 0 && a.wp16, "conv dma: fp16 interleaved input, zero page");
+    constexpr int NBUF = KS >= 11 ? 2 : KS >= 3 ? 3 : 4;   // the fewer taps, the shorter a chunk's MFMA phase and the deeper the prefetch
+    AUR_REQUIRE(a.x_f16 && a.zeros && a.Cin % 16 == 0 && a.Cout % 16 == 0 && a.wp16, "conv dma: fp16 interleaved input, zero page");
+    AUR_REQUIRE(a.Cin / 16 >= NBUF - 1, "conv dma: fewer input-channel chunks than the prefetch depth");
     trace_launch("conv1d_dma_f16_kernel");
+    const int n_q = a.ups_s ? a.max_len + 1 : a.max_len;
     if (a.Mtot % 64 == 0) {
-        dim3 grid((a.max_len + 255) / 256, a.Mtot / 64, a.B);
+        dim3 grid((n_q + 255) / 256, a.Mtot / 64, a.B);
         hipLaunchKernelGGL((conv1d_dma_f16_kernel<KS, DIL, 64, NBUF>), grid, dim3(256), 0, st, a);
     } else {
         AUR_REQUIRE(a.Mtot % 32 == 0, "conv dma: Mtot % 32");
-        dim3 grid((a.max_len + 511) / 512, a.Mtot / 32, a.B);
+        dim3 grid((n_q + 511) / 512, a.Mtot / 32, a.B);
         hipLaunchKernelGGL((conv1d_dma_f16_kernel<KS, DIL, 32, NBUF>), grid, dim3(256), 0, st, a);
     }
 }
@@ -751,7 +757,7 @@ static void launch_conv_dma(const ConvArgs& a, hipStream_t st) {
 template <int KS, int DIL, bool XH, bool PF, bool WIDE>
 static void launch_conv_f16_pf(const ConvArgs& a, hipStream_t st) {
     AUR_REQUIRE(a.Cin % 16 == 0 && a.wp16, "conv f16: Cin % 16, packed fp16 weights");
-    AUR_REQUIRE(!a.out_act_f16 || a.mrf_mode == 0, "conv f16: fp16 output not next to an MRF accumulator");
+    AUR_REQUIRE(!a.out_act_f16 || a.mrf_mode == 0 || a.mrf_mode == 3, "conv f16: fp16 output for plain convs and the MRF mean");
     AUR_REQUIRE(!a.mrf_f16 || a.mrf_mode != 0, "conv f16: mrf_f16 without an MRF mode");
     AUR_REQUIRE((!a.x_f16 && !a.out_act_f16 && !a.res_f16 && !a.mrf_f16) || (a.Cin % 16 == 0 && a.Cout % 16 == 0), "conv f16: interleaved tensors need 16-channel chunks");
     AUR_REQUIRE(!a.res_f16 || (a.res && a.ups_s == 0), "conv f16: fp16 residual only on plain convs");
@@ -787,6 +793,7 @@ void launch_conv1d_f16(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
     // stage (2 chunks per tile, HBM-bound) measured faster register-staged (37.7 vs 40.4 ms per 3 batches)
     if (a.x_f16 && a.zeros && a.Mtot % 64 == 0) {
         switch (KS * 16 + DIL) {
+            case 2 * 16 + 1: launch_conv_dma<2, 1>(a, st); break;
             case 3 * 16 + 1: launch_conv_dma<3, 1>(a, st); break;
             case 3 * 16 + 3: launch_conv_dma<3, 3>(a, st); break;
             case 3 * 16 + 5: launch_conv_dma<3, 5>(a, st); break;
@@ -801,8 +808,9 @@ void launch_conv1d_f16(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
         HIP_CHECK(hipGetLastError());
         return;
     }
-    if (a.x_f16) {   // same inputs, register-staged (32-channel stage; no zero page given: tools/conv_diag's reference point)
+    if (a.x_f16) {   // same inputs, register-staged (32-channel stage, transposed convs; no zero page given: tools/conv_diag's reference point)
         switch (KS * 16 + DIL) {
+            case 2 * 16 + 1: launch_conv_f16_t<2, 1, true>(a, st); break;
             case 3 * 16 + 1: launch_conv_f16_t<3, 1, true>(a, st); break;
             case 3 * 16 + 3: launch_conv_f16_t<3, 3, true>(a, st); break;
             case 3 * 16 + 5: launch_conv_f16_t<3, 5, true>(a, st); break;
@@ -885,6 +893,8 @@ void launch_interp2(const float* lat, long lat_bstride, const int* lat_row, cons
 
 // ------------------------------------------------------------------------------------------------
 // conv_post (Cin -> 1, k7, no bias) + tanh.  Cin <= 32.  HBM-bound: reads Cin floats per sample.
+// XH: x is the fp16 vocoder's stage output, already activated, interleaved [C/16][t][16] halves (strides in elements).
+template <bool XH>
 __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         float* __restrict__ wav, const int* __restrict__ base_len,
                                                         int len_mul, int Cin, long x_stride, long x_bstride,
@@ -907,20 +917,35 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
     const bool okm = tm >= 0 && tm < len, okh = th >= 0 && th < len;
     for (int c0 = 0; c0 < Cin; c0 += CU) {
         float v[CU], h[CU];
+        if constexpr (XH) {   // the 16 channels of a position are 32 contiguous bytes
+            const _Float16* xh = reinterpret_cast<const _Float16*>(x) + (long)b * x_bstride + (long)(c0 >> 4) * x_stride * 16;
+            const h16x8 m0 = *reinterpret_cast<const h16x8*>(xh + (long)tmc * 16), m1 = *reinterpret_cast<const h16x8*>(xh + (long)tmc * 16 + 8);
+            h16x8 h0 = m0, h1 = m1;
+            if (tid < KS - 1) {
+                h0 = *reinterpret_cast<const h16x8*>(xh + (long)thc * 16);
+                h1 = *reinterpret_cast<const h16x8*>(xh + (long)thc * 16 + 8);
+            }
 #pragma unroll
-        for (int u = 0; u < CU; ++u) v[u] = xb[(long)min(c0 + u, Cin - 1) * x_stride + tmc];
-        if (tid < KS - 1) {
+            for (int u = 0; u < 8; ++u) {
+                v[u] = (float)m0[u]; v[u + 8] = (float)m1[u];
+                h[u] = (float)h0[u]; h[u + 8] = (float)h1[u];
+            }
+        } else {
 #pragma unroll
-            for (int u = 0; u < CU; ++u) h[u] = xb[(long)min(c0 + u, Cin - 1) * x_stride + thc];
+            for (int u = 0; u < CU; ++u) v[u] = xb[(long)min(c0 + u, Cin - 1) * x_stride + tmc];
+            if (tid < KS - 1) {
+#pragma unroll
+                for (int u = 0; u < CU; ++u) h[u] = xb[(long)min(c0 + u, Cin - 1) * x_stride + thc];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < CU; ++u)
-            if (c0 + u < Cin) xs[c0 + u][tid] = okm ? lrelu(v[u], slope) : 0.f;
+            if (c0 + u < Cin) xs[c0 + u][tid] = okm ? (XH ? v[u] : lrelu(v[u], slope)) : 0.f;
         if (tid < KS - 1) {
 #pragma unroll
             for (int u = 0; u < CU; ++u)
-                if (c0 + u < Cin) xs[c0 + u][NT + tid] = okh ? lrelu(h[u], slope) : 0.f;
+                if (c0 + u < Cin) xs[c0 + u][NT + tid] = okh ? (XH ? h[u] : lrelu(h[u], slope)) : 0.f;
         }
     }
     __syncthreads();
@@ -936,12 +961,16 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
 
 void launch_conv_post(const float* x, const float* w, float* wav, const int* base_len, int len_mul, int Cin,
                       long x_stride, long x_bstride, long wav_bstride, float slope, int B, int max_len,
-                      hipStream_t st) {
-    AUR_REQUIRE(Cin <= 32, "conv_post: Cin <= 32");
+                      hipStream_t st, bool x_f16_act) {
+    AUR_REQUIRE(Cin <= 32 && (!x_f16_act || Cin % 16 == 0), "conv_post: Cin <= 32 (whole 16-channel chunks for the fp16 form)");
     dim3 grid((max_len + 255) / 256, B);
     trace_launch("conv_post_kernel");
-    hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), 0, st, x, w, wav, base_len, len_mul, Cin, x_stride,
-                       x_bstride, wav_bstride, slope);
+    if (x_f16_act)
+        hipLaunchKernelGGL(conv_post_kernel<true>, grid, dim3(256), 0, st, x, w, wav, base_len, len_mul, Cin, x_stride,
+                           x_bstride, wav_bstride, slope);
+    else
+        hipLaunchKernelGGL(conv_post_kernel<false>, grid, dim3(256), 0, st, x, w, wav, base_len, len_mul, Cin, x_stride,
+                           x_bstride, wav_bstride, slope);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -84,7 +84,8 @@ def conv_summary(d):
     known_f = 64 * 4.0 * (512 * 1219 + 256 * 9752 + 128 * 78016 + 64 * 156032)
     raw_h = sum(sum(v) for k, v in f.items() if re.match(r"conv1d_mfma_f16_kernel<\d+, \d+, 32, true", k))
     raw_f = sum(sum(v) for k, v in f.items() if re.match(r"conv1d_mfma_f16_kernel<2, 1, \d+, false", k))
-    factor = {"h": raw_h / known_h if raw_h else 0.5, "f": raw_f / known_f if raw_f else 0.5}
+    # (since the stage inputs are halves too, only conv_pre reads fp32: no calibration launches, FETCH_SIZE taken as reported)
+    factor = {"h": raw_h / known_h if raw_h else 0.5, "f": raw_f / known_f if raw_f else 1.0}
     cal = {"fp16_inputs": {"launches": "conv1d_mfma_f16_kernel<*, *, 32, true> (the 32-channel stage)", "known_read_bytes": known_h,
                            "fetch_raw": raw_h, "fetch_raw_over_known": factor["h"]},
            "fp32_inputs": {"launches": "conv1d_mfma_f16_kernel<2, 1, *, false> (the four transposed convs)", "known_read_bytes": known_f,
