@@ -69,6 +69,25 @@ static void launch_variant(const GemmRowsArgs& a, const Shape& s, const Cfg& c, 
     else launch_variant_p<0>(a, s, c, st);
 }
 
+// Side-stream weight warmer (experiment): one wave per workgroup streams a slice of the next layer's weights
+// with 16-byte loads and drops them; the loads allocate in the Infinity Cache, so the next layer's GEMMs find their tiles there.
+__global__ __launch_bounds__(64) void warm_kernel(const float4* __restrict__ a, long na, const float4* __restrict__ b, long nb,
+                                                  const float4* __restrict__ c, long nc, const float4* __restrict__ d, long nd,
+                                                  float* sink) {
+    float acc = 0.f;
+    const long stride = (long)gridDim.x * 64, t0 = (long)blockIdx.x * 64 + threadIdx.x;
+    auto sweep = [&](const float4* p, long n) {
+        long i = t0;
+        for (; i + 3 * stride < n; i += 4 * stride) {
+            const float4 v0 = p[i], v1 = p[i + stride], v2 = p[i + 2 * stride], v3 = p[i + 3 * stride];
+            acc += v0.x + v1.y + v2.z + v3.w;
+        }
+        for (; i < n; i += stride) acc += p[i].x;
+    };
+    sweep(a, na); sweep(b, nb); sweep(c, nc); sweep(d, nd);
+    if (acc == 1.2345e30f) *sink = acc;
+}
+
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 64;
     const bool quick = argc > 2 && atoi(argv[2]) == 1;   // 1: chains only
@@ -234,8 +253,20 @@ int main(int argc, char** argv) {
         float* act = dalloc((size_t)256 * 4096, 0.5f, 22);
         float* att = dalloc((size_t)256 * 1024, 0.5f, 23);
         float* qb = dalloc((size_t)256 * 1024, 0.f, 24);
+        hipStream_t st2;
+        HIP_CHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+        std::vector<hipEvent_t> evl(n_layers);
+        for (auto& e : evl) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        int warm_wgs = 0;   // 0 = no warmer; otherwise workgroups (one wave each) of the warmer launched per layer on st2
         auto chain = [&](bool attn, int prec) {
             for (int l = 0; l < n_layers; ++l) {
+                if (warm_wgs && l + 1 < n_layers) {   // at the start of layer l: warm layer l + 1's weights on the side stream
+                    HIP_CHECK(hipEventRecord(evl[l], st));
+                    HIP_CHECK(hipStreamWaitEvent(st2, evl[l], 0));
+                    if (warm_wgs > 0) hipLaunchKernelGGL(warm_kernel, dim3(warm_wgs), dim3(64), 0, st2,
+                                       reinterpret_cast<const float4*>(wq[l + 1]), (long)3072 * 1024 / 4, reinterpret_cast<const float4*>(wp[l + 1]), (long)1024 * 1024 / 4,
+                                       reinterpret_cast<const float4*>(wf[l + 1]), (long)4096 * 1024 / 4, reinterpret_cast<const float4*>(w2[l + 1]), (long)4096 * 1024 / 4, qb);
+                }
                 float* kvl = kv + (size_t)l * kv_blocks * kKvBlockElems;
                 GemmRowsArgs a{};
                 a.M = M; a.prec = prec; a.eps = 1e-5f; a.X = hres; a.xmt = MTT; a.Wt = wq[l]; a.N = 3072; a.K = 1024; a.bias = bias; a.ln_c1 = gamma;
@@ -255,6 +286,14 @@ int main(int argc, char** argv) {
                 launch_gemm_rows(a, false, kEpiResidual, st);
             }
         };
+        for (int ww : {-1, 64, 256}) {   // -1: the event record / wait per layer alone   // the warmer experiment: split arithmetic, attention in the chain
+            warm_wgs = ww;
+            const float us = time_us(st, 20, [&] { chain(true, 1); });
+            HIP_CHECK(hipStreamSynchronize(st2));
+            printf("chain with a side-stream weight warmer (%d waves, one layer ahead): %.1f us per layer (%.3f ms per step)\n", ww, us / n_layers, us / 1000);
+            fflush(stdout);
+        }
+        warm_wgs = 0;
         for (int attn : {0, 1})
             for (int prec : {0, 1}) {
                 const float us = time_us(st, 20, [&] { chain(attn != 0, prec); });
