@@ -1241,7 +1241,7 @@ private:
             void* kvl = kv_layer(l);
             launch_gemm_tile(xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, w.st, nullptr, gemm_prec_);
             launch_qkv_epilogue(P, 1, L.bqkv, w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, w.st, kv_half_);
-            launch_paged_attention(w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, 0, kv_half_);
+            launch_prompt_attention(w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, kv_half_);
             launch_gemm_tile(w.att.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, w.st, nullptr, gemm_prec_);
             launch_rows_ln(P, 1, L.bproj, h, L.ln2w, L.ln2b, xn, M, 1e-5f, w.st);
             const GemmGelu ge{L.bfc, w.act.as<float>(), cfg_.gelu_erf ? 1 : 0};

@@ -912,6 +912,104 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
     }
 }
 
+// Prompt rows (prefill): one workgroup per (32 consecutive rows, head).  A row's 8 lanes span the 64-wide head (8 elements each)
+// and walk the row's whole context key by key -- no cross-group merge, no LDS; the rows of a wave step through the keys
+// together, so rows of one sequence (which is what 32 consecutive prompt rows are) ask for the same K/V addresses in the
+// same instruction and the context is fetched once per wave instead of once per row.  Per row the result depends on nothing
+// but the row (same key order whatever else is in the batch).
+template <bool KVH>
+__global__ __launch_bounds__(256) void prompt_attention_kernel(const float* __restrict__ qbuf, const void* __restrict__ kv_layer_v,
+                                                               const int* __restrict__ row_slot, const int* __restrict__ row_pos,
+                                                               const int* __restrict__ block_tables, int max_blocks,
+                                                               float* __restrict__ out, int M) {
+    constexpr int LPR = 8, EPL = kHeadDim / LPR;   // lanes per row, elements per lane
+    constexpr int UN = 4;                          // keys per loop iteration (their loads are issued together)
+    using KT = typename std::conditional<KVH, _Float16, float>::type;
+    using RawT = typename std::conditional<KVH, h16x8g, f32x4>::type;
+    constexpr int NR = KVH ? 1 : 2;                // raw loads per 8 elements
+    const int head = blockIdx.y;
+    const int r = blockIdx.x * 32 + (threadIdx.x >> 3), dl = threadIdx.x & 7;
+    const bool live = r < M;
+    const int m = live ? r : M - 1;
+    const int slot = row_slot[m];
+    const int n_keys = live ? row_pos[m] + 1 : 0;
+    const int* bt = block_tables + (long)slot * max_blocks;
+    const KT* kv_layer = reinterpret_cast<const KT*>(kv_layer_v);
+    float qv[EPL];
+    {
+        const float* qp = qbuf + (long)m * kHidden + head * kHeadDim + dl * EPL;
+#pragma unroll
+        for (int c4 = 0; c4 < EPL / 4; ++c4) {
+            const f32x4 q4 = *reinterpret_cast<const f32x4*>(qp + 4 * c4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qv[4 * c4 + c] = q4[c];
+        }
+    }
+    float mi = -INFINITY, li = 0.f, o[EPL];
+#pragma unroll
+    for (int c = 0; c < EPL; ++c) o[c] = 0.f;
+    // the wave iterates to the longest context among its rows; a row's own keys beyond n_keys are masked (clamped addresses)
+    int n_max = n_keys;
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) n_max = max(n_max, __shfl_xor(n_max, sh, 64));
+    for (int t0 = 0; t0 < n_max; t0 += UN) {
+        RawT kraw[UN][NR], vraw[UN][NR];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int t = min(t0 + u, max(n_keys - 1, 0));
+            const int blk = bt[t / kKvBlockTokens];
+            const KT* kp = kv_layer + kv_offset(blk, 0, head, t % kKvBlockTokens) + dl * EPL;
+            const KT* vp = kp + (long)kHeads * kKvBlockTokens * kHeadDim;
+#pragma unroll
+            for (int h = 0; h < NR; ++h) {
+                kraw[u][h] = *reinterpret_cast<const RawT*>(kp + h * (EPL / NR));
+                vraw[u][h] = *reinterpret_cast<const RawT*>(vp + h * (EPL / NR));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            float kx[EPL], vx[EPL];
+#pragma unroll
+            for (int c = 0; c < EPL; ++c) {
+                kx[c] = (float)kraw[u][c / (EPL / NR)][c % (EPL / NR)];
+                vx[c] = (float)vraw[u][c / (EPL / NR)][c % (EPL / NR)];
+            }
+            float sc = ((qv[0] * kx[0] + qv[1] * kx[1]) + (qv[2] * kx[2] + qv[3] * kx[3])) +
+                       ((qv[4] * kx[4] + qv[5] * kx[5]) + (qv[6] * kx[6] + qv[7] * kx[7]));
+#pragma unroll
+            for (int sh = LPR / 2; sh > 0; sh >>= 1) sc += __shfl_xor(sc, sh, 64);
+            sc *= 0.125f;   // 1/sqrt(64)
+            if (t0 + u < n_keys) {
+                const float mn = fmaxf(mi, sc);
+                const float alpha = expf(mi - mn);   // mi = -inf on first use -> 0
+                const float pw = expf(sc - mn);
+                li = li * alpha + pw;
+#pragma unroll
+                for (int c = 0; c < EPL; ++c) o[c] = o[c] * alpha + pw * vx[c];
+                mi = mn;
+            }
+        }
+    }
+    if (live) {
+        float* op = out + (long)m * kHidden + head * kHeadDim + dl * EPL;
+        const float inv = 1.0f / li;
+#pragma unroll
+        for (int c4 = 0; c4 < EPL / 4; ++c4)
+            *reinterpret_cast<f32x4*>(op + 4 * c4) = f32x4{o[4 * c4] * inv, o[4 * c4 + 1] * inv, o[4 * c4 + 2] * inv, o[4 * c4 + 3] * inv};
+    }
+}
+
+void launch_prompt_attention(const float* qbuf, const void* kv_layer, const int* row_slot, const int* row_pos,
+                             const int* block_tables, int max_blocks, float* out, int M, hipStream_t st, bool kv_half) {
+    trace_launch("prompt_attention_kernel");
+    const dim3 grid((M + 31) / 32, kHeads);
+    if (kv_half)
+        hipLaunchKernelGGL(prompt_attention_kernel<true>, grid, dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos, block_tables, max_blocks, out, M);
+    else
+        hipLaunchKernelGGL(prompt_attention_kernel<false>, grid, dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos, block_tables, max_blocks, out, M);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_paged_attention(const float* qbuf, const void* kv_layer, const int* row_slot, const int* row_pos,
                             const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
                             hipStream_t st, int out_mtt, bool kv_half, const int* row_meta) {
