@@ -996,6 +996,8 @@ public:
         launch_sampler(a, st_);
         HIP_CHECK(hipStreamSynchronize(st_));
         HIP_CHECK(hipMemcpy(tokens_out, w.i_out_tok.p, B * 4, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b)
+            if (tokens_out[b] >= 0) tokens_out[b] &= ~kTokFinishedBit;
     }
 
 private:
@@ -1309,8 +1311,7 @@ private:
     }
     void sample_readback(RowWs& w, int Ms, hipStream_t st, int* pin = nullptr) {
         if (!pin) pin = w.pin.as<int>();
-        HIP_CHECK(hipMemcpyAsync(pin, w.i_out_tok.p, (size_t)Ms * 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(pin + cfg_.max_seqs, slot_finished_.p, (size_t)cfg_.max_seqs * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(pin, w.i_out_tok.p, (size_t)Ms * 4, hipMemcpyDeviceToHost, st));   // token | finished bit
     }
     void sample_launch(RowWs& w, const std::vector<int>& sample_row, const std::vector<int>& sample_slot,
                        const std::vector<int>* next_kvpos) {
@@ -1324,9 +1325,9 @@ private:
         const int* pin = w.pin.as<int>();
         for (int j = 0; j < Ms; ++j) {
             Seq* s = slot_owner_[sample_slot[j]];
-            s->tokens.push_back(pin[j]);
+            s->tokens.push_back(pin[j] & ~kTokFinishedBit);
             stats_.tokens_generated++;
-            if (pin[cfg_.max_seqs + sample_slot[j]]) just_finished_.push_back(s);
+            if (pin[j] & kTokFinishedBit) just_finished_.push_back(s);
         }
     }
     // sequences whose tokens completed in this step: (optional literal second pass) -> latent pool -> vocoder queue
@@ -1524,14 +1525,15 @@ private:
         const int* pin = pin_rb_[f.buf].as<int>();
         int rows = 0;
         for (size_t j = 0; j < f.slots.size(); ++j) {
-            const int tok = pin[j];
-            if (tok < 0) continue;   // ghost row of a sequence that had already finished
+            const int raw = pin[j];
+            if (raw < 0) continue;   // ghost row of a sequence that had already finished
+            const int tok = raw & ~kTokFinishedBit;
             Seq* s = slot_owner_[f.slots[j]];
             AUR_REQUIRE(s && s->state == SeqState::RUNNING, "decode read-back for a slot without a running sequence");
             s->tokens.push_back(tok);
             stats_.tokens_generated++;
             ++rows;
-            if (pin[cfg_.max_seqs + f.slots[j]]) just_finished_.push_back(s);
+            if (raw & kTokFinishedBit) just_finished_.push_back(s);
         }
         float ms = 0.f;
         HIP_CHECK(hipEventElapsedTime(&ms, ev_ds_[f.buf], ev_de_[f.buf]));

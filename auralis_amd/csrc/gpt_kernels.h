@@ -144,6 +144,7 @@ void launch_final_norm(const float* xn, const int* sample_row, const int* sample
 void launch_double_norm_rows(const float* src, float* dst, int n, const float* gamma, const float* beta, float eps,
                              hipStream_t st);
 
+constexpr int kTokFinishedBit = 1 << 30;
 struct SamplerArgs {
     const float* P;          // [S][Ms][Npad] logits slabs
     int S, Ms, Npad, V;
@@ -164,7 +165,7 @@ struct SamplerArgs {
     const int* max_tokens;
     const int* ignore_stop;
     const unsigned* seed;
-    int* out_tok;            // [Ms]
+    int* out_tok;            // [Ms]: token | kTokFinishedBit when the sequence finished with it; -1 for a ghost row
     float* dbg_logits;       // optional [Ms][V] penalised logits
     int stop_token;
     int force_full_sort;     // 1: always take the 2048-key bitonic path (A/B of the top-k fast path)

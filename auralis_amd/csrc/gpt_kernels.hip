@@ -1315,9 +1315,8 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
         for (int v = tid; v < V; v += 256) z[v] = z[v] / T;
         __syncthreads();
         const int topk = a.top_k[slot];
-        // ---- top-k fast path (0 < k <= 64, the XTTS default is 50): the k-th largest value is found by a 32-step
-        // bisection on the order-preserving integer image of the logits (one ballot/popcount per element, one barrier
-        // per step), the >= threshold survivors (k plus ties) are compacted and sorted by ONE wave, no workgroup
+        // ---- top-k fast path (0 < k <= 64, the XTTS default is 50): the k-th largest value is found by an 8-step, 16-way
+        // search on the order-preserving integer image of the logits (ballot/popcount counts, one barrier per step), the >= threshold survivors (k plus ties) are compacted and sorted by ONE wave, no workgroup
         // barriers.  Same threshold, same survivor set and same (value, id) order as the full sort below, so both paths
         // give identical tokens; it replaces 66 barrier-separated passes over 2048 keys.
         bool sorted = false;
@@ -1328,16 +1327,25 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
                 const int v = tid + 256 * u;
                 ov[u] = (v < V) ? f2ord(z[v] + 0.0f) : 0u;   // (-0 -> +0: equal floats, equal images); 0 sorts below every float
             }
+            // four bits per step: the 15 candidate thresholds lo | (d << shift) are counted together (one barrier per step, 8
+            // steps); the digit is the largest d whose count reaches k -- the same lo the bit-by-bit bisection arrives at
             unsigned lo = 0u;
-            for (int bit = 31; bit >= 0; --bit) {
-                const unsigned x = lo | (1u << bit);
-                int c = 0;
+            for (int shift = 28, it = 0; shift >= 0; shift -= 4, ++it) {
+                int* cc = &si[(it & 1) * 64];
 #pragma unroll
-                for (int u = 0; u < 5; ++u) c += __popcll(__ballot(ov[u] >= x));
-                if ((tid & 63) == 0) si[(bit & 1) * 4 + (tid >> 6)] = c;
+                for (int d = 1; d < 16; ++d) {
+                    const unsigned x = lo | ((unsigned)d << shift);
+                    int c = 0;
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) c += __popcll(__ballot(ov[u] >= x));
+                    if ((tid & 63) == 0) cc[(tid >> 6) * 16 + d] = c;
+                }
                 __syncthreads();
-                const int* cc = &si[(bit & 1) * 4];
-                if ((cc[0] + cc[1]) + (cc[2] + cc[3]) >= topk) lo = x;
+                unsigned digit = 0;
+#pragma unroll
+                for (int d = 1; d < 16; ++d)
+                    if ((cc[d] + cc[16 + d]) + (cc[32 + d] + cc[48 + d]) >= topk) digit = (unsigned)d;   // counts fall as d grows
+                lo |= digit << shift;
             }
             // lo = image of the k-th largest logit; survivors: everything >= lo
             if (tid == 0) sh_i[1] = 0;
@@ -1465,7 +1473,6 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
     }
 
     if (tid == 0) {
-        a.out_tok[j] = tok;
         a.seen[(long)slot * kSeenStride + tok] = 1;
         const int ng = a.slot_ngen[slot] + 1;
         a.slot_ngen[slot] = ng;
@@ -1473,7 +1480,9 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
         a.slot_pos[slot] = ng;   // k-th generated token enters at mel position k (vllm_mm_gpt.py:480)
         a.slot_kvpos[slot] = a.next_kvpos ? a.next_kvpos[j] : a.slot_kvpos[slot] + 1;
         const bool stop = (tok == a.stop_token) && !a.ignore_stop[slot];
-        if (stop || ng >= a.max_tokens[slot]) a.slot_finished[slot] = 1;
+        const bool fin = stop || ng >= a.max_tokens[slot];
+        if (fin) a.slot_finished[slot] = 1;
+        a.out_tok[j] = tok | (fin ? kTokFinishedBit : 0);   // one read-back word per row: the token and "this was the last one"
     }
 }
 
