@@ -467,16 +467,13 @@ void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
 //   B[k][n = lane&31]                 = x[ci0 + k][t]     (LDS rows [t][16 ch], 48-B row pitch => conflict-free b128)
 
 // XH: the input tensor is fp16 in HBM and already activated (ConvArgs::x_f16), staged without conversion.
-// PF: software-pipelined staging — the global loads of chunk i+1 are issued before the MFMAs of chunk i and parked in
-// registers (2 waves per SIMD: ~200 VGPRs, no spills); !PF: synchronous staging at 3 waves per SIMD (under the 168-VGPR cap of
-// 3 waves the prefetch registers spilled, which is why round 1 measured it slower).
-// WIDE (64-channel tiles only): 512 instead of 256 positions per workgroup — twice the MFMAs per staged weight chunk.
-// DBG (tools/conv_diag only): bit 0 = no global loads in the staging, bit 2 = no LDS fragment reads / MFMAs, bit 3 = no epilogue
-template <int KS, int DIL, int MT, bool XH, bool PF, bool WIDE = false, int DBG = 0>
-__global__ __launch_bounds__(256, ((PF && !XH) || WIDE) ? 2 : 3) void conv1d_mfma_f16_kernel(ConvArgs a) {
+// Staging is synchronous (load -> barrier -> LDS write -> barrier -> MFMAs) at 3 waves per SIMD; the software-pipelined and
+// 512-position forms measured in round 2 (92-111 ms against 94-103 per batch) are gone from the source.
+template <int KS, int DIL, int MT, bool XH, int DBG = 0>
+__global__ __launch_bounds__(256, 3) void conv1d_mfma_f16_kernel(ConvArgs a) {
     constexpr int CK = 16;
     constexpr int WM = MT / 32;
-    constexpr int WN = (MT == 64) ? (WIDE ? 4 : 2) : 4;
+    constexpr int WN = (MT == 64) ? 2 : 4;
     constexpr int NTW = 32 * WN;
     constexpr int NT = 4 * NTW;
     constexpr int HALO = (KS - 1) * DIL;
@@ -578,14 +575,12 @@ __global__ __launch_bounds__(256, ((PF && !XH) || WIDE) ? 2 : 3) void conv1d_mfm
         AUR_WST(0, w0) AUR_WST(1, w1) AUR_WST(2, w2) AUR_WST(3, w3) AUR_WST(4, w4) AUR_WST(5, w5)
     };
 
-    if (PF) load_chunk(0);
     for (int ci0 = 0; ci0 < a.Cin; ci0 += CK) {
-        if (!PF) load_chunk(ci0);          // synchronous staging: fewer live registers, more waves per SIMD
+        load_chunk(ci0);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         store_chunk();
         __syncthreads();
-        if (PF && ci0 + CK < a.Cin) load_chunk(ci0 + CK);
         __builtin_amdgcn_sched_barrier(0);
         const _Float16* xbase = &xs[(wv * NTW + l31) * RS + 8 * hi];
         const _Float16* wbase = &ws[l31 * RS + 8 * hi];
@@ -754,8 +749,8 @@ static void launch_conv_dma(const ConvArgs& a, hipStream_t st) {
     }
 }
 
-template <int KS, int DIL, bool XH, bool PF, bool WIDE>
-static void launch_conv_f16_pf(const ConvArgs& a, hipStream_t st) {
+template <int KS, int DIL, bool XH>
+static void launch_conv_f16_t(const ConvArgs& a, hipStream_t st) {
     AUR_REQUIRE(a.Cin % 16 == 0 && a.wp16, "conv f16: Cin % 16, packed fp16 weights");
     AUR_REQUIRE(!a.out_act_f16 || a.mrf_mode == 0 || a.mrf_mode == 3, "conv f16: fp16 output for plain convs and the MRF mean");
     AUR_REQUIRE(!a.mrf_f16 || a.mrf_mode != 0, "conv f16: mrf_f16 without an MRF mode");
@@ -764,28 +759,15 @@ static void launch_conv_f16_pf(const ConvArgs& a, hipStream_t st) {
     const int n_q = a.ups_s ? a.max_len + 1 : a.max_len;
     trace_launch("conv1d_mfma_f16_kernel");
     if (a.Mtot % 64 == 0) {
-        constexpr int NT64 = WIDE ? 512 : 256;
+        constexpr int NT64 = 256;
         dim3 grid((n_q + NT64 - 1) / NT64, a.Mtot / 64, a.B);
-        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 64, XH, PF, WIDE>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 64, XH>), grid, dim3(256), 0, st, a);
     } else {
         AUR_REQUIRE(a.Mtot % 32 == 0, "conv f16: Mtot % 32");
         constexpr int NT32 = 512;
         dim3 grid((n_q + NT32 - 1) / NT32, a.Mtot / 32, a.B);
-        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 32, XH, PF, false>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 32, XH>), grid, dim3(256), 0, st, a);
     }
-}
-
-// The software-pipelined (PF) and 512-position (WIDE) forms of the kernel were measured in round 2 and are NOT instantiated:
-//  * fp32-input staging (32 registers per chunk), 2 waves per SIMD, by input-channel threshold: convs 105.4-111.0 ms per
-//    64-utterance batch against 103.5 ms synchronous; 512-position tiles on top (spills at 256 VGPRs): 125.7-177.6 ms;
-//  * with the interleaved fp16 activated inputs (16 staging registers, no spills at 3 waves per SIMD): pipelined 92.4-94.8 ms,
-//    512-position tiles 93.3-93.7 ms, synchronous 94.1 ms — all within run-to-run noise.
-// PMC of the heavy kernels (k = 7 / 11 at 128 / 256 channels): waves spend 50-58 % of their cycles in SQ_WAIT_INST_ANY (issue
-// stalls) and 28-34 % parked on waitcnt / barriers, LDS bank conflicts are ~2 % — the limiter is inside the MFMA / LDS-read
-// issue stream, not the staging latency these variants attack.
-template <int KS, int DIL, bool XH>
-static void launch_conv_f16_t(const ConvArgs& a, hipStream_t st) {
-    launch_conv_f16_pf<KS, DIL, XH, false, false>(a, st);
 }
 
 void launch_conv1d_f16(const ConvArgs& a, int KS, int DIL, hipStream_t st) {

@@ -124,3 +124,20 @@ def test_vocoder_fp16_storage_of_resblock_tensors(ctx16, monkeypatch):
             assert x.shape == y.shape and err <= 1e-4 and err <= 2e-3 * sig, (err, sig)
     finally:
         e_ref.close()
+
+
+def test_vocoder_lds_dma_staging_equals_register_staging(ctx16, monkeypatch):
+    """The ResBlock and transposed convs of the fp16 vocoder run on the LDS-DMA staged kernel (conv1d_dma_f16_kernel);
+    AUR_CONV_DMA=0 selects the register-staged one.  Same chunks, same tap order, same MFMAs: the waveforms are equal bit for bit."""
+    e16, _, _ = ctx16
+    monkeypatch.setenv("AUR_CONV_DMA", "0")
+    e_reg, *_ = make_engine(1, max_seqs=2, vocoder_fp16=True)
+    try:
+        gen = torch.Generator().manual_seed(6)
+        lat = torch.randn(2, 61, 1024, generator=gen).numpy()
+        a = e16.vocode(lat, [61, 17], SPK_KEY)
+        b = e_reg.vocode(lat, [61, 17], SPK_KEY)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    finally:
+        e_reg.close()

@@ -29,7 +29,7 @@ template <int KS, int DIL, int DBG>
 static float run(const ConvArgs& a, hipStream_t st) {
     const int n_q = a.max_len;
     dim3 grid((n_q + 255) / 256, a.Mtot / 64, a.B);
-    return time_ms(st, 5, [&] { hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 64, true, false, false, DBG>), grid, dim3(256), 0, st, a); });
+    return time_ms(st, 5, [&] { hipLaunchKernelGGL((conv1d_mfma_f16_kernel<KS, DIL, 64, true, DBG>), grid, dim3(256), 0, st, a); });
 }
 
 template <int KS, int DIL, int NBUF>
