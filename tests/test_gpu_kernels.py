@@ -56,6 +56,12 @@ def test_gemm_tile_is_batch_invariant_bitwise(eng):
     big = eng.dbg_gemm(X.numpy(), W.numpy())
     for m in (1, 71, 128, 129, 300):
         assert np.array_equal(big[:m], eng.dbg_gemm(X[:m].numpy(), W.numpy())), m
+    # narrow GEMMs pick their tile shape by the number of rows (128 x 128 / 128 x 64 / 64 x 64): same bits on every shape
+    X2 = torch.randn(3300, 1024, generator=g)
+    W2 = torch.randn(1024, 1024, generator=g) * 0.05
+    big2 = eng.dbg_gemm(X2.numpy(), W2.numpy())
+    for m in (64, 300, 2000):
+        assert np.array_equal(big2[:m], eng.dbg_gemm(X2[:m].numpy(), W2.numpy())), m
 
 
 def _gelu_new(x):
