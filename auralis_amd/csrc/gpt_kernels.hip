@@ -338,20 +338,34 @@ __global__ __launch_bounds__(256) void pack_wt16_kernel(const float* __restrict_
 }
 
 // LayerNorm folded into a [K][N] weight matrix: Wf[k][n] = gamma[k] * W[k][n] (then packed like pack_wt16), c1[n] = sum_k Wf[k][n],
-// c2[n] = sum_k beta[k] * W[k][n] + bias[n] (sums in double).  One thread per column for the vectors.
+// c2[n] = sum_k beta[k] * W[k][n] + bias[n] (sums in double).  A workgroup takes 16 columns; its 16 k-slices are combined in a
+// fixed order.
 __global__ __launch_bounds__(256) void fold_ln_vectors_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ bias,
                                                               float* __restrict__ c1, float* __restrict__ c2, int K, int N) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ double p1[16][16], p2[16][16];
+    const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int n = blockIdx.x * 16 + col;
+    const int k0 = (int)((long)K * sl / 16), k1 = (int)((long)K * (sl + 1) / 16);
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < K; ++k) {
-        const float wv = W[(long)k * ldw + n];
-        s1 += (double)(gamma[k] * wv);   // the rounded product the GEMM multiplies with
-        s2 += (double)beta[k] * (double)wv;
+    if (n < N)
+        for (int k = k0; k < k1; ++k) {
+            const float wv = W[(long)k * ldw + n];
+            s1 += (double)(gamma[k] * wv);   // the rounded product the GEMM multiplies with
+            s2 += (double)beta[k] * (double)wv;
+        }
+    p1[sl][col] = s1;
+    p2[sl][col] = s2;
+    __syncthreads();
+    if (sl == 0 && n < N) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int i = 0; i < 16; ++i) {
+            t1 += p1[i][col];
+            t2 += p2[i][col];
+        }
+        c1[n] = (float)t1;
+        c2[n] = (float)(t2 + (bias ? (double)bias[n] : 0.0));
     }
-    c1[n] = (float)s1;
-    c2[n] = (float)(s2 + (bias ? (double)bias[n] : 0.0));
 }
 __global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ gamma,
                                                          float* __restrict__ out, int K, int N) {
@@ -364,7 +378,7 @@ void launch_fold_ln(const float* W, int ldw, const float* gamma, const float* be
                     float* c1, float* c2, int K, int N, hipStream_t st) {
     AUR_REQUIRE(N % 16 == 0 && K % 16 == 0 && ldw >= N, "fold_ln: shape");
     trace_launch("fold_ln");
-    hipLaunchKernelGGL(fold_ln_vectors_kernel, dim3((N + 255) / 256), dim3(256), 0, st, W, ldw, gamma, beta, bias, c1, c2, K, N);
+    hipLaunchKernelGGL(fold_ln_vectors_kernel, dim3((N + 15) / 16), dim3(256), 0, st, W, ldw, gamma, beta, bias, c1, c2, K, N);
     hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)(((long)K * N + 255) / 256)), dim3(256), 0, st, W, ldw, gamma, scratch, K, N);
     HIP_CHECK(hipGetLastError());
     launch_pack_wt16(scratch, N, Wt, K, N, st);
