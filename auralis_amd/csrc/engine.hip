@@ -1621,6 +1621,27 @@ private:
             launch_conv1d(a, KS, DIL, st_voc_);
         if (prof) HIP_CHECK(hipEventRecord(ev->b, st_voc_));
     }
+    void round_conv(RoundArgs& a, int KS, int DIL, double tot) {
+        const bool prof = cfg_.profile != 0;
+        ConvEvent* ev = nullptr;
+        if (prof) {
+            if (n_conv_events_ == conv_events_.size()) {
+                ConvEvent e{};
+                HIP_CHECK(hipEventCreate(&e.a));
+                HIP_CHECK(hipEventCreate(&e.b));
+                conv_events_.push_back(e);
+            }
+            ev = &conv_events_[n_conv_events_++];
+            ev->kind = a.C == 64 ? 2 : 3;
+            ev->flops = 2.0 * (2.0 * a.C * KS * a.C * tot);   // conv1 + conv2
+            // stream in, then: stream out (mode 0) | running sum out (1) | in and out (2) | running sum in, stage output out (3)
+            const double io = a.mrf_mode == 0 ? 2.0 : a.mrf_mode == 1 ? 2.0 : 4.0;
+            ev->bytes = a.C * tot * (2.0 + io);
+            HIP_CHECK(hipEventRecord(ev->a, st_voc_));
+        }
+        launch_resblock_round_f16(a, KS, DIL, st_voc_);
+        if (prof) HIP_CHECK(hipEventRecord(ev->b, st_voc_));
+    }
     void collect_conv_events() {
         for (size_t i = 0; i < n_conv_events_; ++i) {
             float ms = 0.f;
@@ -1682,6 +1703,7 @@ private:
         if (xt_f16_) {   // the residual stream as activated halves (stage input, running value)
             v_Ah_.ensure(Bz * 8192 * T * 2);
             v_Ch_.ensure(Bz * 8192 * T * 2);
+            v_Ch2_.ensure(Bz * 8192 * T * 2);
         } else {
             v_A_.ensure(Bz * 8192 * T * 4);
             v_C_.ensure(Bz * 8192 * T * 4);
@@ -1705,7 +1727,7 @@ private:
         const float* in = v_s0_.as<float>();
         int Cin = 512, mul = 1, cond_off = 512;
         float *A = v_A_.as<float>(), *Bb = v_B_.as<float>(), *Cb = v_C_.as<float>(), *D = v_D_.as<float>(), *E = v_E_.as<float>();
-        void *Ah = v_Ah_.p, *Ch = v_Ch_.p;   // fp16 vocoder: the activated residual stream (stage input / after rounds 0, 1)
+        void *Ah = v_Ah_.p, *Ch = v_Ch_.p, *Ch2 = v_Ch2_.p;   // fp16 vocoder: the activated residual stream (stage input / after rounds 0, 1)
         for (int i = 0; i < 4; ++i) {
             const int s = rates[i], C = chans[i], mul_out = mul * s;
             const long Lin = (long)T * mul, Lout = (long)T * mul_out;
@@ -1719,7 +1741,25 @@ private:
             if (xt_f16_) { a.out = reinterpret_cast<float*>(Ah); a.out_act_f16 = 1; a.out_slope = 0.1f; }
             conv(a, 2, 1, totT * mul, totT * mul_out);
             cond_off += C;
-            for (int j = 0; j < 3; ++j)
+            // the 64- and 32-channel stages (HBM-bound as two launches per round): one fused launch per ResBlock round, the
+            // conv1 -> conv2 intermediate stays in LDS and the residual comes from the staged window (vocoder_kernels.h, RoundArgs);
+            // the stream ping-pongs Ah -> Ch -> Ch2 because neighbouring tiles read each other's halo
+            const bool fused = xt_f16_ && conv_dma_ && C <= 64;
+            for (int j = 0; j < 3 && fused; ++j)
+                for (int c = 0; c < 3; ++c) {
+                    RoundArgs ra{};
+                    ra.y = (c == 0) ? Ah : (c == 1) ? Ch : Ch2;
+                    ra.out = (c == 0) ? Ch : (c == 1) ? Ch2 : nullptr;
+                    ra.w1 = v_c1_[i][j][c].wp16; ra.w2 = v_c2_[i][j][c].wp16; ra.b1 = v_c1_[i][j][c].bias; ra.b2 = v_c2_[i][j][c].bias;
+                    ra.base_len = d_len; ra.len_mul = mul_out; ra.stride = Lout; ra.bstride = (long)C * Lout; ra.C = C;
+                    ra.B = B; ra.max_len = maxT * mul_out; ra.zeros = v_zero_.p;
+                    if (c == 2) {
+                        ra.mrf = D; ra.e_out = E; ra.mrf_mode = (j == 0) ? 1 : (j == 1) ? 2 : 3;
+                        ra.e_slope = (i == 3) ? 0.01f : 0.1f;
+                    }
+                    round_conv(ra, rk[j], rd[c], totT * mul_out);
+                }
+            for (int j = 0; j < 3 && !fused; ++j)
                 for (int c = 0; c < 3; ++c) {
                     // fp16 vocoder: the residual stream of a ResBlock lives in HBM as activated interleaved halves, fp16(lrelu(x)):
                     // Ah (the transposed conv's output, shared by the stage's three ResBlocks) in round 0, Ch (updated in place by
@@ -1922,7 +1962,7 @@ private:
     // vocoder
     ConvLayer v_pre_, v_ups_[4], v_c1_[4][3][3], v_c2_[4][3][3];
     const float* v_post_ = nullptr;
-    DevBuf v_meta_, v_z_, v_s0_, v_A_, v_B_, v_C_, v_D_, v_E_, v_Ch_, v_Ah_, v_zero_, tmp_lat_, tmp_wav_;
+    DevBuf v_meta_, v_z_, v_s0_, v_A_, v_B_, v_C_, v_D_, v_E_, v_Ch_, v_Ch2_, v_Ah_, v_zero_, tmp_lat_, tmp_wav_;
     std::vector<ConvEvent> conv_events_;
     std::vector<ConvEvent> gemm_events_;
     size_t n_gemm_events_ = 0;

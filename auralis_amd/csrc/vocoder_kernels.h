@@ -59,6 +59,32 @@ struct ConvArgs {
 };
 
 void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st);
+
+// One ResBlock round of the fp16 vocoder in ONE launch (the 64- and 32-channel stages, which are HBM-bound as two launches):
+//   h = fp16(lrelu(conv1(y) + b1, 0.1))            conv1: k taps, dilation d, input = the activated stream y = fp16(lrelu(x))
+//   v = x + conv2(h) + b2                           conv2: k taps, dilation 1; x = y un-activated (read back from the staged window)
+//   mrf_mode 0: out = fp16(lrelu(v, 0.1))  (the next round's stream; out must not alias y: neighbouring tiles read y's halo)
+//   mrf_mode 1 / 2 / 3: the ResBlock's last round, as ConvArgs (mrf = halves; mode 3 writes e_out = fp16(lrelu(mean, e_slope)))
+// h never leaves LDS: per element the round moves 2 B in + 2 B out instead of 10.  Same chunk, tap and MFMA order as the two
+// separate kernels, so the results are equal bit for bit.  All tensors are interleaved halves [C/16][stride][16].
+struct RoundArgs {
+    const void* y;          // [B][C/16][stride][16] halves
+    void* out;              // mode 0
+    void* mrf;              // modes 1, 2 (read-modify-write), 3 (read)
+    void* e_out;            // mode 3
+    const void* w1;         // packed fp16 [C/16][KS][C][16] (ConvLayer::wp16 of c1 / c2)
+    const void* w2;
+    const float* b1;
+    const float* b2;
+    const int* base_len;
+    int len_mul;
+    long stride, bstride;   // positions per channel chunk row / elements per batch item (C * stride)
+    int C, mrf_mode;
+    float e_slope;
+    int B, max_len;
+    const void* zeros;      // >= 16 zero bytes
+};
+void launch_resblock_round_f16(const RoundArgs& a, int KS, int DIL, hipStream_t st);
 // same contract on fp16 MFMA inputs (fp32 accumulate, fp32 activations in HBM); uses a.wp16
 void launch_conv1d_f16(const ConvArgs& a, int KS, int DIL, hipStream_t st);
 

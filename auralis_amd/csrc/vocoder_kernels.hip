@@ -13,6 +13,8 @@
 // 4 LDS dword reads.  D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include "vocoder_kernels.h"
 
+#include <type_traits>
+
 namespace aur {
 
 // Shared epilogue of the MFMA conv kernels: bias, speaker conditioning, residual, MRF fold, masked store.
@@ -747,6 +749,203 @@ static void launch_conv_dma(const ConvArgs& a, hipStream_t st) {
         dim3 grid((n_q + 511) / 512, a.Mtot / 32, a.B);
         hipLaunchKernelGGL((conv1d_dma_f16_kernel<KS, DIL, 32, NBUF>), grid, dim3(256), 0, st, a);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused ResBlock round (vocoder_kernels.h, RoundArgs).  Workgroup = C/32 x 4 waves, each wave a 32-channel x 64-position block
+// of a [C] x [256] conv1 tile; conv2 then yields NT2 = 256 - (KS - 1) output positions of it.  LDS: the input window of ALL C
+// channels (staged once, by LDS-DMA, also the source of the residual), the conv1 result h as [chunk][position][16] rows, and two
+// weight-chunk buffers through which the 2 * C/16 weight chunks of conv1 then conv2 stream (DMA of chunk g + 1 under the MFMAs of
+// chunk g).  Row halves are swapped when bit 3 of the row index is set (as conv1d_dma_f16_kernel) in all three images.
+__device__ __forceinline__ int swz16(int row, int half) { return 16 * (half ^ ((row >> 3) & 1)); }
+
+template <int KS, int DIL, int C>
+__global__ __launch_bounds__(64 * (C / 32) * 4) void resblock_round_f16_kernel(RoundArgs a) {
+    constexpr int NCH = C / 16, NW = (C / 32) * 4;
+    constexpr int P1 = (KS - 1) / 2 * DIL, P2 = (KS - 1) / 2;
+    constexpr int NT1 = 256, NT2 = NT1 - (KS - 1);
+    constexpr int XROW = (NT1 + (KS - 1) * DIL + 31) / 32 * 32;   // window rows per chunk, whole 1-KiB copies
+    constexpr int HROW = (NT1 + (KS - 1) + 31) / 32 * 32;
+    constexpr int WCH = KS * C * 32;                               // bytes of one weight chunk
+    constexpr int XI = XROW / 32, WI = WCH / 1024;                 // 1-KiB copies per window chunk / weight chunk
+    static_assert(WCH % 1024 == 0, "weight chunk in whole copies");
+    __shared__ __attribute__((aligned(1024))) char xs[NCH * XROW * 32];
+    __shared__ __attribute__((aligned(1024))) char hs[NCH * HROW * 32];
+    __shared__ __attribute__((aligned(1024))) char ws[2][WCH];
+
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * NT2;
+    const int len = a.base_len[b] * a.len_mul;
+    if (q0 >= len) return;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wvs = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wvs >> 2, wn = wvs & 3;
+    const _Float16* yb = reinterpret_cast<const _Float16*>(a.y) + (long)b * a.bstride;
+    const unsigned xs_l = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)xs;
+    const unsigned ws_l = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)&ws[0][0];
+
+    auto issue_w = [&](int g) {   // weight chunk g of the sequence conv1[0..NCH), conv2[0..NCH) into buffer g & 1
+        const char* src0 = reinterpret_cast<const char*>(g < NCH ? a.w1 : a.w2) + (long)(g < NCH ? g : g - NCH) * WCH;
+        for (int ii = wvs; ii < WI; ii += NW) {
+            const int s = ii * 64 + lane, row = s >> 1, h = (s & 1) ^ ((row >> 3) & 1);
+            glds16(src0 + (row * 2 + h) * 16, __builtin_amdgcn_readfirstlane(ws_l + (unsigned)(g & 1) * WCH + (unsigned)ii * 1024));
+        }
+    };
+    // the input window of every chunk: row i <-> position q0 - P2 - P1 + i
+    for (int ii = wvs; ii < NCH * XI; ii += NW) {
+        const int c = ii / XI, s = (ii - c * XI) * 64 + lane, row = s >> 1, h = (s & 1) ^ ((row >> 3) & 1);
+        const int t = q0 - P2 - P1 + row;
+        const char* src = (t >= 0 && t < len) ? reinterpret_cast<const char*>(yb + ((long)c * a.stride + t) * 16 + 8 * h)
+                                              : reinterpret_cast<const char*>(a.zeros);
+        glds16(src, __builtin_amdgcn_readfirstlane(xs_l + (unsigned)ii * 1024));
+    }
+    issue_w(0);
+    issue_w(1);
+
+    f32x16 acc[2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    };
+    // one weight chunk: B fragments from `img` (rows of 32 B, chunk-major), row = wn * 64 + n * 32 + l31 + j * dil
+    auto mfma_chunk = [&](const char* img, int rows_per_chunk, int c, int g, auto DILc) {
+        constexpr int dil = decltype(DILc)::value;
+        const char* wb = &ws[g & 1][0] + (wm * 32 + l31) * 32 + 16 * (hi ^ ((l31 >> 3) & 1));
+        const char* xb = img + (long)c * rows_per_chunk * 32;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const h16x8 av = *reinterpret_cast<const h16x8*>(wb + j * C * 32);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int i = wn * 64 + n * 32 + l31 + j * dil;
+                const h16x8 bv = *reinterpret_cast<const h16x8*>(xb + i * 32 + swz16(i, hi));
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[n], 0, 0, 0);
+            }
+        }
+    };
+    auto sync_chunk = [&](int g) {   // chunk g's copies have landed everywhere; refill the buffer chunk g - 1 used
+        wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (g >= 1 && g + 1 < 2 * NCH) issue_w(g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- conv1 over the 256 positions q0 - P2 .. of the tile
+    zero_acc();
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        sync_chunk(c);
+        mfma_chunk(xs, XROW, c, c, std::integral_constant<int, DIL>{});
+    }
+    // h = fp16(lrelu(. + b1)), zero outside the utterance (conv2 pads the conv1 OUTPUT with zeros)
+    {
+        const int c0 = wm * 32 + 4 * hi;
+        float bias[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias[r] = a.b1[c0 + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int p = wn * 64 + n * 32 + l31, pg = q0 - P2 + p;
+            const bool in = pg >= 0 && pg < len;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c = c0 + 8 * g4;
+                h16x4v hv;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) hv[k] = (_Float16)(in ? lrelu(acc[n][4 * g4 + k] + bias[4 * g4 + k], 0.1f) : 0.f);
+                *reinterpret_cast<h16x4v*>(hs + ((long)(c >> 4) * HROW + p) * 32 + swz16(p, (c & 15) >> 3) + (c & 7) * 2) = hv;
+            }
+        }
+    }
+    // ---- conv2 over h (the barrier of its first chunk also publishes h)
+    zero_acc();
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        sync_chunk(NCH + c);
+        mfma_chunk(hs, HROW, c, NCH + c, std::integral_constant<int, 1>{});
+    }
+    // ---- epilogue: + b2 + residual (the window's own rows, un-activated) -> stream / MRF
+    {
+        const int c0 = wm * 32 + 4 * hi;
+        float bias[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias[r] = a.b2[c0 + (r & 3) + 8 * (r >> 2)];
+        const long ob = (long)b * a.bstride;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int p = wn * 64 + n * 32 + l31, q = q0 + p;
+            const bool ok = p < NT2 && q < len;
+            const int qc = min(q, len - 1), i = min(p, NT2 - 1) + P2 + P1;
+            h16x4v mold[4];
+            if (a.mrf_mode >= 2) {
+                const _Float16* mb = reinterpret_cast<const _Float16*>(a.mrf) + ob;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int c = c0 + 8 * g4;
+                    mold[g4] = *reinterpret_cast<const h16x4v*>(mb + ((long)(c >> 4) * a.stride + qc) * 16 + (c & 15));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!ok) continue;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c = c0 + 8 * g4;
+                const h16x4v yv = *reinterpret_cast<const h16x4v*>(xs + ((long)(c >> 4) * XROW + i) * 32 + swz16(i, (c & 15) >> 3) + (c & 7) * 2);
+                float val[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float yk = (float)yv[k];
+                    val[k] = acc[n][4 * g4 + k] + bias[4 * g4 + k] + (yk < 0.f ? yk * 10.0f : yk);
+                }
+                const long off = ((long)(c >> 4) * a.stride + q) * 16 + (c & 15);
+                h16x4v o;
+                if (a.mrf_mode == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = (_Float16)lrelu(val[k], 0.1f);
+                    *reinterpret_cast<h16x4v*>(reinterpret_cast<_Float16*>(a.out) + ob + off) = o;
+                } else if (a.mrf_mode == 1 || a.mrf_mode == 2) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = (_Float16)(a.mrf_mode == 2 ? val[k] + (float)mold[g4][k] : val[k]);
+                    *reinterpret_cast<h16x4v*>(reinterpret_cast<_Float16*>(a.mrf) + ob + off) = o;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = (_Float16)lrelu(((float)mold[g4][k] + val[k]) / 3.0f, a.e_slope);
+                    *reinterpret_cast<h16x4v*>(reinterpret_cast<_Float16*>(a.e_out) + ob + off) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int KS, int DIL>
+static void launch_round_c(const RoundArgs& a, hipStream_t st) {
+    const int nt2 = 256 - (KS - 1);
+    const dim3 grid((a.max_len + nt2 - 1) / nt2, a.B);
+    trace_launch("resblock_round_f16_kernel");
+    if (a.C == 64) hipLaunchKernelGGL((resblock_round_f16_kernel<KS, DIL, 64>), grid, dim3(512), 0, st, a);
+    else if (a.C == 32) hipLaunchKernelGGL((resblock_round_f16_kernel<KS, DIL, 32>), grid, dim3(256), 0, st, a);
+    else throw InvalidArgument("resblock round: 64 or 32 channels");
+}
+
+void launch_resblock_round_f16(const RoundArgs& a, int KS, int DIL, hipStream_t st) {
+    AUR_REQUIRE(a.y && a.zeros && a.w1 && a.w2 && a.b1 && a.b2, "resblock round: arguments");
+    AUR_REQUIRE(a.mrf_mode == 0 ? (a.out && a.out != a.y) : (a.mrf && (a.mrf_mode != 3 || a.e_out)), "resblock round: outputs of the mode");
+    switch (KS * 16 + DIL) {
+        case 3 * 16 + 1: launch_round_c<3, 1>(a, st); break;
+        case 3 * 16 + 3: launch_round_c<3, 3>(a, st); break;
+        case 3 * 16 + 5: launch_round_c<3, 5>(a, st); break;
+        case 7 * 16 + 1: launch_round_c<7, 1>(a, st); break;
+        case 7 * 16 + 3: launch_round_c<7, 3>(a, st); break;
+        case 7 * 16 + 5: launch_round_c<7, 5>(a, st); break;
+        case 11 * 16 + 1: launch_round_c<11, 1>(a, st); break;
+        case 11 * 16 + 3: launch_round_c<11, 3>(a, st); break;
+        case 11 * 16 + 5: launch_round_c<11, 5>(a, st); break;
+        default: throw InvalidArgument("resblock round: k in {3,7,11}, dilation in {1,3,5}");
+    }
+    HIP_CHECK(hipGetLastError());
 }
 
 template <int KS, int DIL, bool XH>
