@@ -752,16 +752,16 @@ static void launch_conv_dma(const ConvArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused ResBlock round (vocoder_kernels.h, RoundArgs).  Workgroup = C/32 x 4 waves, each wave a 32-channel x 64-position block
+// Fused ResBlock round (vocoder_kernels.h, RoundArgs).  Workgroup = C/32 x 8/WN waves, each wave a 32-channel x 32*WN-position block
 // of a [C] x [256] conv1 tile; conv2 then yields NT2 = 256 - (KS - 1) output positions of it.  LDS: the input window of ALL C
 // channels (staged once, by LDS-DMA, also the source of the residual), the conv1 result h as [chunk][position][16] rows, and two
 // weight-chunk buffers through which the 2 * C/16 weight chunks of conv1 then conv2 stream (DMA of chunk g + 1 under the MFMAs of
 // chunk g).  Row halves are swapped when bit 3 of the row index is set (as conv1d_dma_f16_kernel) in all three images.
 __device__ __forceinline__ int swz16(int row, int half) { return 16 * (half ^ ((row >> 3) & 1)); }
 
-template <int KS, int DIL, int C>
-__global__ __launch_bounds__(64 * (C / 32) * 4) void resblock_round_f16_kernel(RoundArgs a) {
-    constexpr int NCH = C / 16, NW = (C / 32) * 4;
+template <int KS, int DIL, int C, int WN>
+__global__ __launch_bounds__(64 * (C / 32) * (8 / WN)) void resblock_round_f16_kernel(RoundArgs a) {
+    constexpr int NCH = C / 16, NWN = 8 / WN, NW = (C / 32) * NWN, PW = 32 * WN;   // NWN waves along the positions, PW positions each
     constexpr int P1 = (KS - 1) / 2 * DIL, P2 = (KS - 1) / 2;
     constexpr int NT1 = 256, NT2 = NT1 - (KS - 1);
     constexpr int XROW = (NT1 + (KS - 1) * DIL + 31) / 32 * 32;   // window rows per chunk, whole 1-KiB copies
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(64 * (C / 32) * 4) void resblock_round_f16_kernel(R
     if (q0 >= len) return;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wvs = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wvs >> 2, wn = wvs & 3;
+    const int wm = wvs / NWN, wn = wvs % NWN;
     const _Float16* yb = reinterpret_cast<const _Float16*>(a.y) + (long)b * a.bstride;
     const unsigned xs_l = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)xs;
     const unsigned ws_l = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)&ws[0][0];
@@ -802,14 +802,14 @@ __global__ __launch_bounds__(64 * (C / 32) * 4) void resblock_round_f16_kernel(R
     issue_w(0);
     issue_w(1);
 
-    f32x16 acc[2];
+    f32x16 acc[WN];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < WN; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
     };
-    // one weight chunk: B fragments from `img` (rows of 32 B, chunk-major), row = wn * 64 + n * 32 + l31 + j * dil
+    // one weight chunk: B fragments from `img` (rows of 32 B, chunk-major), row = wn * PW + n * 32 + l31 + j * dil
     auto mfma_chunk = [&](const char* img, int rows_per_chunk, int c, int g, auto DILc) {
         constexpr int dil = decltype(DILc)::value;
         const char* wb = &ws[g & 1][0] + (wm * 32 + l31) * 32 + 16 * (hi ^ ((l31 >> 3) & 1));
@@ -818,8 +818,8 @@ __global__ __launch_bounds__(64 * (C / 32) * 4) void resblock_round_f16_kernel(R
         for (int j = 0; j < KS; ++j) {
             const h16x8 av = *reinterpret_cast<const h16x8*>(wb + j * C * 32);
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int i = wn * 64 + n * 32 + l31 + j * dil;
+            for (int n = 0; n < WN; ++n) {
+                const int i = wn * PW + n * 32 + l31 + j * dil;
                 const h16x8 bv = *reinterpret_cast<const h16x8*>(xb + i * 32 + swz16(i, hi));
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[n], 0, 0, 0);
             }
@@ -847,8 +847,8 @@ __global__ __launch_bounds__(64 * (C / 32) * 4) void resblock_round_f16_kernel(R
 #pragma unroll
         for (int r = 0; r < 16; ++r) bias[r] = a.b1[c0 + (r & 3) + 8 * (r >> 2)];
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int p = wn * 64 + n * 32 + l31, pg = q0 - P2 + p;
+        for (int n = 0; n < WN; ++n) {
+            const int p = wn * PW + n * 32 + l31, pg = q0 - P2 + p;
             const bool in = pg >= 0 && pg < len;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -875,8 +875,8 @@ __global__ __launch_bounds__(64 * (C / 32) * 4) void resblock_round_f16_kernel(R
         for (int r = 0; r < 16; ++r) bias[r] = a.b2[c0 + (r & 3) + 8 * (r >> 2)];
         const long ob = (long)b * a.bstride;
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int p = wn * 64 + n * 32 + l31, q = q0 + p;
+        for (int n = 0; n < WN; ++n) {
+            const int p = wn * PW + n * 32 + l31, q = q0 + p;
             const bool ok = p < NT2 && q < len;
             const int qc = min(q, len - 1), i = min(p, NT2 - 1) + P2 + P1;
             h16x4v mold[4];
@@ -925,8 +925,10 @@ static void launch_round_c(const RoundArgs& a, hipStream_t st) {
     const int nt2 = 256 - (KS - 1);
     const dim3 grid((a.max_len + nt2 - 1) / nt2, a.B);
     trace_launch("resblock_round_f16_kernel");
-    if (a.C == 64) hipLaunchKernelGGL((resblock_round_f16_kernel<KS, DIL, 64>), grid, dim3(512), 0, st, a);
-    else if (a.C == 32) hipLaunchKernelGGL((resblock_round_f16_kernel<KS, DIL, 32>), grid, dim3(256), 0, st, a);
+    // positions per wave: 64 (8 waves) at 64 channels, 32 (8 waves) at 32 channels -- 9.6 vs 10.1 ms for the 32-channel stage,
+    // no difference at 64 channels (16 waves: 16.2 vs 16.4)
+    if (a.C == 64) hipLaunchKernelGGL((resblock_round_f16_kernel<KS, DIL, 64, 2>), grid, dim3(512), 0, st, a);
+    else if (a.C == 32) hipLaunchKernelGGL((resblock_round_f16_kernel<KS, DIL, 32, 1>), grid, dim3(512), 0, st, a);
     else throw InvalidArgument("resblock round: 64 or 32 channels");
 }
 
