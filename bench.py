@@ -174,9 +174,9 @@ def build_report(args, st, dims, world, samples, dt, audio_s):
             r["rocprof"] = {"avg_launch_us": us, "achieved": g2, "frac": g2 / HBM_PEAK_GBPS, "source": prof_path}
         return r
 
-    # fp16 vocoder: the ResBlock convs with 64-channel output tiles run the LDS-DMA staged kernel, the rest the register-staged one
-    conv_kernel = "conv1d_dma_f16_kernel + conv1d_mfma_f16_kernel" if args.vocoder == "fp16" else "conv1d_mfma_kernel"
-    conv_re = r"conv1d_(dma|mfma)_f16_kernel<" if args.vocoder == "fp16" else r"conv1d_mfma_kernel<"
+    # fp16 vocoder: LDS-DMA staged convs (256 / 128 channels, transposed convs), fused ResBlock rounds (64 / 32 channels), conv_pre register-staged
+    conv_kernel = "conv1d_dma_f16_kernel + resblock_round_f16_kernel + conv1d_mfma_f16_kernel" if args.vocoder == "fp16" else "conv1d_mfma_kernel"
+    conv_re = r"(conv1d_(dma|mfma)_f16_kernel|resblock_round_f16_kernel)<" if args.vocoder == "fp16" else r"conv1d_mfma_kernel<"
     # SURVEY 8(d) counts the vocoder's layer-granular activation traffic in fp32 (21 301 B per output sample); conv_bytes is the
     # same accounting in the dtype each tensor is really stored in
     roof_conv = roof(f"{conv_kernel} (HiFi-GAN convs, all instantiations)", st["conv_ms"], st["conv_launches"], st["conv_bytes"],

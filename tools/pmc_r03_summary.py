@@ -1,15 +1,15 @@
 """Fold the rocprofv3 PMC passes of the default bench command into profiles/hbm_traffic.json["r03_decode"] / ["r03_conv"].
 
   PMC_PASSES='fetch write' PMC_KERNELS='paged_attention_kernel|gemm_rows_kernel' PMC_BENCH_ARGS='--tokens 40' tools/pmc.sh r03dec
-  PMC_PASSES='fetch write' PMC_KERNELS='conv1d_' tools/pmc.sh r03conv
+  PMC_PASSES='fetch write' PMC_KERNELS='conv1d_|resblock_round' tools/pmc.sh r03conv
   python tools/pmc_r03_summary.py gpurun_out/pmc_r03dec 40 gpurun_out/pmc_r03conv
 
 Units and corrections (MI355X_MICROARCH.md §HBM): Counter_Value is KiB per dispatch; FETCH_SIZE reports 1/2 of the bytes of a
 wide coalesced streaming read (16 B per lane), other access widths are uncalibrated, WRITE_SIZE is taken as reported.
 * decode kernels: every load is a 16-B-per-lane float4 stream -> fetch = 2 x raw.
 * conv kernels: two input families, each calibrated on launches whose compulsory read traffic is known exactly
-    fp16 interleaved inputs (ResBlock convs: 16-B loads or LDS-DMA copies + 8-B residual loads): the 18 launches of the 32-channel
-      stage, one co-tile each, 29 fp16 tensors of 64 x 32 x 312 064 halves
+    fp16 interleaved inputs (ResBlock convs, fused rounds, transposed convs: LDS-DMA copies or 16-B loads + 8-B loads): the 9 fused
+      round launches of the 32-channel stage, 11 fp16 tensors of 64 x 32 x 312 064 halves
     fp32 inputs (conv_pre, the four polyphase transposed convs: 4-B loads): the transposed convs' input tensors
   every launch's FETCH_SIZE is divided by its family's factor (raw / known)."""
 import collections
@@ -71,22 +71,22 @@ def conv_summary(d):
     w = load(os.path.join(d, "write", "pmc_counter_collection.csv"), "WRITE_SIZE")
 
     def family(name):   # "h": fp16 interleaved inputs (16-B loads / LDS-DMA copies, 8-B residual loads); "f": fp32 inputs (4-B loads)
-        if name.startswith("conv1d_dma_f16_kernel<"):
+        if name.startswith("conv1d_dma_f16_kernel<") or name.startswith("resblock_round_f16_kernel<"):
             return "h"
         m = re.search(r"conv1d_mfma_f16_kernel<(\d+), (\d+), (\d+), (true|false)", name)
         return None if not m else ("h" if m.group(4) == "true" else "f")
     half = 64 * 32 * 312064 * 2.0   # one fp16 tensor of the 32-channel stage, 64 utterances at full length: 1.278 GB
     # known compulsory reads (one co-tile per launch, so nothing is read twice):
-    #  h: the 18 ResBlock launches of the 32-channel stage: 9 first convs read the stream (1 tensor), 9 residual convs read the
-    #     c1 -> c2 intermediate and the stream (2), the MRF convs of ResBlocks 1 and 2 also the running sum (1 each) = 29 tensors
+    #  h: the 9 fused ResBlock-round launches of the 32-channel stage: each reads the stream once (1 tensor), the last rounds of
+    #     ResBlocks 1 and 2 also the running sum (1 each) = 11 tensors
     #  f: the four transposed convs read their fp32 input once per 64-row co-tile group; compulsory = the input tensors
-    known_h = 29 * half
+    known_h = 11 * half
     known_f = 64 * 4.0 * (512 * 1219 + 256 * 9752 + 128 * 78016 + 64 * 156032)
-    raw_h = sum(sum(v) for k, v in f.items() if re.match(r"conv1d_mfma_f16_kernel<\d+, \d+, 32, true", k))
+    raw_h = sum(sum(v) for k, v in f.items() if re.match(r"resblock_round_f16_kernel<\d+, \d+, 32", k))
     raw_f = sum(sum(v) for k, v in f.items() if re.match(r"conv1d_mfma_f16_kernel<2, 1, \d+, false", k))
     # (since the stage inputs are halves too, only conv_pre reads fp32: no calibration launches, FETCH_SIZE taken as reported)
     factor = {"h": raw_h / known_h if raw_h else 0.5, "f": raw_f / known_f if raw_f else 1.0}
-    cal = {"fp16_inputs": {"launches": "conv1d_mfma_f16_kernel<*, *, 32, true> (the 32-channel stage)", "known_read_bytes": known_h,
+    cal = {"fp16_inputs": {"launches": "resblock_round_f16_kernel<*, *, 32, *> (the 32-channel stage)", "known_read_bytes": known_h,
                            "fetch_raw": raw_h, "fetch_raw_over_known": factor["h"]},
            "fp32_inputs": {"launches": "conv1d_mfma_f16_kernel<2, 1, *, false> (the four transposed convs)", "known_read_bytes": known_f,
                            "fetch_raw": raw_f, "fetch_raw_over_known": factor["f"]}}
@@ -102,7 +102,7 @@ def conv_summary(d):
         tot_f += fb
         tot_w += wb
         by_kernel[k] = {"launches": len(v), "fetch_bytes_per_launch": fb / len(v), "write_bytes_per_launch": wb / len(v)}
-    return {"command": "PMC_PASSES='fetch write' PMC_KERNELS='conv1d_' tools/pmc.sh r03conv; python tools/pmc_r03_summary.py ...",
+    return {"command": "PMC_PASSES='fetch write' PMC_KERNELS='conv1d_|resblock_round' tools/pmc.sh r03conv; python tools/pmc_r03_summary.py ...",
             "conv_fp16": {"launches": int(n), "fetch_bytes_per_launch": tot_f / max(1, n), "write_bytes_per_launch": tot_w / max(1, n),
                           "bytes_per_launch": (tot_f + tot_w) / max(1, n)},
             "calibration": cal, "by_kernel": by_kernel,
