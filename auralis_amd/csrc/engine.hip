@@ -27,6 +27,8 @@ namespace aur {
 
 static thread_local std::string g_last_error;
 
+constexpr int kProj2Slabs = 4;   // split-K slabs of the prompt-row MLP projection (forward_rows)
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -1248,9 +1250,11 @@ private:
             launch_rows_ln(P, 1, L.bproj, h, L.ln2w, L.ln2b, xn, M, 1e-5f, w.st);
             const GemmGelu ge{L.bfc, w.act.as<float>(), cfg_.gelu_erf ? 1 : 0};
             launch_gemm_tile(xn, kHidden, L.wfc, P, M, 4 * kHidden, kHidden, w.st, &ge, gemm_prec_);
-            launch_gemm_tile(w.act.as<float>(), 4 * kHidden, L.wproj2, P, M, kHidden, 4 * kHidden, w.st, nullptr, gemm_prec_);
+            // K = 4096 against N = 1024: four K-slabs (4x the workgroups of a GEMM that otherwise fills one round of CUs with
+            // 256 dependent k-steps); rows_ln sums them in a fixed order
+            launch_gemm_tile(w.act.as<float>(), 4 * kHidden, L.wproj2, P, M, kHidden, 4 * kHidden, w.st, nullptr, gemm_prec_, kProj2Slabs);
             const bool last = (l + 1 == cfg_.n_layer);
-            launch_rows_ln(P, 1, L.bproj2, h, last ? lnfw_ : layers_[l + 1].ln1w, last ? lnfb_ : layers_[l + 1].ln1b,
+            launch_rows_ln(P, kProj2Slabs, L.bproj2, h, last ? lnfw_ : layers_[l + 1].ln1w, last ? lnfb_ : layers_[l + 1].ln1b,
                            xn, M, 1e-5f, w.st);
         }
     }

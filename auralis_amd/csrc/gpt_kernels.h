@@ -96,8 +96,10 @@ void launch_final_rows(const float* h, int mtt, const int* sample_slot, const fl
 // in the same step (all prefill-type calls use this kernel, small M included).  N % 64 == 0, K % 16 == 0.
 // prec = 1: the decode GEMMs' three-way bf16 split arithmetic (gemm_tile_split_kernel, v_mfma_f32_32x32x16_bf16, the operands
 // split on their way into LDS) — same tiles, same k order per output element; prec = 0: exact-f32 MFMA.
+// slabs > 1: split-K, slab s = K / slabs consecutive k, written to P + s * M * N (the consumer sums the slabs in a fixed order,
+// rows_ln / qkv_epilogue's S); the slab count is a property of the call site, never of M, so results stay batch-invariant.
 void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, int N, int K, hipStream_t st,
-                      const GemmGelu* gelu = nullptr, int prec = 0);
+                      const GemmGelu* gelu = nullptr, int prec = 0, int slabs = 1);
 
 // h[m] += sum_s P[s][m] + bias (if S > 0); out[m] = LayerNorm(h[m]; gamma, beta, eps).  Rows of 1024.
 void launch_rows_ln(const float* P, int S, const float* bias, float* h, const float* gamma, const float* beta,

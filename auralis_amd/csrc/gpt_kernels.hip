@@ -65,6 +65,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(const float* __restri
         }
     }
     const int m0 = mtile * BM, n0 = ntile * BN;
+    // split-K slabs (grid.y): slab s multiplies columns [s*K, (s+1)*K) of X with the matching rows of W into P[s] (K = slab depth)
+    X += (long)blockIdx.y * K;
+    W += (long)blockIdx.y * K * N;
+    P += (long)blockIdx.y * M * N;
     // staging roles: A = float4 of 4 consecutive k for row tid/4 (+64), B = float4 of 4 columns for k row tid/(BN/4) (+256/(BN/4))
     constexpr int BT = BN / 4;                  // threads per B row
     const int a_row = tid >> 2, a_kq = tid & 3, b_kr = tid / BT, b_n4 = tid % BT;
@@ -191,6 +195,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
         }
     }
     const int m0 = mtile * BM, n0 = ntile * BN;
+    // split-K slabs (grid.y): slab s multiplies columns [s*K, (s+1)*K) of X with the matching rows of W into P[s] (K = slab depth)
+    X += (long)blockIdx.y * K;
+    W += (long)blockIdx.y * K * N;
+    P += (long)blockIdx.y * M * N;
     const int a_row = tid >> 2, a_kq = tid & 3;          // A: rows a_row (+64), k-quad a_kq
     const int b_n = tid % BN, b_kq = tid / BN;           // B: column b_n, k-quads b_kq (+ 256 / BN)
     const float* ap[LA];
@@ -291,8 +299,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
         }
 }
 
-void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, int N, int K, hipStream_t st,
-                      const GemmGelu* gelu, int prec) {
+void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, int N, int Kfull, hipStream_t st,
+                      const GemmGelu* gelu, int prec, int slabs) {
+    AUR_REQUIRE(slabs >= 1 && Kfull % slabs == 0 && (slabs == 1 || !gelu), "gemm_tile: slabs");
+    const int K = Kfull / slabs;
     AUR_REQUIRE(N % 64 == 0 && K % 16 == 0 && ldx % 4 == 0 && M >= 1, "gemm_tile: shape");
     trace_launch("gemm_tile_kernel");
     const GemmGelu none{nullptr, nullptr, 0};
@@ -302,12 +312,12 @@ void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, 
     // of every output element is the same for both shapes.
     const bool small = N <= 1024 || N % 128 != 0;
 #define AUR_GT(KERN, BM_, BN_, GE) \
-    hipLaunchKernelGGL((KERN<BM_, BN_, GE>), dim3((unsigned)((N / BN_) * ((M + BM_ - 1) / BM_))), dim3(256), 0, st, X, ldx, W, P, M, N, K, g)
+    hipLaunchKernelGGL((KERN<BM_, BN_, GE>), dim3((unsigned)((N / BN_) * ((M + BM_ - 1) / BM_)), (unsigned)slabs), dim3(256), 0, st, X, ldx, W, P, M, N, K, g)
     if (prec) {
         // split arithmetic, narrow GEMMs (N <= 1024): the largest tile that still gives every CU a workgroup -- 128 x 128 for a
         // 64-prompt prefill (288 workgroups, one round: 34.8 ms per prefill against 36.4 on 128 x 64 = 576 workgroups on 512
         // slots), 128 x 64 and 64 x 64 for smaller batches.  The k order of an output element is the same for every shape.
-        const long n128 = (long)(N / 128) * ((M + 127) / 128), n64 = (long)(N / 64) * ((M + 127) / 128);
+        const long n128 = (long)slabs * (N / 128) * ((M + 127) / 128), n64 = (long)slabs * (N / 64) * ((M + 127) / 128);
         if (!small || (N % 128 == 0 && n128 >= 200)) { if (gelu) AUR_GT(gemm_tile_split_kernel, 128, 128, true); else AUR_GT(gemm_tile_split_kernel, 128, 128, false); }
         else if (n64 >= 200) { if (gelu) AUR_GT(gemm_tile_split_kernel, 128, 64, true); else AUR_GT(gemm_tile_split_kernel, 128, 64, false); }
         else { if (gelu) AUR_GT(gemm_tile_split_kernel, 64, 64, true); else AUR_GT(gemm_tile_split_kernel, 64, 64, false); }
