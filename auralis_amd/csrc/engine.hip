@@ -27,6 +27,7 @@ namespace aur {
 
 static thread_local std::string g_last_error;
 
+constexpr int kProfileEvery = 64;   // profile mode: every 64th decode step carries HIP-event pairs around each launch (4.7 us per pair)
 constexpr int kProj2Slabs = 4;   // split-K slabs of the prompt-row MLP projection (forward_rows)
 
 struct DevBuf {
@@ -1116,7 +1117,7 @@ private:
         w.i_desc.ensure((size_t)cap * sizeof(int4));
         w.rows_cap = cap;
     }
-    // decode-regime GEMM launch (gemm_rows_kernel); profile mode: HIP-event pairs around the launches of every 16th decode
+    // decode-regime GEMM launch (gemm_rows_kernel); profile mode: HIP-event pairs around the launches of every 64th decode
     // step.  Algorithmic bytes of a launch:
     // weights once + the activation rows once + the output tile once (the residual epilogue reads and writes it).
     ConvEvent& prof_event(int kind, double flops, double bytes) {
@@ -1503,7 +1504,7 @@ private:
         f.slots = active;
         f.buf = rb_next_;
         rb_next_ ^= 1;
-        f.profiled = cfg_.profile != 0 && (decode_step_count_++ % 16 == 0);
+        f.profiled = cfg_.profile != 0 && (decode_step_count_++ % kProfileEvery == 0);
         pin_rb_[f.buf].ensure(((size_t)cfg_.max_seqs * 2 + 16) * sizeof(int));
         // algorithmic bytes of this step: every live sequence's context (prompt + tokens so far, + 1 if the previous step is
         // still in flight) in K and V, all layers; the weights once

@@ -110,7 +110,7 @@ typedef struct aur_stats {
     double conv_ms;
     double conv_flops;             /* algorithmic FLOPs of those launches */
     double conv_bytes;             /* algorithmic (layer-granular) HBM bytes of those launches */
-    int64_t gemm_launches;         /* profile == 1: decode GEMM launches sampled (every 16th decode step) */
+    int64_t gemm_launches;         /* profile == 1: decode GEMM launches sampled (every 64th decode step) */
     double gemm_ms;                /* event time minus the fixed event-pair overhead below */
     double gemm_ms_raw;
     double event_pair_overhead_ms;
