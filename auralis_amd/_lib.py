@@ -278,33 +278,42 @@ class NativeEngine:
         self._check(self.lib.aur_step(self.h, C.byref(live), C.byref(fin)))
         return live.value, fin.value
 
-    def poll(self, cap: int = 64, want_latents: bool = True) -> List[dict]:
+    def poll(self, cap: int = 64, want_latents: bool = True, copy: bool = True) -> List[dict]:
+        """Finished sequences.  copy=True: owned numpy arrays, the engine's result block is released at once.  copy=False: the
+        arrays are VIEWS of the engine's pinned result block (aur_result.wav / .tokens / .latents, valid until release(seq_id));
+        the caller releases each sequence when it is done with the view."""
         res = (aur_result * cap)()
         n = C.c_size_t()
         self._check(self.lib.aur_poll_finished(self.h, res, cap, C.byref(n)))
+        own = (lambda a: a.copy()) if copy else (lambda a: a)
         out = []
         for i in range(n.value):
             r = res[i]
             item = {
                 "seq_id": r.seq_id,
-                "tokens": (np.ctypeslib.as_array(r.tokens, shape=(r.n_tokens,)).copy() if r.n_tokens
+                "tokens": (own(np.ctypeslib.as_array(r.tokens, shape=(r.n_tokens,))) if r.n_tokens
                            else np.zeros(0, dtype=np.int32)),
-                "wav": (np.ctypeslib.as_array(r.wav, shape=(r.n_samples,)).copy() if r.n_samples
+                "wav": (own(np.ctypeslib.as_array(r.wav, shape=(r.n_samples,))) if r.n_samples
                         else np.zeros(0, dtype=np.float32)),   # failed sequences carry no audio (error != 0)
                 "error": r.error,
             }
             if want_latents and r.n_latent_rows:
-                item["latents"] = np.ctypeslib.as_array(r.latents, shape=(r.n_latent_rows, 1024)).copy()
-            self._check(self.lib.aur_release(self.h, r.seq_id))
+                item["latents"] = own(np.ctypeslib.as_array(r.latents, shape=(r.n_latent_rows, 1024)))
+            if copy:
+                self._check(self.lib.aur_release(self.h, r.seq_id))
             out.append(item)
         return out
 
-    def run_until_done(self, max_steps: int = 100000) -> List[dict]:
-        """Drive aur_step until nothing is live; returns finished results in completion order."""
+    def release(self, seq_id: int):
+        """Give a sequence's result block back (after poll(copy=False))."""
+        self._check(self.lib.aur_release(self.h, seq_id))
+
+    def run_until_done(self, max_steps: int = 100000, copy: bool = True) -> List[dict]:
+        """Drive aur_step until nothing is live; returns finished results in completion order (copy: see poll)."""
         done: List[dict] = []
         for _ in range(max_steps):
             live, _fin = self.step()
-            done.extend(self.poll())
+            done.extend(self.poll(copy=copy))
             if live == 0:
                 break
         else:

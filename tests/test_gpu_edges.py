@@ -312,3 +312,25 @@ def test_in_library_rccl_communicator_and_broadcast_world1(dims):
         assert after["tokens"].tolist() == before["tokens"].tolist() and np.array_equal(after["wav"], before["wav"])
     finally:
         e.close()
+
+
+def test_poll_views_of_the_result_block_equal_owned_copies(ctx, dims):
+    """poll(copy=False) hands out views of the engine's pinned result block (aur_result.wav / .tokens), valid until
+    release(seq_id); they hold what poll(copy=True) copies, and the blocks are reusable after the release."""
+    e = ctx[0]
+    ids = make_synthetic_text_ids(dims, n_text=12, seed=21)
+
+    def run(copy):
+        for k in range(3):
+            e.submit(ids, SPK_KEY, max_tokens=6 + k, temperature=0.0)
+        return sorted(e.run_until_done(copy=copy), key=lambda o: len(o["tokens"]))
+
+    owned = run(True)
+    for _ in range(2):   # twice: the second pass reuses the blocks released after the first
+        views = run(False)
+        assert len(views) == len(owned) == 3
+        for v, o in zip(views, owned):
+            assert v["error"] == 0 and not v["wav"].flags["OWNDATA"]
+            assert np.array_equal(v["tokens"], o["tokens"]) and np.array_equal(v["wav"], o["wav"])
+        for v in views:
+            e.release(v["seq_id"])
