@@ -311,9 +311,12 @@ class NativeEngine:
     def run_until_done(self, max_steps: int = 100000, copy: bool = True) -> List[dict]:
         """Drive aur_step until nothing is live; returns finished results in completion order (copy: see poll)."""
         done: List[dict] = []
+        last_fin = -1
         for _ in range(max_steps):
-            live, _fin = self.step()
-            done.extend(self.poll(copy=copy))
+            live, fin = self.step()
+            if fin != last_fin or live == 0:   # aur_step's second output counts finished sequences: poll only when it moved
+                done.extend(self.poll(copy=copy))
+                last_fin = fin
             if live == 0:
                 break
         else:
