@@ -759,11 +759,11 @@ static void launch_conv_dma(const ConvArgs& a, hipStream_t st) {
 // chunk g).  Row halves are swapped when bit 3 of the row index is set (as conv1d_dma_f16_kernel) in all three images.
 __device__ __forceinline__ int swz16(int row, int half) { return 16 * (half ^ ((row >> 3) & 1)); }
 
-template <int KS, int DIL, int C, int WN>
-__global__ __launch_bounds__(64 * (C / 32) * (8 / WN)) void resblock_round_f16_kernel(RoundArgs a) {
-    constexpr int NCH = C / 16, NWN = 8 / WN, NW = (C / 32) * NWN, PW = 32 * WN;   // NWN waves along the positions, PW positions each
+template <int KS, int DIL, int C, int WN, int NT1>
+__global__ __launch_bounds__(64 * (C / 32) * (NT1 / 32 / WN)) void resblock_round_f16_kernel(RoundArgs a) {
+    constexpr int NCH = C / 16, NWN = NT1 / 32 / WN, NW = (C / 32) * NWN, PW = 32 * WN;   // NWN waves along the positions, PW positions each
     constexpr int P1 = (KS - 1) / 2 * DIL, P2 = (KS - 1) / 2;
-    constexpr int NT1 = 256, NT2 = NT1 - (KS - 1);
+    constexpr int NT2 = NT1 - (KS - 1);   // NT1 conv1 positions per tile -> NT2 outputs
     constexpr int XROW = (NT1 + (KS - 1) * DIL + 31) / 32 * 32;   // window rows per chunk, whole 1-KiB copies
     constexpr int HROW = (NT1 + (KS - 1) + 31) / 32 * 32;
     constexpr int WCH = KS * C * 32;                               // bytes of one weight chunk
@@ -922,13 +922,19 @@ __global__ __launch_bounds__(64 * (C / 32) * (8 / WN)) void resblock_round_f16_k
 
 template <int KS, int DIL>
 static void launch_round_c(const RoundArgs& a, hipStream_t st) {
-    const int nt2 = 256 - (KS - 1);
-    const dim3 grid((a.max_len + nt2 - 1) / nt2, a.B);
     trace_launch("resblock_round_f16_kernel");
-    // positions per wave: 64 (8 waves) at 64 channels, 32 (8 waves) at 32 channels -- 9.6 vs 10.1 ms for the 32-channel stage,
-    // no difference at 64 channels (16 waves: 16.2 vs 16.4)
-    if (a.C == 64) hipLaunchKernelGGL((resblock_round_f16_kernel<KS, DIL, 64, 2>), grid, dim3(512), 0, st, a);
-    else if (a.C == 32) hipLaunchKernelGGL((resblock_round_f16_kernel<KS, DIL, 32, 1>), grid, dim3(512), 0, st, a);
+    // 64 channels, k = 3 / 7: 128-position tiles (8 waves of 32 channels x 32 positions, <= 69 KB of LDS) so that two workgroups
+    // share a CU -- 15.6 vs 16.4 ms for the stage; k = 11 needs 120 KB either way and keeps 256 positions (64 per wave).
+    // 32 channels: 256 positions, 32 per wave (9.6 vs 10.1 ms with 64 per wave).
+    if (a.C == 64 && KS < 11) {
+        constexpr int nt2 = 128 - (KS - 1);
+        hipLaunchKernelGGL((resblock_round_f16_kernel<KS, DIL, 64, 1, 128>), dim3((a.max_len + nt2 - 1) / nt2, a.B), dim3(512), 0, st, a);
+        return;
+    }
+    constexpr int nt2 = 256 - (KS - 1);
+    const dim3 grid((a.max_len + nt2 - 1) / nt2, a.B);
+    if (a.C == 64) hipLaunchKernelGGL((resblock_round_f16_kernel<KS, DIL, 64, 2, 256>), grid, dim3(512), 0, st, a);
+    else if (a.C == 32) hipLaunchKernelGGL((resblock_round_f16_kernel<KS, DIL, 32, 1, 256>), grid, dim3(512), 0, st, a);
     else throw InvalidArgument("resblock round: 64 or 32 channels");
 }
 
