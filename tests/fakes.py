@@ -61,9 +61,12 @@ class FakeNativeEngine:
                 self.done.append({"seq_id": s["seq_id"], "tokens": np.arange(n, dtype=np.int32), "wav": wav, "error": 0})
         return len(self.waiting) + len(self.running), 0
 
-    def poll(self, cap=64, want_latents=True):
+    def poll(self, cap=64, want_latents=True, copy=True):
         out, self.done = self.done, []
         return out
+
+    def release(self, seq_id):   # (poll(copy=False) contract of NativeEngine; the fake's arrays are always owned)
+        pass
 
     def stats(self):
         return {"kv_blocks_total": 0}
