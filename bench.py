@@ -219,6 +219,12 @@ def build_report(args, st, dims, world, samples, dt, audio_s):
                      st["gemm_ms_raw"], st["gemm_launches"], st["gemm_bytes"], st["gemm_flops"], gemm_peak, r"gemm_rows_kernel<", None,
                      "per-launch average over the five GEMM kinds weighted by their launch counts; per-kind entries in "
                      "decode_gemm_kernels; HIP-event durations (fixed cost of an event pair NOT subtracted here)")
+    # PMC traffic of the family: the per-kind figures (profiles/hbm_traffic.json) weighted by the launches timed in this run
+    tl = [(g["traffic"], g["launches_timed"]) for g in gemms if g.get("traffic") and g.get("launches_timed")]
+    if tl and sum(n for _, n in tl) == roof_gemm["launches_timed"]:
+        roof_gemm["traffic"] = sum(t * n for t, n in tl) / sum(n for _, n in tl)
+        roof_gemm["traffic_source"] = {"file": "profiles/hbm_traffic.json[r03_decode]", "note": "launch-weighted mean of the five GEMM kinds' "
+                                       "measured-to-algorithmic ratios applied to this run's algorithmic bytes"}
     n_dec = max(1, st["decode_steps"])
     per_layer = sum(g["avg_launch_ms"] for g in gemms[:4]) * 1e3
     roof_gemm["four_gemms_per_layer_us"] = {"events": per_layer,
@@ -227,7 +233,7 @@ def build_report(args, st, dims, world, samples, dt, audio_s):
     est = {"paged_attention_kernel": roof_attn["avg_launch_ms"] * args.layers * n_dec,
            conv_kernel: st["conv_ms"],
            "gemm_rows_kernel": (per_layer * 1e-3 * args.layers + gemms[4]["avg_launch_ms"]) * n_dec,
-           "gemm_tile_kernel (prefill, upper bound: whole prefill phase)": st["prefill_ms"]}
+           "gemm_tile_split_kernel / gemm_tile_kernel (prefill, upper bound: whole prefill phase)": st["prefill_ms"]}
     by_family = {"paged_attention_kernel": roof_attn, conv_kernel: roof_conv, "gemm_rows_kernel": roof_gemm}
     order = sorted(by_family, key=lambda k: -est[k])
     top = order[0]
@@ -273,7 +279,7 @@ def build_report(args, st, dims, world, samples, dt, audio_s):
         "metric": "audio_samples_per_s (64-way batch; rtf = wall_s / audio_s alongside)",
         "value": samples / dt, "unit": "audio-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32 (GPT: storage, softmax, LayerNorm, sampler; decode GEMMs "
+        "dtype": ("f32 (GPT: storage, softmax, LayerNorm, sampler; decode and prompt GEMMs "
                   + ("on exact-f32 MFMA" if args.gemm == "f32" else "as exact 3-way bf16 splits of the f32 operands, f32 accumulate") + ")")
                  + ("" if args.vocoder == "fp32" else " + f16-in/f32-acc MFMA (vocoder convs)")
                  + (" + f16 K/V pool (throughput mode, not the parity configuration)" if args.kv == "fp16" else ""), "data": "synthetic",
