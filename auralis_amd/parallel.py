@@ -51,8 +51,16 @@ def broadcast_conditioning_native(engine, speaker_key: int, gpt_cond_latent: Opt
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
     if not getattr(engine, "_comm_ready", False):
-        ids = [type(engine).comm_unique_id() if rank == 0 else None]
+        uid = None
+        if rank == 0:   # a failure to create the id must not leave the other ranks waiting in the broadcast below
+            try:
+                uid = type(engine).comm_unique_id()
+            except Exception as ex:   # noqa: BLE001 - re-raised on every rank
+                uid = ex
+        ids = [uid]
         dist.broadcast_object_list(ids, src=0)
+        if isinstance(ids[0], Exception):
+            raise RuntimeError(f"rank 0 could not create the RCCL communicator id: {ids[0]}")
         engine.comm_init(ids[0], rank, world)
         engine._comm_ready = True
     if rank == src:
