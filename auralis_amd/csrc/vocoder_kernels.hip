@@ -752,8 +752,8 @@ static void launch_conv_dma(const ConvArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused ResBlock round (vocoder_kernels.h, RoundArgs).  Workgroup = C/32 x 8/WN waves, each wave a 32-channel x 32*WN-position block
-// of a [C] x [256] conv1 tile; conv2 then yields NT2 = 256 - (KS - 1) output positions of it.  LDS: the input window of ALL C
+// Fused ResBlock round (vocoder_kernels.h, RoundArgs).  Workgroup = C/32 x NT1/(32*WN) waves, each wave a 32-channel x
+// 32*WN-position block of a [C] x [NT1] conv1 tile; conv2 then yields NT2 = NT1 - (KS - 1) output positions of it.  LDS: the input window of ALL C
 // channels (staged once, by LDS-DMA, also the source of the residual), the conv1 result h as [chunk][position][16] rows, and two
 // weight-chunk buffers through which the 2 * C/16 weight chunks of conv1 then conv2 stream (DMA of chunk g + 1 under the MFMAs of
 // chunk g).  Row halves are swapped when bit 3 of the row index is set (as conv1d_dma_f16_kernel) in all three images.
