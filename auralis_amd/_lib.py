@@ -79,7 +79,7 @@ EXPORTS = [
     "aur_set_conditioning", "aur_set_conditioning_device", "aur_has_conditioning", "aur_compute_conditioning", "aur_comm_unique_id", "aur_comm_init", "aur_broadcast_conditioning",
     "aur_comm_info", "aur_conditioning_checksum",
     "aur_submit", "aur_step", "aur_poll_finished",
-    "aur_release", "aur_vocode", "aur_sync", "aur_get_stats", "aur_reset_stats", "aur_dbg_gemm", "aur_dbg_gemm_rows",
+    "aur_release", "aur_vocode", "aur_sync", "aur_get_stats", "aur_reset_stats", "aur_set_profile", "aur_dbg_gemm", "aur_dbg_gemm_rows",
     "aur_dbg_layernorm", "aur_dbg_conv1d", "aur_dbg_conv1d_f16", "aur_dbg_prefill", "aur_dbg_sample",
 ]
 
@@ -126,6 +126,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "aur_sync": [eng],
         "aur_get_stats": [eng, C.POINTER(aur_stats)],
         "aur_reset_stats": [eng],
+        "aur_set_profile": [eng, C.c_int32],
         "aur_dbg_gemm": [eng, fp, fp, fp, C.c_int32, C.c_int32, C.c_int32],
         "aur_dbg_gemm_rows": [eng, fp, fp, fp, fp, fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32],
         "aur_dbg_layernorm": [eng, fp, fp, fp, fp, C.c_int32],
@@ -315,7 +316,11 @@ class NativeEngine:
         for _ in range(max_steps):
             live, fin = self.step()
             if fin != last_fin or live == 0:   # aur_step's second output counts finished sequences: poll only when it moved
-                done.extend(self.poll(copy=copy))
+                while True:                    # a vocoder batch (or a failed step) can finish more than one poll's worth at once
+                    got = self.poll(cap=64, copy=copy)
+                    done.extend(got)
+                    if len(got) < 64:
+                        break
                 last_fin = fin
             if live == 0:
                 break
@@ -345,6 +350,10 @@ class NativeEngine:
 
     def reset_stats(self):
         self._check(self.lib.aur_reset_stats(self.h))
+
+    def set_profile(self, every: int):
+        """Profile mode on (every > 0: conv launches event-timed, replay batches after every `every`-th decode step) / off (0)."""
+        self._check(self.lib.aur_set_profile(self.h, int(every)))
 
     # -- per-kernel debug entry points -------------------------------------------------------------------
     def dbg_gemm(self, X, W) -> np.ndarray:

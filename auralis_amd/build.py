@@ -45,7 +45,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     exactly these sources.  Prints which of the two happened.  Returns the library's path."""
     want = source_hash()
     if not force and not _stale(want):
-        print(f"[auralis_amd.build] reused {os.path.relpath(LIB, os.path.dirname(HERE))} (source hash {want[:16]})", flush=True)
+        print(f"[auralis_amd.build] reused {os.path.relpath(LIB, os.path.dirname(HERE))} (source hash {want[:16]})", file=sys.stderr, flush=True)
         return LIB
     os.makedirs(OUT_DIR, exist_ok=True)
 
@@ -68,7 +68,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with open(HASH_FILE, "w") as f:
         f.write(want + "\n")
     print(f"[auralis_amd.build] compiled {len(SOURCES)} translation units with hipcc for gfx950 -> "
-          f"{os.path.relpath(LIB, os.path.dirname(HERE))} (source hash {want[:16]})", flush=True)
+          f"{os.path.relpath(LIB, os.path.dirname(HERE))} (source hash {want[:16]})", file=sys.stderr, flush=True)
     return LIB
 
 

@@ -39,7 +39,7 @@ typedef struct aur_config {
     int32_t max_prefill_rows; /* cap on prompt rows prefetched in one step (0 = default 8192) */
     int32_t max_speakers;     /* speaker-conditioning table entries (0 = default 64) */
     int32_t vocoder_min_batch;/* hold finished sequences until this many are ready (0/1 = vocode at once) */
-    int32_t profile;          /* 1 = record HIP events around the vocoder conv launches (aur_stats) */
+    int32_t profile;          /* 1 = profile mode from the start (see aur_set_profile; every 64th decode step) */
     int32_t vocoder_fp16;     /* 1 = HiFi-GAN convs on fp16-input / fp32-accumulate MFMA (needs the voc16.* tensors);
                                  0 = exact-f32 MFMA parity mode */
     int32_t second_pass;      /* 1 = A/B mode: recompute the latents with the reference's literal second GPT pass
@@ -51,10 +51,11 @@ typedef struct aur_config {
                                  and P.V stay fp32), which halves the bytes the decode attention streams.  NOT the parity mode:
                                  greedy ids can differ from the fp32 reference after a near-tie (measured rate: DESIGN.md §4).
                                  0 (default) = fp32 K/V, bit-exact contract */
-    int32_t gemm_f32_exact;   /* decode-regime GEMMs (one token per live sequence): 0 (default) = every fp32 operand is split exactly
-                                 into three bf16 terms and a product runs as six bf16 MFMAs with fp32 accumulation (the accuracy of
-                                 an fp32 dot product at 2.7x less matrix-pipe time); 1 = v_mfma_f32_16x16x4_f32, bitwise an fp32
-                                 fma chain.  Prompt rows always run on exact-f32 MFMA */
+    int32_t gemm_f32_exact;   /* arithmetic of BOTH GEMM regimes (decode rows: gemm_rows_kernel; prompt rows: gemm_tile_split_kernel /
+                                 gemm_tile_kernel): 0 (default) = every fp32 operand is split exactly into three bf16 terms and a product
+                                 runs as six bf16 MFMAs with fp32 accumulation (the accuracy of an fp32 dot product at 2.7x less
+                                 matrix-pipe time); 1 = v_mfma_f32_*_f32, bitwise an fp32 fma chain.  The speaker-conditioning networks
+                                 always use the exact-f32 kernels */
     int32_t gelu_erf;         /* MLP activation: 0 = tanh form ("gelu_new", what checkpoint_converter.py:197 writes), 1 = erf form
                                  ("gelu", the XTTSGPTConfig class default, xttsv2_gpt_config.py:184); from the checkpoint's
                                  gpt/config.json "activation_function" */
@@ -110,19 +111,21 @@ typedef struct aur_stats {
     double conv_ms;
     double conv_flops;             /* algorithmic FLOPs of those launches */
     double conv_bytes;             /* algorithmic (layer-granular) HBM bytes of those launches */
-    int64_t gemm_launches;         /* profile == 1: decode GEMM launches sampled (every 64th decode step) */
-    double gemm_ms;                /* event time minus the fixed event-pair overhead below */
-    double gemm_ms_raw;
-    double event_pair_overhead_ms;
+    int64_t gemm_launches;         /* profile mode: decode GEMM launches timed in the replay batches (aur_set_profile) */
+    double gemm_ms;                /* event time of the batches minus one event-pair overhead per batch */
+    double gemm_ms_raw;            /* event time of the batches */
+    double event_pair_overhead_ms; /* measured cost of one empty HIP-event pair */
     double gemm_flops;
     double gemm_bytes;             /* algorithmic: weights once + activations + slabs */
     double vocoder_ms;             /* whole vocoder batches (interp .. conv_post), event-timed */
     double gpt_ms;                 /* prefill + decode + sampling, event-timed per step */
     int64_t kv_blocks_total;
     int64_t kv_blocks_free;
-    /* profile == 1, same sampled decode steps as gemm_*: per-kernel splits.  GEMM kinds: 0 qkv, 1 attn proj, 2 fc, 3 mlp proj,
-     * 4 mel head.  Times are raw HIP-event intervals on the launch stream; bytes are ALGORITHMIC (weights + activations in
-     * + activations out, fp32 as stored; attention: K and V rows of every live sequence's whole context + q + out). */
+    /* profile mode, per-kernel splits.  GEMM kinds: 0 qkv, 1 attn proj, 2 fc, 3 mlp proj, 4 mel head.  After a profiled decode
+     * step its launches are replayed kind by kind, the n_layer launches of one kind back to back between ONE HIP-event pair
+     * (outputs redirected to scratch): *_ms are those intervals, *_launches the launches inside them.  Bytes are ALGORITHMIC
+     * (weights + activations in + activations out, fp32 as stored; attention: K and V rows of every live sequence's whole
+     * context + q + out). */
     int64_t gemm_kind_launches[5];
     double gemm_kind_ms[5];
     double gemm_kind_bytes[5];
@@ -218,10 +221,14 @@ int aur_vocode(aur_engine* e, const float* latents, const int32_t* n_lat, int32_
 int aur_sync(aur_engine* e);
 int aur_get_stats(aur_engine* e, aur_stats* out);
 int aur_reset_stats(aur_engine* e);
+/* Profile mode at run time (new surface; the reference has no counterpart): every > 0 -- HIP events around every vocoder conv
+ * launch, and after every `every`-th decode step the per-kind replay batches described at aur_stats.gemm_kind_*; 0 = off (the
+ * configuration the parity tests run).  Results of the sequences are the same either way. */
+int aur_set_profile(aur_engine* e, int32_t every);
 
 /* ---- per-kernel entry points used by the parity tests (host pointers) ------------------------------- */
-/* Prefill-regime GEMM (gemm_tile_kernel, exact-f32 MFMA, the kernel every prompt-row linear of vLLM's GPT2Block runs on
- * here, vllm_mm_gpt.py:757-761 at M = prompt rows): out[M][N] = X[M][K] @ W[K][N]. */
+/* Prefill-regime GEMM (gemm_tile_split_kernel, or gemm_tile_kernel under aur_config.gemm_f32_exact: the kernel every prompt-row
+ * linear of vLLM's GPT2Block runs on here, vllm_mm_gpt.py:757-761 at M = prompt rows): out[M][N] = X[M][K] @ W[K][N]. */
 int aur_dbg_gemm(aur_engine* e, const float* X, const float* W, float* out, int32_t M, int32_t N, int32_t K);
 /* Decode-regime GEMM (gemm_rows_kernel: full-K workgroups, fused LayerNorm prologue and bias / gelu / residual epilogue;
  * replaces one GPT2Block linear of vLLM's GPT2Attention / GPT2MLP at M = live sequences, vllm_mm_gpt.py:757-761):
