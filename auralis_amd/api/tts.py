@@ -125,15 +125,20 @@ class TTS:
                 self._submit(agen.aclose()).result()
         return streaming_wrapper()
 
-    async def shutdown(self):
+    async def shutdown(self, keep_engine: bool = False):
         if self.scheduler:
             await self.scheduler.shutdown()
         if self.tts_engine:
-            await self.tts_engine.shutdown()
+            if keep_engine:   # stop the plugin's driver thread, leave the native engine to its owner (with_engine callers)
+                drv = getattr(self.tts_engine, "driver", None)
+                if drv is not None:
+                    drv.shutdown()
+            else:
+                await self.tts_engine.shutdown()
 
-    def close(self):
+    def close(self, keep_engine: bool = False):
         try:
-            self._submit(self.shutdown()).result(timeout=10)
+            self._submit(self.shutdown(keep_engine)).result(timeout=10)
         finally:
             self._loop.call_soon_threadsafe(self._loop.stop)
             self._thread.join(timeout=5)

@@ -69,9 +69,11 @@ struct GemmRowsArgs {
     long long* prof;     // optional (tools/gemm_bench): 8 wall_clock64 stamps (100 MHz, device-wide) per workgroup, written by wave 0
 };
 void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream_t st);
-// Workgroup shape the launcher picks for a GEMM kind at M rows: 16*mt rows x 16*ntl columns, nw waves (K split nw ways).
+// Workgroup shape the launcher picks for a GEMM kind at M rows: 16*mt rows x 16*ntl columns, nw waves (K split nw ways);
+// nt: non-temporal weight loads (M <= 16: every weight tile has one reader).
 struct GemmRowsShape {
     int mt, nw, ntl;
+    bool nt;
 };
 GemmRowsShape gemm_rows_shape(int M, int N, int K, bool ln);
 

@@ -420,8 +420,10 @@ __device__ __forceinline__ void split3_bf16(const f32x4& x0, const f32x4& x1, bf
     }
 }
 
-// DBG (tools/gemm_bench only): bit 0 = no weight loads, bit 1 = no activation loads, bit 2 = no MFMAs
-template <int MT, int KCH, bool LN, int EPI, int NW, int NTL = 1, int PREC = 0, int DBG = 0>
+// NT: the packed weight tiles are requested with the non-temporal policy.  For M <= 16 rows a tile is read by exactly one
+// workgroup (one row group): streamed weights that nobody re-reads should not displace the activations in L2.  (At M = 64 the
+// four row groups of a column tile share its weights through L2 and NT measured neutral, profiles/r03_gemm_nt_weights.log.)
+template <int MT, int KCH, bool LN, int EPI, int NW, int NTL = 1, int PREC = 0, bool NT = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, NW == 16 ? 4 : (NW == 8 ? 6 : 8))))
 void gemm_rows_kernel(GemmRowsArgs a) {
     // (amdgpu_waves_per_eu: without the cap hipcc schedules for 8 waves per SIMD — 64 VGPRs — and gets there by issuing the tile
@@ -467,14 +469,11 @@ void gemm_rows_kernel(GemmRowsArgs a) {
         for (int b = 0; b < NB; ++b) {
 #pragma unroll
             for (int t = 0; t < NTL; ++t) {
-                if (DBG & 1) bf[buf][t][b] = f32x4{0.01f * lane, 0.02f, 0.03f, 0.01f * (kb0 + b)};
+                if constexpr (NT) bf[buf][t][b] = __builtin_nontemporal_load(&wt[t * wt_tile + (long)(kb0 + b) * 64]);
                 else bf[buf][t][b] = wt[t * wt_tile + (long)(kb0 + b) * 64];
             }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (DBG & 2) af[buf][mt][b] = f32x4{0.01f * lane, 0.02f, 0.03f, 0.01f * (kb0 + b)};
-                else af[buf][mt][b] = xp[((long)(kb0 + b) * a.xmt + mt) * 64];
-            }
+            for (int mt = 0; mt < MT; ++mt) af[buf][mt][b] = xp[((long)(kb0 + b) * a.xmt + mt) * 64];
             if (PREC == 0 || (b & 1)) __builtin_amdgcn_sched_barrier(0);   // (hipcc reorders the loads among themselves otherwise)
         }
         // nothing below may move above this line and no load above may sink below it (hipcc otherwise sinks the tile loads
@@ -536,12 +535,7 @@ void gemm_rows_kernel(GemmRowsArgs a) {
         if (!LN) __builtin_amdgcn_sched_barrier(0);   // the next chunks' loads are issued before this chunk's MFMAs
 #pragma unroll
         for (int b = 0; b < NB; b += (PREC ? 2 : 1)) {
-            if constexpr ((DBG & 4) != 0) {
-#pragma unroll
-                for (int t = 0; t < NTL; ++t)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt][t] += af[cur][mt][b] * bf[cur][t][b];
-            } else if constexpr (PREC == 0) {
+            if constexpr (PREC == 0) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -646,9 +640,10 @@ void gemm_rows_kernel(GemmRowsArgs a) {
     if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 5] = (long long)wall_clock64();
 }
 
-// Workgroup shapes in use (tools/gemm_bench measures every one of them per GEMM kind).  16 waves, K-slice 64 per wave, is the
-// default; 8 waves (K-slices of 128) remain for A/B.  K = 4096 needs two chunk buffers: at most 32 rows per workgroup.
-template <int KCH, bool LN, int EPI, int PREC, int DBG = 0>
+// Workgroup shapes.  16 waves, K-slice 64 per wave, is what the engine uses; tools/gemm_bench.hip defines AUR_GEMM_ALL_SHAPES and
+// also gets the A/B shapes (8 waves = K-slices of 128, wider tiles).  K = 4096 needs two chunk buffers: at most 32 rows per
+// workgroup.
+template <int KCH, bool LN, int EPI, int PREC, bool NT = false>
 static void launch_gemm_rows_mt(const GemmRowsArgs& a, int mt, int nw, hipStream_t st, int ntl = 1) {
     const int n_tiles = a.N / (16 * ntl);
     const int n_grp = (a.M + 16 * mt - 1) / (16 * mt);
@@ -656,20 +651,30 @@ static void launch_gemm_rows_mt(const GemmRowsArgs& a, int mt, int nw, hipStream
     AUR_REQUIRE(a.N % (16 * ntl) == 0, "gemm_rows: N is not a multiple of the workgroup's column tile");
 #define AUR_GR(MT_, NW_, NTL_)                                                                                     \
     if (mt == MT_ && nw == NW_ && ntl == NTL_) {                                                                   \
-        hipLaunchKernelGGL((gemm_rows_kernel<MT_, KCH, LN, EPI, NW_, NTL_, PREC, DBG>), grid, dim3(64 * NW_), 0, st, a); \
+        hipLaunchKernelGGL((gemm_rows_kernel<MT_, KCH, LN, EPI, NW_, NTL_, PREC, NT>), grid, dim3(64 * NW_), 0, st, a); \
         return;                                                                                                    \
     }
     AUR_GR(1, 16, 1)
-    AUR_GR(2, 16, 1)
-    if constexpr (KCH == 1) {
-        AUR_GR(4, 16, 1)
-        AUR_GR(1, 16, 2)
-        AUR_GR(1, 16, 3)
-        AUR_GR(1, 16, 4)
-        AUR_GR(2, 16, 2)
-        AUR_GR(1, 8, 1)
-        AUR_GR(2, 8, 1)
-        AUR_GR(1, 8, 2)
+    if constexpr (!NT) {
+        if constexpr (KCH == 1 && LN) {
+            AUR_GR(1, 16, 3)
+            AUR_GR(2, 16, 2)
+        }
+#ifdef AUR_GEMM_ALL_SHAPES
+        AUR_GR(2, 16, 1)
+        if constexpr (KCH == 1) {
+            AUR_GR(4, 16, 1)
+            AUR_GR(1, 16, 2)
+            AUR_GR(1, 16, 4)
+            if constexpr (!LN) {
+                AUR_GR(1, 16, 3)
+                AUR_GR(2, 16, 2)
+            }
+            AUR_GR(1, 8, 1)
+            AUR_GR(2, 8, 1)
+            AUR_GR(1, 8, 2)
+        }
+#endif
     }
 #undef AUR_GR
     throw InvalidArgument("gemm_rows: no kernel for this (rows, waves, column tiles) workgroup shape");
@@ -677,34 +682,39 @@ static void launch_gemm_rows_mt(const GemmRowsArgs& a, int mt, int nw, hipStream
 
 // Shape policy.  The waves per workgroup fix the K grouping of the reduction, so they depend on the GEMM kind only (16
 // everywhere), never on M: a row's result must not change with the number of live rows.  Rows x columns per workgroup do not
-// enter the arithmetic.  One workgroup per CU when the launch is large enough for it (256 CUs):
+// enter the arithmetic (the K order of an output element is the same for every tile shape: bitwise equal).
+// M > 16 — one workgroup per CU when the launch is large enough for it (256 CUs):
 //   LN GEMMs, N = 3072 (QKV): 16 rows x 48 columns  -> 64 x ceil(M/16) workgroups (256 at M = 64); the CU pulls its 16
 //       activation rows once for three column tiles
 //   LN GEMMs, N = 4096 (FC) : 32 rows x 32 columns  -> 128 x ceil(M/32)
 //   N = 1024 (proj, proj2), head: 16 rows x 16 columns
+// M <= 16 (one row group; a single utterance is M = 1) — the launch is pure weight streaming and every weight tile has exactly one
+//   reader: 16 x 16 tiles everywhere (QKV 192, FC 256 workgroups instead of 64 / 128) with non-temporal weight loads.
 GemmRowsShape gemm_rows_shape(int M, int N, int K, bool ln) {
-    GemmRowsShape s{1, 16, 1};
-    if (ln) {
+    GemmRowsShape s{1, 16, 1, false};
+    if (M <= 16) {
+        s.nt = true;
+    } else if (ln) {
         if (N % 48 == 0 && N < 4096) {
             s.ntl = 3;
         } else if (N % 32 == 0) {
             s.ntl = 2;
-            s.mt = M > 16 ? 2 : 1;
+            s.mt = 2;
         }
     }
     (void)K;
     return s;
 }
 
-template <int PREC>
+template <int PREC, bool NT>
 static void launch_gemm_rows_prec(const GemmRowsArgs& b, bool ln, GemmRowsEpi epi, const GemmRowsShape& s, hipStream_t st) {
-    if (ln && epi == kEpiQkv) launch_gemm_rows_mt<1, true, kEpiQkv, PREC>(b, s.mt, s.nw, st, s.ntl);
-    else if (ln && epi == kEpiBiasGelu) launch_gemm_rows_mt<1, true, kEpiBiasGelu, PREC>(b, s.mt, s.nw, st, s.ntl);
-    else if (ln && epi == kEpiBias) launch_gemm_rows_mt<1, true, kEpiBias, PREC>(b, s.mt, s.nw, st, s.ntl);
-    else if (!ln && epi == kEpiResidual && b.K == 1024) launch_gemm_rows_mt<1, false, kEpiResidual, PREC>(b, s.mt, s.nw, st, s.ntl);
-    else if (!ln && epi == kEpiResidual && b.K == 4096) launch_gemm_rows_mt<4, false, kEpiResidual, PREC>(b, s.mt, s.nw, st, s.ntl);
-    else if (!ln && epi == kEpiBias && b.K == 1024) launch_gemm_rows_mt<1, false, kEpiBias, PREC>(b, s.mt, s.nw, st, s.ntl);
-    else if (!ln && epi == kEpiBias && b.K == 4096) launch_gemm_rows_mt<4, false, kEpiBias, PREC>(b, s.mt, s.nw, st, s.ntl);
+    if (ln && epi == kEpiQkv) launch_gemm_rows_mt<1, true, kEpiQkv, PREC, NT>(b, s.mt, s.nw, st, s.ntl);
+    else if (ln && epi == kEpiBiasGelu) launch_gemm_rows_mt<1, true, kEpiBiasGelu, PREC, NT>(b, s.mt, s.nw, st, s.ntl);
+    else if (ln && epi == kEpiBias) launch_gemm_rows_mt<1, true, kEpiBias, PREC, NT>(b, s.mt, s.nw, st, s.ntl);
+    else if (!ln && epi == kEpiResidual && b.K == 1024) launch_gemm_rows_mt<1, false, kEpiResidual, PREC, NT>(b, s.mt, s.nw, st, s.ntl);
+    else if (!ln && epi == kEpiResidual && b.K == 4096) launch_gemm_rows_mt<4, false, kEpiResidual, PREC, NT>(b, s.mt, s.nw, st, s.ntl);
+    else if (!ln && epi == kEpiBias && b.K == 1024) launch_gemm_rows_mt<1, false, kEpiBias, PREC, NT>(b, s.mt, s.nw, st, s.ntl);
+    else if (!ln && epi == kEpiBias && b.K == 4096) launch_gemm_rows_mt<4, false, kEpiBias, PREC, NT>(b, s.mt, s.nw, st, s.ntl);
     else throw InvalidArgument("launch_gemm_rows: unsupported (ln, epilogue, K) combination");
 }
 
@@ -716,8 +726,13 @@ void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream
     const GemmRowsShape s = gemm_rows_shape(a.M, a.N, a.K, ln);
     trace_launch("gemm_rows_kernel");
     AUR_REQUIRE(a.prec == 0 || a.prec == 1, "gemm_rows: prec is 0 (exact f32 MFMA) or 1 (bf16 x 3 split)");
-    if (a.prec == 1) launch_gemm_rows_prec<1>(a, ln, epi, s, st);
-    else launch_gemm_rows_prec<0>(a, ln, epi, s, st);
+    if (a.prec == 1) {
+        if (s.nt) launch_gemm_rows_prec<1, true>(a, ln, epi, s, st);
+        else launch_gemm_rows_prec<1, false>(a, ln, epi, s, st);
+    } else {
+        if (s.nt) launch_gemm_rows_prec<0, true>(a, ln, epi, s, st);
+        else launch_gemm_rows_prec<0, false>(a, ln, epi, s, st);
+    }
     HIP_CHECK(hipGetLastError());
 }
 

@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — realtime-factor / audio-samples-per-second of the generate_speech() hot path on MI355X.
 
-One "step" = one pass of the hot path over one batch of synthetic input: BASELINE.json configs[2]
-(64 concurrent 200-char utterances, shared speaker latent, temperature 0.75 / top_p 0.85 / top_k 50 /
-repetition penalty 5.0) per GPU: 70 text tokens -> prefill of 103 rows -> 280 mel tokens (fixed-length
-mode) -> latent stash -> HiFi-GAN -> 312 064 samples per utterance, waveforms copied to host.
-Weights (seeded synthetic, true shapes) and speaker conditioning are resident in HBM before the timed region.
+Headline workload (default, `--workload c3`) = BASELINE.json configs[2], the configuration `metric` is quoted on: 64 concurrent
+200-char utterances per GPU, shared speaker latent, temperature 0.75 / top_p 0.85 / top_k 50 / repetition penalty 5.0;
+one "step" = one pass of the hot path over one such batch: 70 text tokens -> prefill of 103 rows -> 280 mel tokens (fixed-length
+mode) -> latent stash -> HiFi-GAN -> 312 064 samples per utterance, waveforms delivered to the host.  Weights (seeded
+synthetic, true shapes) and speaker conditioning are resident in HBM before the timed region.  The timed region runs the engine
+exactly as the parity tests do (profile mode OFF); the per-kernel roofline numbers come from a profile pass right after it (the
+same workload once more with aur_set_profile on: HIP events on the stream the kernels run on, see include/auralis_amd.h).
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-Multi-GPU: utterances are independent, so each rank runs its own 64-way batch (weak scaling); the only
-collective is one RCCL broadcast of the speaker conditioning (133 120 B) from rank 0 before the timed region.
+Other workloads: `--workload c2` (configs[1]: ONE 200-char utterance, greedy, batch 1: time to audio), `--workload c5s` (configs[4]
+at single-GPU scale: >= 20 k characters of mixed en/fr/de through longform.stream_longform, natural stop, ragged),
+`--workload c4` (configs[3]: 512 utterances dealt 64 at a time to the ranks by parallel.shard_units, strong scaling).  The default
+run also measures c2 and c5s once after the headline (`--no-side` skips them) and, under torchrun with N > 1, c4.
+
+Output: the LAST stdout line is one compact JSON object (< 4 KB: the contract fields + roofline + cpu_baseline + one summary per
+side workload); everything else goes to gpurun_out/bench_full.json and stderr.
+
+Multi-GPU: utterances are independent, so each rank runs its own batches; the only collective is one RCCL broadcast of the speaker
+conditioning (133 120 B) from rank 0 before the timed region.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,34 +38,48 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP32_MFMA_PEAK_TFLOPS = 157.3  # exact-f32 MFMA / vector peak
+HBM_PEAK_GBPS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 achievable)
+FP32_MFMA_PEAK_TFLOPS = 157.3    # exact-f32 MFMA / vector peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA
+MATMUL_PARAMS_PER_LAYER = 12_582_912   # c_attn + c_proj + c_fc + mlp.c_proj (SURVEY 8a, a5)
+VOC_BYTES_8D_FP32, VOC_BYTES_8D_FP16 = 21301.0, 10650.0   # vocoder activation bytes per output sample
+GEMM_KINDS = ["qkv", "proj", "fc", "proj2", "head"]
+STOP_BIAS_C5S = 1.35             # mel_head.bias[1025] that makes the stop id reachable on the synthetic checkpoint (tests/test_gpu_baseline_size.py)
 
 
 def _log(msg: str):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, n_tokens: int = 280):
+def _r(x, n=4):
+    """round for the compact line"""
+    if x is None:
+        return None
+    if isinstance(x, (list, tuple)):
+        return [_r(v, n) for v in x]
+    return float(f"{x:.{n}g}")
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, n_tokens: int = 280, with_c1: bool = False):
     """CPU baseline (kind "port": the torch-CPU fp32 restatement of the reference path in oracle/) on this box's host cores.
 
     Sample = BASELINE configs[1] (C2) IN FULL: one 200-char utterance, 70 text ids, greedy, `n_tokens` = 280 mel tokens ->
     prefill + 279 decode steps + the reference's literal second pass (XTTSv2.py:617-687) + HiFi-GAN -> 312 064 samples,
-    with per-stage times; configs[0] (C1: 50-char utterance, 18 text ids, 70 tokens) is timed next to it.  The thread count
-    is swept first on an 8-token probe (more threads than the GEMV-sized matmuls can use makes the decode loop slower:
-    round 1 measured 0.35 s/token at 64 threads against 36 ms/token at 8) and the best one is used."""
+    with per-stage times.  The thread count is swept first on a 4-token probe (more threads than the GEMV-sized matmuls can
+    use makes the decode loop slower: round 1 measured 0.35 s/token at 64 threads against 36 ms/token at 8)."""
     from oracle import xtts_oracle as O
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     gpt = O.GPTOracle(gpt_sd, xtts_sd)
     w = O.vocoder_effective_weights(xtts_sd)
     c = gpt.build_cond(cond, text_ids)
     sweep = {}
-    for nt in sorted({t for t in (4, 8, 16, 32, 64) if t <= cores} | {min(cores, 8)}):
+    for nt in sorted({t for t in (8, 16, 32) if t <= cores} | {min(cores, 8)}):
         torch.set_num_threads(nt)
         gpt.generate(c, O.SamplingCfg(temperature=0.0, max_tokens=2, ignore_stop=True))          # warm-up
         t0 = time.perf_counter()
-        gpt.generate(c, O.SamplingCfg(temperature=0.0, max_tokens=8, ignore_stop=True))
-        sweep[nt] = (time.perf_counter() - t0) / 8.0
+        gpt.generate(c, O.SamplingCfg(temperature=0.0, max_tokens=4, ignore_stop=True))
+        sweep[nt] = (time.perf_counter() - t0) / 4.0
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
     _log("cpu_baseline: thread sweep (s per token incl. prefill share) " + ", ".join(f"{k}: {v:.3f}" for k, v in sweep.items())
@@ -74,64 +99,19 @@ def cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, n_tokens: int = 280
                 "samples_per_s": ns / (t3 - t0), "rtf": (t3 - t0) / (ns / 24000.0)}
 
     c2 = run(text_ids, n_tokens)
-    c1 = run(list(text_ids[:17]) + [text_ids[-1]], 70)
-    return {
+    out = {
         "value": c2["samples_per_s"], "unit": "audio-samples/s", "cores": best, "kind": "port",
-        "sample": f"BASELINE configs[1] in full: 1 utterance, 70 text ids, {n_tokens} mel tokens greedy -> {c2['samples']} samples in "
-                  f"{c2['wall_s']:.2f} s (prefill + AR decode {c2['ar_tokens_s']:.2f} s, literal second pass "
-                  f"{c2['second_pass_s']:.2f} s, HiFi-GAN {c2['vocoder_s']:.2f} s); torch CPU fp32 oracle, {best} threads "
-                  f"(best of the sweep, box has {cores} cores)",
-        "rtf": c2["rtf"], "c2": c2, "c1_50char_70_tokens": c1, "thread_sweep_s_per_token": {str(k): v for k, v in sweep.items()},
-        "host_cores": cores,
+        "sample": f"C2 in full: 1 utterance, 70 text ids, {n_tokens} greedy mel tokens -> {c2['samples']} samples in "
+                  f"{c2['wall_s']:.1f} s (AR {c2['ar_tokens_s']:.1f}, second pass {c2['second_pass_s']:.1f}, HiFi-GAN "
+                  f"{c2['vocoder_s']:.1f}); torch CPU fp32 oracle, {best} threads",
+        "rtf": c2["rtf"], "host_cores": cores, "c2": c2, "thread_sweep_s_per_token": {str(k): v for k, v in sweep.items()},
     }
+    if with_c1:   # BASELINE configs[0]: 50-char utterance, 18 text ids, 70 tokens
+        out["c1_50char_70_tokens"] = run(list(text_ids[:17]) + [text_ids[-1]], 70)
+    return out
 
 
-GEMM_KINDS = ["qkv (LayerNorm folded, KV page write) [64x1024]x[1024x3072]", "attn proj (+residual) [64x1024]x[1024x1024]",
-              "fc (LayerNorm folded, gelu) [64x1024]x[1024x4096]", "mlp proj (+residual) [64x4096]x[4096x1024]",
-              "mel head [64x1024]x[1024x1088]"]
-# gemm_rows_kernel<MT, KCH, LN, EPI, NW, NTL, PREC, DBG>: (LN, EPI) and KCH identify the GEMM kind in a kernel trace
-GEMM_KERNEL_RE = [r"gemm_rows_kernel<\d+, 1, true, 3,", r"gemm_rows_kernel<\d+, 1, false, 2,", r"gemm_rows_kernel<\d+, 1, true, 1,",
-                  r"gemm_rows_kernel<\d+, 4, false, 2,", r"gemm_rows_kernel<\d+, 1, false, 0,"]
-BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA
-MATMUL_PARAMS_PER_LAYER = 12_582_912   # c_attn + c_proj + c_fc + mlp.c_proj (SURVEY 8a, a5)
-
-
-def _rocprof_table():
-    """The committed rocprofv3 --kernel-trace --stats summary of this command (latest profiles/r*_bench_kernel_stats.csv):
-    {kernel name: (calls, average us)}."""
-    import csv
-    import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]*_bench_kernel_stats.csv")))
-    if not paths:
-        return None, {}
-    rows = {}
-    with open(paths[-1]) as f:
-        for r in csv.DictReader(f):
-            rows[r["Name"]] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)
-    return os.path.relpath(paths[-1], ROOT), rows
-
-
-def _rocprof_avg(rows, pattern):
-    import re
-    n = t = 0.0
-    for name, (calls, us) in rows.items():
-        if re.search(pattern, name):
-            n += calls
-            t += calls * us
-    return (t / n) if n else None
-
-
-def _rocprof_by_function(rows):
-    """GPU time per __global__ function: kernel names summed by the part before '<' (all template instantiations together)."""
-    fam = {}
-    for name, (calls, us) in rows.items():
-        key = name.split("<")[0].split("(")[0].strip()
-        c, t = fam.get(key, (0, 0.0))
-        fam[key] = (c + calls, t + calls * us)
-    tot = sum(t for _, t in fam.values()) or 1.0
-    return {k: {"calls": c, "total_ms": t / 1e3, "share": t / tot} for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])}
-
-
+# ------------------------------------------------------------------------------------------------ rooflines from a profile pass
 def _traffic():
     try:
         return json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
@@ -139,182 +119,355 @@ def _traffic():
         return {}
 
 
-def build_report(args, st, dims, world, samples, dt, audio_s):
-    prof_path, prof_rows = _rocprof_table()
+def kernel_rooflines(args, st, dims, samples_in_pass):
+    """Per-kernel numbers from the engine's HIP-event timing of ONE profile pass (`st` = aur_stats of that pass).
+    Decode GEMMs / attention: replay batches (one event pair per n_layer back-to-back launches of one kind, the step's real
+    operands, outputs to scratch).  Vocoder convs: a pair per launch (0.2-2 ms each).  Prefill: the whole phase."""
     tj = _traffic()
-    pmc = tj.get("r03_decode", {})
+    pmc_key = "r04_decode" if "r04_decode" in tj else "r03_decode"
+    pmc = tj.get(pmc_key, {})
     gemm_peak = FP32_MFMA_PEAK_TFLOPS if args.gemm == "f32" else BF16_MFMA_PEAK_TFLOPS / 6.0
-    gemm_arith = ("exact-f32 MFMA (v_mfma_f32_16x16x4_f32)" if args.gemm == "f32" else
-                  "fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMAs per product, fp32 accumulate (peak = dense bf16 / 6)")
 
-    def roof(kernel, ms, n, nbytes, flops, mfma_peak, rocprof_re, pmc_key, note):
-        ms_l = ms / max(1, n)
-        gbps = (nbytes / max(1, n)) / (ms_l * 1e-3) / 1e9 if ms_l > 0 else 0.0
-        r = {"kernel": kernel, "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
-             "traffic": None,
-             "avg_launch_ms": ms_l, "launches_timed": n, "algorithmic_bytes_per_launch": nbytes / max(1, n), "note": note}
-        pm = pmc.get(pmc_key) if pmc_key else None
-        if pm:   # PMC FETCH_SIZE (x2) + WRITE_SIZE of the committed rocprofv3 --pmc passes of this command (profiles/hbm_traffic.json);
-            # the ratio to that run's algorithmic bytes carries over to this run's launch size (attention grows with the context)
-            r["traffic"] = pm["ratio_to_algorithmic"] * nbytes / max(1, n)
-            r["traffic_source"] = {"file": "profiles/hbm_traffic.json[r03_decode]", "measured_bytes_per_launch": pm["bytes_per_launch"],
-                                   "algorithmic_bytes_per_launch_in_that_run": pm["algorithmic_bytes_per_launch_in_that_run"],
-                                   "ratio": pm["ratio_to_algorithmic"]}
+    def roof(name, ms, n, nbytes, flops, mfma_peak, pmc_name):
+        if not n or ms <= 0:
+            return None
+        us = ms / n * 1e3
+        gbps = (nbytes / n) / (us * 1e-6) / 1e9
+        r = {"kernel": name, "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+             "avg_launch_us": us, "launches_timed": n, "algorithmic_bytes_per_launch": nbytes / n, "traffic": None}
+        pm = pmc.get(pmc_name) if pmc_name else None
+        if pm:   # PMC FETCH_SIZE (x2) + WRITE_SIZE of committed rocprofv3 --pmc passes; the ratio carries over to this run's bytes
+            r["traffic"] = pm["ratio_to_algorithmic"] * nbytes / n
+            r["traffic_ratio"] = pm["ratio_to_algorithmic"]
+            r["traffic_from_committed_profile"] = f"profiles/hbm_traffic.json[{pmc_key}]"
         if flops:
-            tf = (flops / max(1, n)) / (ms_l * 1e-3) / 1e12 if ms_l > 0 else 0.0
+            tf = (flops / n) / (us * 1e-6) / 1e12
+            t_hbm = (nbytes / n) / (HBM_PEAK_GBPS * 1e9)
+            t_mfma = (flops / n) / (mfma_peak * 1e12)
             r["mfma"] = {"achieved": tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tf / mfma_peak}
-            # which roof binds this launch: time at the HBM peak for its bytes vs time at the matrix-pipe peak for its flops
-            t_hbm = (nbytes / max(1, n)) / (HBM_PEAK_GBPS * 1e9)
-            t_mfma = (flops / max(1, n)) / (mfma_peak * 1e12)
-            r["binding_roof"] = {"name": "hbm" if t_hbm >= t_mfma else "mfma", "floor_us_hbm": t_hbm * 1e6, "floor_us_mfma": t_mfma * 1e6,
-                                 "frac_of_binding_floor": max(t_hbm, t_mfma) / (ms_l * 1e-3) if ms_l > 0 else 0.0}
-        us = _rocprof_avg(prof_rows, rocprof_re) if rocprof_re else None
-        if us:
-            g2 = (nbytes / max(1, n)) / (us * 1e-6) / 1e9
-            r["rocprof"] = {"avg_launch_us": us, "achieved": g2, "frac": g2 / HBM_PEAK_GBPS, "source": prof_path}
+            r["binding_roof"] = "hbm" if t_hbm >= t_mfma else "mfma"
+            r["binding_floor_us"] = max(t_hbm, t_mfma) * 1e6
+            r["binding_floor_frac"] = max(t_hbm, t_mfma) / (us * 1e-6)
         return r
 
-    # fp16 vocoder: LDS-DMA staged convs (256 / 128 channels, transposed convs), fused ResBlock rounds (64 / 32 channels), conv_pre register-staged
-    conv_kernel = "conv1d_dma_f16_kernel + resblock_round_f16_kernel + conv1d_mfma_f16_kernel" if args.vocoder == "fp16" else "conv1d_mfma_kernel"
-    conv_re = r"(conv1d_(dma|mfma)_f16_kernel|resblock_round_f16_kernel)<" if args.vocoder == "fp16" else r"conv1d_mfma_kernel<"
-    # SURVEY 8(d) counts the vocoder's layer-granular activation traffic in fp32 (21 301 B per output sample); conv_bytes is the
-    # same accounting in the dtype each tensor is really stored in
-    roof_conv = roof(f"{conv_kernel} (HiFi-GAN convs, all instantiations)", st["conv_ms"], st["conv_launches"], st["conv_bytes"],
-                     st["conv_flops"], FP32_MFMA_PEAK_TFLOPS if args.vocoder == "fp32" else BF16_MFMA_PEAK_TFLOPS, conv_re, None,
-                     "bytes counted as stored")
-    conv_pmc = tj.get("r03_conv", {}).get(f"conv_{args.vocoder}")
-    if conv_pmc:   # PMC passes of the CURRENT layouts (profiles/hbm_traffic.json["r03_conv"]); absent = not measured this round
-        roof_conv["traffic"] = conv_pmc["bytes_per_launch"]
-        roof_conv["traffic_source"] = {"file": "profiles/hbm_traffic.json[r03_conv]", **conv_pmc}
-    if st["conv_ms"] > 0:
-        g = 21301.0 * samples / world / (st["conv_ms"] * 1e-3) / 1e9
-        roof_conv["survey_8d_fp32_bytes"] = {"bytes_per_sample": 21301, "achieved": g, "frac": g / HBM_PEAK_GBPS}
-    # per class: the wide stages are bounded by the fp16 matrix pipe / LDS, the narrow ones by HBM
-    conv_classes = []
-    names = ["ResBlock convs, 256 channels x 9 752 positions", "ResBlock convs, 128 channels x 78 016", "ResBlock convs, 64 channels x 156 032",
-             "ResBlock convs, 32 channels x 312 064", "conv_pre + 4 polyphase transposed convs"]
-    for k in range(5):
-        n, ms = st["conv_class_launches"][k], st["conv_class_ms"][k]
-        if n and ms > 0:
-            gb = st["conv_class_bytes"][k] / (ms * 1e-3) / 1e9
-            tf = st["conv_class_flops"][k] / (ms * 1e-3) / 1e12
-            pk = FP32_MFMA_PEAK_TFLOPS if args.vocoder == "fp32" else BF16_MFMA_PEAK_TFLOPS
-            t_h, t_m = st["conv_class_bytes"][k] / (HBM_PEAK_GBPS * 1e9), st["conv_class_flops"][k] / (pk * 1e12)
-            conv_classes.append({"class": names[k], "launches": n, "ms": ms, "hbm": {"achieved": gb, "frac": gb / HBM_PEAK_GBPS},
-                                 "mfma": {"achieved": tf, "frac": tf / pk}, "binding_roof": "hbm" if t_h >= t_m else "mfma",
-                                 "frac_of_binding_floor": max(t_h, t_m) / (ms * 1e-3)})
-    roof_conv["by_class"] = conv_classes
-    if conv_classes:   # the whole vocoder against the roof that binds each class: sum of the class floors / measured time
-        roof_conv["frac_of_binding_floors"] = sum(c["frac_of_binding_floor"] * c["ms"] for c in conv_classes) / sum(c["ms"] for c in conv_classes)
-    roof_attn = roof("paged_attention_kernel (decode: one query row per sequence against its paged K/V)",
-                     st["attn_ms"], st["attn_launches"], st["attn_bytes"], 0.0, 1.0, r"paged_attention_kernel<", "attention",
-                     "algorithmic bytes = K and V rows of every live sequence's context (8 KiB per token per layer) + q + out")
-    gemms = []
-    for k in range(5):
-        gemms.append(roof("gemm_rows_kernel: " + GEMM_KINDS[k], st["gemm_kind_ms"][k], st["gemm_kind_launches"][k],
-                          st["gemm_kind_bytes"][k], st["gemm_kind_flops"][k], gemm_peak, GEMM_KERNEL_RE[k],
-                          ["gemm_qkv", "gemm_proj", "gemm_fc", "gemm_proj2", "gemm_head"][k],
-                          "algorithmic bytes = weights + activation rows in + rows out (fp32 as stored); " + gemm_arith))
-    roof_gemm = roof("gemm_rows_kernel (decode-regime GEMMs: qkv, attn proj, fc, mlp proj, mel head — every template instantiation)",
-                     st["gemm_ms_raw"], st["gemm_launches"], st["gemm_bytes"], st["gemm_flops"], gemm_peak, r"gemm_rows_kernel<", None,
-                     "per-launch average over the five GEMM kinds weighted by their launch counts; per-kind entries in "
-                     "decode_gemm_kernels; HIP-event durations (fixed cost of an event pair NOT subtracted here)")
-    # PMC traffic of the family: the per-kind figures (profiles/hbm_traffic.json) weighted by the launches timed in this run
-    tl = [(g["traffic"], g["launches_timed"]) for g in gemms if g.get("traffic") and g.get("launches_timed")]
-    if tl and sum(n for _, n in tl) == roof_gemm["launches_timed"]:
-        roof_gemm["traffic"] = sum(t * n for t, n in tl) / sum(n for _, n in tl)
-        roof_gemm["traffic_source"] = {"file": "profiles/hbm_traffic.json[r03_decode]", "note": "launch-weighted mean of the five GEMM kinds' "
-                                       "measured-to-algorithmic ratios applied to this run's algorithmic bytes"}
+    gemms = [roof("gemm_rows_kernel: " + GEMM_KINDS[k], st["gemm_kind_ms"][k], st["gemm_kind_launches"][k], st["gemm_kind_bytes"][k],
+                  st["gemm_kind_flops"][k], gemm_peak, "gemm_" + GEMM_KINDS[k]) for k in range(5)]
     n_dec = max(1, st["decode_steps"])
-    per_layer = sum(g["avg_launch_ms"] for g in gemms[:4]) * 1e3
-    roof_gemm["four_gemms_per_layer_us"] = {"events": per_layer,
-                                            "rocprof": (sum((_rocprof_avg(prof_rows, GEMM_KERNEL_RE[k]) or 0.0) for k in range(4)) or None)}
-    # which __global__ function has the most GPU time in the timed region?  sampled per-launch averages x launches per step
-    est = {"paged_attention_kernel": roof_attn["avg_launch_ms"] * args.layers * n_dec,
-           conv_kernel: st["conv_ms"],
-           "gemm_rows_kernel": (per_layer * 1e-3 * args.layers + gemms[4]["avg_launch_ms"]) * n_dec,
-           "gemm_tile_split_kernel / gemm_tile_kernel (prefill, upper bound: whole prefill phase)": st["prefill_ms"]}
-    by_family = {"paged_attention_kernel": roof_attn, conv_kernel: roof_conv, "gemm_rows_kernel": roof_gemm}
-    order = sorted(by_family, key=lambda k: -est[k])
-    top = order[0]
-    dominant = dict(by_family[top], est_total_ms_in_timed_region=est[top], est_total_ms_of_candidates=est,
-                    rocprof_time_by_function=_rocprof_by_function(prof_rows) if prof_rows else None)
-    second = by_family[order[1]]
+    fam = None
+    if all(gemms):
+        # the family as it runs in a decode step: n_layer launches of each block GEMM + one head launch
+        L = args.layers
+        w = [L, L, L, L, 1]
+        us = sum(g["avg_launch_us"] * k for g, k in zip(gemms, w)) / sum(w)
+        by = sum(g["algorithmic_bytes_per_launch"] * k for g, k in zip(gemms, w)) / sum(w)
+        fl = sum(st["gemm_kind_flops"][k] / st["gemm_kind_launches"][k] * w[k] for k in range(5)) / sum(w)
+        gbps = by / (us * 1e-6) / 1e9
+        t_hbm, t_mfma = by / (HBM_PEAK_GBPS * 1e9), fl / (gemm_peak * 1e12)
+        tr = [g.get("traffic_ratio") for g in gemms]
+        fam = {"kernel": "gemm_rows_kernel (decode-regime GEMMs: qkv, attn proj, fc, mlp proj, mel head; every instantiation, "
+                         "weighted as they occur in a decode step)",
+               "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+               "avg_launch_us": us, "launches_timed": int(sum(g["launches_timed"] for g in gemms)),
+               "algorithmic_bytes_per_launch": by,
+               "frac_survey8d_fp16_bytes": gbps / 2 / HBM_PEAK_GBPS,
+               "binding_roof": "hbm" if t_hbm >= t_mfma else "mfma", "binding_floor_frac": max(t_hbm, t_mfma) / (us * 1e-6),
+               "four_gemms_per_layer_us": sum(g["avg_launch_us"] for g in gemms[:4]),
+               "per_kind_us": {GEMM_KINDS[k]: gemms[k]["avg_launch_us"] for k in range(5)},
+               "per_kind_frac": {GEMM_KINDS[k]: gemms[k]["frac"] for k in range(5)},
+               "traffic": None,
+               "measured_by": "HIP events around n_layer back-to-back launches per kind (replay of the step's launches, outputs to "
+                              "scratch): the launch-to-launch period, as a kernel trace reports it"}
+        if all(t is not None for t in tr):
+            ratio = sum(gemms[k]["traffic_ratio"] * gemms[k]["algorithmic_bytes_per_launch"] * w[k] for k in range(5)) / (by * sum(w))
+            fam["traffic"], fam["traffic_ratio"] = ratio * by, ratio
+            fam["traffic_from_committed_profile"] = f"profiles/hbm_traffic.json[{pmc_key}]"
+    attn = roof("paged_attention_kernel (decode: one query row per sequence against its paged K/V)", st["attn_ms"], st["attn_launches"],
+                st["attn_bytes"], 0.0, 1.0, "attention")
+    # vocoder
+    voc = None
+    if st["conv_ms"] > 0:
+        ms = st["conv_ms"]
+        mf_peak = FP32_MFMA_PEAK_TFLOPS if args.vocoder == "fp32" else BF16_MFMA_PEAK_TFLOPS
+        tf = st["conv_flops"] / (ms * 1e-3) / 1e12
+        gb = st["conv_bytes"] / (ms * 1e-3) / 1e9
+        names = ["resblocks_256ch", "resblocks_128ch", "resblocks_64ch", "resblocks_32ch", "conv_pre_and_transposed"]
+        cls = {}
+        for k in range(5):
+            n, m = st["conv_class_launches"][k], st["conv_class_ms"][k]
+            if n and m > 0:
+                cls[names[k]] = {"launches": n, "ms": m, "frac_mfma": st["conv_class_flops"][k] / (m * 1e-3) / 1e12 / mf_peak,
+                                 "frac_hbm_as_stored": st["conv_class_bytes"][k] / (m * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        conv_pmc = (tj.get("r04_conv") or tj.get("r03_conv") or {}).get(f"conv_{args.vocoder}")
+        voc = {"kernel": "conv1d_dma_f16_kernel + resblock_round_f16_kernel + conv1d_mfma_f16_kernel (HiFi-GAN convs)"
+                         if args.vocoder == "fp16" else "conv1d_mfma_kernel",
+               "ms_per_batch": ms / max(1, st["vocoder_batches"]), "launches": st["conv_launches"],
+               "bound": "mfma", "achieved": tf, "peak": mf_peak, "unit": "TFLOP/s", "frac_mfma": tf / mf_peak,
+               "frac_hbm_as_stored": gb / HBM_PEAK_GBPS, "bytes_per_sample_as_stored": st["conv_bytes"] / max(1, samples_in_pass),
+               "frac_hbm_8d_fp16": VOC_BYTES_8D_FP16 * samples_in_pass / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+               "frac_hbm_8d_fp32": VOC_BYTES_8D_FP32 * samples_in_pass / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+               "by_class": cls,
+               "traffic_ratio_as_stored": (conv_pmc["bytes_per_launch"] * st["conv_launches"] / st["conv_bytes"]) if conv_pmc and st["conv_bytes"] else None}
     # prefill (north_star: ">= 40 % MFMA util on GPT prefill"): matmul flops of the prompt rows over the event-timed prefill phases
-    # (which also hold the prompt attention, LayerNorm and embedding launches: a lower bound on the GEMM kernels' own rate).
-    # `peak` is the exact-f32 MFMA peak, the rate a hardware fp32 GEMM is bounded by.  With --gemm bf16x3 (default) the kernels reach
-    # those results through 6 bf16 MFMAs per product; `split_bf16` prices the same time against that arithmetic's own ceiling.
     prefill = None
     if st["prefill_ms"] > 0:
         fl = 2.0 * MATMUL_PARAMS_PER_LAYER * args.layers * st["prefill_rows"]
         tf = fl / (st["prefill_ms"] * 1e-3) / 1e12
-        split = args.gemm != "f32"
-        prefill = {"kernel": ("gemm_tile_split_kernel (prompt rows, fp32 operands as three bf16, 6 x v_mfma_f32_32x32x16_bf16 per product)" if split
-                              else "gemm_tile_kernel (prompt rows, exact-f32 MFMA)"),
-                   "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS,
-                   "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS, "prefill_rows": st["prefill_rows"], "prefill_ms": st["prefill_ms"],
-                   "note": "matmul flops of the prompt rows (2 x 12 582 912 x layers per row; speaker-prefix rows are shared and "
-                           "not recomputed) over the whole prefill phase; peak = exact-f32 MFMA"}
-        if split:
-            prefill["split_bf16"] = {"mfma_flops_per_product_flop": 6, "peak": BF16_MFMA_PEAK_TFLOPS / 6.0,
-                                     "frac": tf / (BF16_MFMA_PEAK_TFLOPS / 6.0), "matrix_pipe_busy": 6.0 * tf / BF16_MFMA_PEAK_TFLOPS}
-        by_kernel = {}
-        for name, (calls, us) in prof_rows.items():
-            if "gemm_tile" in name and ("split" in name) == split:
-                by_kernel[name.split("(")[0].replace("void aur::", "")] = {"calls": calls, "avg_launch_us": us}
-        if by_kernel:
-            prefill["rocprof_launches"] = {"source": prof_path, "kernels": by_kernel}
-    # whole decode step against the HBM roofline: weights once per step + K/V of every live context
-    dstep = None
-    if st["decode_steps"]:
-        ms = st["decode_ms"] / st["decode_steps"]
-        b32 = (st["decode_weight_bytes"] + st["decode_kv_bytes"]) / st["decode_steps"]
-        dstep = {"ms_per_step": ms, "steps": st["decode_steps"],
-                 "fp32_as_stored": {"bytes_per_step": b32, "achieved_GBps": b32 / ms / 1e6, "frac": b32 / ms / 1e6 / HBM_PEAK_GBPS},
-                 "survey_8d_fp16": {"bytes_per_step": b32 / 2, "achieved_GBps": b32 / 2 / ms / 1e6,
-                                    "frac": b32 / 2 / ms / 1e6 / HBM_PEAK_GBPS},
-                 "note": "fp32 weights and K/V are what this engine stores and streams; SURVEY 8(d) quotes the reference GPU path's "
-                         "fp16 storage, i.e. half the bytes for the same step"}
-    return {
-        "metric": "audio_samples_per_s (64-way batch; rtf = wall_s / audio_s alongside)",
-        "value": samples / dt, "unit": "audio-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32 (GPT: storage, softmax, LayerNorm, sampler; decode and prompt GEMMs "
-                  + ("on exact-f32 MFMA" if args.gemm == "f32" else "as exact 3-way bf16 splits of the f32 operands, f32 accumulate") + ")")
-                 + ("" if args.vocoder == "fp32" else " + f16-in/f32-acc MFMA (vocoder convs)")
-                 + (" + f16 K/V pool (throughput mode, not the parity configuration)" if args.kv == "fp16" else ""), "data": "synthetic",
-        "rtf": dt / audio_s, "audio_sec_per_wall_sec": audio_s / dt,
-        "config": {"workload": f"{args.batch} concurrent 200-char utterances per GPU (70 text tokens -> "
-                               f"{args.tokens} mel tokens fixed-length -> {dims.voc.samples_for_latents(args.tokens)} "
-                               f"samples each), T=0.75 top_p=0.85 top_k=50 rep_pen=5.0, shared speaker latent, "
-                               f"continuous batching; BASELINE.json configs[2]"
-                               + ("; consecutive steps pipelined (vocoder of batch k overlaps GPT of batch k+1)" if args.pipeline else ""),
-                   "utterances_per_gpu": args.batch, "mel_tokens": args.tokens, "gpt_layers": args.layers,
-                   "vocoder_mfma_inputs": args.vocoder, "kv_cache": args.kv, "decode_gemm_arithmetic": args.gemm,
-                   "parallelism": f"dp{world} (independent utterances, 1 RCCL broadcast of conditioning)"},
-        "roofline": dominant,
-        "roofline_second_kernel": second,
-        "roofline_vocoder": roof_conv,
-        "prefill_roofline": prefill,
-        "decode_gemm_kernels": gemms,
-        "decode_gemm_family": roof_gemm,
-        "decode_attention": roof_attn,
-        "decode_step_roofline": dstep,
-        "event_pair_overhead_ms": st["event_pair_overhead_ms"],
-        "breakdown_ms_per_step": {"gpt": st["gpt_ms"] / args.steps, "gpt_prefill": st["prefill_ms"] / args.steps,
-                                  "gpt_decode": st["decode_ms"] / args.steps, "vocoder": st["vocoder_ms"] / args.steps,
-                                  "vocoder_convs": st["conv_ms"] / args.steps,
-                                  "gpt_ms_per_decode_step": st["decode_ms"] / max(1, st["decode_steps"]),
-                                  "gpt_ms_per_decode_step_incl_prefill_share": st["gpt_ms"] / max(1, st["steps"])},
-    }
+        prefill = {"kernel": "gemm_tile_split_kernel (+ prompt attention, LayerNorm, embedding launches of the phase)" if args.gemm != "f32"
+                             else "gemm_tile_kernel", "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac_f32_peak": tf / FP32_MFMA_PEAK_TFLOPS, "prefill_rows": st["prefill_rows"],
+                   "ms_per_batch": st["prefill_ms"] / max(1, st["vocoder_batches"]),
+                   "matrix_pipe_busy": (6.0 * tf / BF16_MFMA_PEAK_TFLOPS) if args.gemm != "f32" else tf / FP32_MFMA_PEAK_TFLOPS}
+    est = {}
+    if fam and attn:
+        est = {"gemm_rows_kernel": fam["avg_launch_us"] * (4 * args.layers + 1) * n_dec * 1e-3,
+               "paged_attention_kernel": attn["avg_launch_us"] * args.layers * n_dec * 1e-3,
+               "vocoder_convs": st["conv_ms"], "prefill_phase": st["prefill_ms"]}
+    return {"gemm_family": fam, "gemm_kinds": gemms, "attention": attn, "vocoder": voc, "prefill": prefill,
+            "est_gpu_ms_in_pass": est, "event_pair_overhead_us": st["event_pair_overhead_ms"] * 1e3}
 
 
-def _f32_wav(x, sr: int = 22050) -> bytes:
-    import struct
-    data = np.asarray(x, dtype="<f4").tobytes()
-    fmt = struct.pack("<HHIIHH", 3, 1, sr, sr * 4, 4, 32)
-    return (b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + len(data)) + b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt +
-            b"data" + struct.pack("<I", len(data)) + data)
+def decode_step_roofline(st):
+    if not st["decode_steps"]:
+        return None
+    ms = st["decode_ms"] / st["decode_steps"]
+    b32 = (st["decode_weight_bytes"] + st["decode_kv_bytes"]) / st["decode_steps"]
+    return {"ms": ms, "steps": st["decode_steps"], "bytes_per_step_as_stored": b32,
+            "frac_as_stored": b32 / ms / 1e6 / HBM_PEAK_GBPS, "frac_8d_fp16": b32 / 2 / ms / 1e6 / HBM_PEAK_GBPS,
+            "rows_per_step": st["decode_rows"] / st["decode_steps"],
+            "note": "fp32 weights and K/V are what this engine stores and streams (bit-exact contract against the fp32 CPU path); "
+                    "SURVEY 8(d) quotes the reference GPU path's fp16 storage, i.e. half the bytes for the same step"}
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+class Bench:
+    def __init__(self, args, rank, world, local_rank, use_dist):
+        self.args, self.rank, self.world, self.local_rank, self.use_dist = args, rank, world, local_rank, use_dist
+        from auralis_amd._lib import NativeEngine
+        from auralis_amd.checkpoint import (make_synthetic_conditioning, make_synthetic_gpt, make_synthetic_text_ids,
+                                            make_synthetic_xtts)
+        from auralis_amd.config import XTTSDims
+        from auralis_amd.weights import pack_all
+        self.dims = XTTSDims()
+        _log("building synthetic checkpoint")
+        self.gpt_sd = make_synthetic_gpt(self.dims.gpt, seed=1234, n_layer=args.layers)
+        self.xtts_sd = make_synthetic_xtts(self.dims, seed=1234, gpt_sd=self.gpt_sd)
+        # profile=False: the engine configuration the parity tests run (tests/test_gpu_baseline_size.py)
+        self.eng = NativeEngine(n_layer=args.layers, max_seqs=args.batch, device=local_rank, profile=False,
+                                vocoder_fp16=(args.vocoder == "fp16"), return_latents=False,   # audio + tokens, as TTSOutput
+                                kv_fp16=(args.kv == "fp16"), gemm_f32_exact=(args.gemm == "f32"))
+        self.packed = pack_all(self.gpt_sd, self.xtts_sd)
+        self.eng.load_weights(self.packed)
+        _log("weights resident")
+        self.cond, self.spk = make_synthetic_conditioning(self.dims)
+        self.text_ids = make_synthetic_text_ids(self.dims, n_text=70, seed=11)
+        self.make_ids = lambda n, seed: make_synthetic_text_ids(self.dims, n_text=n, seed=seed)
+        self.SPK = 1
+
+    def fence(self):
+        if self.use_dist:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        self.eng.sync()
+
+    def run_batches(self, keys, batch=None, sampled=True):
+        """one batch of `batch` utterances per key, one after the other; results consumed in place (views of the engine's pinned
+        result blocks: the D2H copies are part of the step), released once counted"""
+        a, eng = self.args, self.eng
+        batch = batch or a.batch
+        total = 0
+        groups = [list(keys)] if a.pipeline else [[k] for k in keys]
+        for grp in groups:
+            for k in grp:
+                for b in range(batch):
+                    eng.submit(self.text_ids, self.SPK, temperature=0.75 if sampled else 0.0, top_p=0.85, top_k=50, repetition_penalty=5.0,
+                               max_tokens=a.tokens, seed=(self.rank * 100003 + (k + 7) * 1009 + b), ignore_stop=True)
+            outs = eng.run_until_done(max_steps=len(grp) * (a.tokens + 16) + 64, copy=False)
+            assert len(outs) == batch * len(grp)
+            total += sum(len(o["wav"]) for o in outs)
+            for o in outs:
+                assert o["error"] == 0
+                eng.release(o["seq_id"])
+        return total
+
+    # -- c2: BASELINE configs[1], one utterance, greedy, batch 1 (the regime the reference publishes latencies for, README.md:483-485)
+    def workload_c2(self, reps=3):
+        a, eng = self.args, self.eng
+        walls, stl = [], []
+        for r in range(reps + 1):
+            eng.reset_stats()
+            self.fence()
+            t0 = time.perf_counter()
+            eng.submit(self.text_ids, self.SPK, temperature=0.0, top_p=0.85, top_k=50, repetition_penalty=5.0, max_tokens=a.tokens,
+                       seed=r, ignore_stop=True)
+            outs = eng.run_until_done(copy=False)
+            dt = time.perf_counter() - t0
+            ns = len(outs[0]["wav"])
+            eng.release(outs[0]["seq_id"])
+            if r:   # first repetition = warm-up (buffer growth)
+                walls.append(dt)
+                stl.append(eng.stats())
+        i = int(np.argsort(walls)[len(walls) // 2])
+        st, dt = stl[i], walls[i]
+        ds = decode_step_roofline(st)
+        return {"workload": "BASELINE configs[1]: 1 x 200-char utterance (70 text ids), greedy, rep_pen 5.0, 280 mel tokens fixed-length, batch 1",
+                "time_to_audio_ms": dt * 1e3, "samples": ns, "audio_s": ns / 24000.0, "rtf": dt / (ns / 24000.0), "samples_per_s": ns / dt,
+                "prefill_ms": st["prefill_ms"], "decode_ms": st["decode_ms"], "vocoder_ms": st["vocoder_ms"],
+                "decode_step": ds, "wall_ms_all_reps": [w * 1e3 for w in walls],
+                "hbm_floor_ms_per_step": (ds["bytes_per_step_as_stored"] / (HBM_PEAK_GBPS * 1e9) * 1e3) if ds else None}
+
+    # -- c5s: BASELINE configs[4] at single-GPU scale: mixed-language long form through the facade, natural stop, ragged
+    def workload_c5s(self, chars=20000, window=32):
+        from auralis_amd import TTS
+        from auralis_amd.api.text import XTTSTokenizer
+        from auralis_amd.api.xtts_engine import XTTSv2Engine
+        from auralis_amd.longform import build_requests, stream_longform
+        a, eng = self.args, self.eng
+        EN = ("It was a bright cold day in April, and the clocks were striking thirteen. Nobody in the street seemed to notice, "
+              "and the wind kept pushing the dust along the old road as if nothing had happened at all. ")
+        FR = ("Il était une fois, dans une petite ville que nous ne connaissons pas, un homme qui avait beaucoup d'idées et très peu "
+              "de temps pour les écrire. Il marchait chaque matin le long de la rivière avec son chien. ")
+        DE = ("Es war einmal ein Mann, der nicht mit dem Zug fahren wollte und auch nicht zu Fuß gehen konnte, weil der Weg durch "
+              "den Wald zu lang war. Also blieb er zu Hause und schrieb Briefe an seine Freunde. ")
+        rng = np.random.default_rng(5)
+        paras = []
+        while sum(len(p) for p in paras) < chars:
+            for s in (EN, FR, DE):
+                paras.append((s * int(rng.integers(1, 4)))[: int(rng.integers(90, 600))].strip())
+        # the stop id becomes reachable (as in the ragged baseline-size parity test); sequences end on it or at 605 tokens
+        hb = np.array(self.packed["mel_head.b"], dtype=np.float32, copy=True)
+        hb[1025] = STOP_BIAS_C5S
+        eng.load_weights({"mel_head.b": hb})
+        voice = {"gpt_cond_latent": self.cond.numpy(), "speaker_embedding": self.spk.numpy()}
+        reqs = build_requests(paras, [voice], seed=3)   # request defaults: T 0.75 / top_p 0.85 / top_k 50 / rep_pen 5.0
+        xe = XTTSv2Engine(eng, XTTSTokenizer(None, vocab_size=self.xtts_sd["text_embedding.weight"].shape[0], synthetic=True),
+                          max_concurrency=a.batch)
+        tts = TTS(scheduler_max_concurrency=a.batch).with_engine(xe)
+        try:
+            eng.reset_stats()
+            self.fence()
+            t0 = time.perf_counter()
+            first, n_chunks, ns, order_ok, last = None, 0, 0, True, -1
+            toks = []
+            for i, c in stream_longform(tts, reqs, window=window):
+                if first is None:
+                    first = time.perf_counter() - t0
+                order_ok &= i >= last
+                last = i
+                n_chunks += 1
+                ns += len(c.array)
+                toks.append(int(c.token_length or 0))
+            dt = time.perf_counter() - t0
+            st = eng.stats()
+        finally:
+            tts.close(keep_engine=True)   # the bench still needs the native engine
+            eng.load_weights({"mel_head.b": np.asarray(self.packed["mel_head.b"], np.float32)})
+        occ = st["decode_rows"] / max(1, st["decode_steps"]) / a.batch
+        return {"workload": f"BASELINE configs[4] at 1-GPU scale: {sum(len(p) for p in paras)} chars, {len(paras)} paragraphs en/fr/de "
+                            f"(language=auto), {n_chunks} chunks, natural stop (mel_head.bias[1025] = {STOP_BIAS_C5S}), window {window}, "
+                            f"{a.batch} slots, streamed in (paragraph, chunk) order through TTS / longform.stream_longform",
+                "chars": sum(len(p) for p in paras), "paragraphs": len(paras), "chunks": n_chunks, "in_order": bool(order_ok),
+                "wall_s": dt, "first_chunk_s": first, "samples": ns, "audio_s": ns / 24000.0, "samples_per_s": ns / dt, "rtf": dt / max(1e-9, ns / 24000.0),
+                "chars_per_s": sum(len(p) for p in paras) / dt, "slot_occupancy": occ,
+                "tokens_per_chunk": {"mean": float(np.mean(toks)), "min": int(np.min(toks)), "max": int(np.max(toks))} if toks else None,
+                "decode_steps": st["decode_steps"], "decode_ms_per_step": st["decode_ms"] / max(1, st["decode_steps"]),
+                "gpt_ms": st["gpt_ms"], "vocoder_ms": st["vocoder_ms"], "vocoder_batches": st["vocoder_batches"]}
+
+    # -- c4: BASELINE configs[3]: 512 utterances dealt 64 at a time to the ranks (strong scaling; 8 GPUs -> one batch each)
+    def workload_c4(self, n_units=512):
+        from auralis_amd.parallel import merge_ordered, shard_units
+        a, eng = self.args, self.eng
+        mine = shard_units(n_units, self.world, self.rank, per_gpu_batch=a.batch)
+        self.fence()
+        t0 = time.perf_counter()
+        digests, ns = [], 0
+        for start in range(0, len(mine), a.batch):
+            blk = mine[start:start + a.batch]
+            ids = {}
+            for u in blk:
+                ids[eng.submit(self.text_ids, self.SPK, temperature=0.75, top_p=0.85, top_k=50, repetition_penalty=5.0, max_tokens=a.tokens,
+                               seed=u, ignore_stop=True)] = u
+            for o in eng.run_until_done(copy=False):
+                assert o["error"] == 0
+                hh = hashlib.blake2b(digest_size=8)
+                hh.update(np.asarray(o["tokens"], np.int32).tobytes())
+                digests.append((ids[o["seq_id"]], len(o["wav"]), hh.hexdigest()))
+                ns += len(o["wav"])
+                eng.release(o["seq_id"])
+        self.fence()
+        dt = time.perf_counter() - t0
+        if self.use_dist:
+            per = [None] * self.world
+            torch.distributed.all_gather_object(per, digests)
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        else:
+            per = [digests]
+        merged = merge_ordered(per)
+        total = sum(n for _, n, _ in merged)
+        return {"workload": f"BASELINE configs[3]: {n_units} x 200-char utterances dealt {a.batch} at a time to {self.world} rank(s) by "
+                            "parallel.shard_units, per-unit seeds, results merged by unit index (parallel.merge_ordered)",
+                "units": n_units, "units_returned_in_order": [u for u, _, _ in merged] == list(range(n_units)),
+                "wall_s": dt, "samples": total, "samples_per_s": total / dt, "rtf": dt / (total / 24000.0), "scaling": "strong",
+                "ids_digest": hashlib.blake2b("".join(h for _, _, h in merged).encode(), digest_size=8).hexdigest()}
+
+
+def compact(line, full_path):
+    """The driver-facing line: contract fields + roofline + cpu_baseline + one summary per side workload, < 4 KB."""
+    k = line["kernels"] or {}
+    fam, attn, voc, pre = k.get("gemm_family"), k.get("attention"), k.get("vocoder"), k.get("prefill")
+    out = {key: line[key] for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                      "vs_baseline", "dtype", "data", "rtf", "config")}
+    out["value"], out["ms_per_step"], out["rtf"] = _r(out["value"], 6), _r(out["ms_per_step"], 6), _r(out["rtf"], 4)
+    if fam:
+        out["roofline"] = {"kernel": "gemm_rows_kernel (decode GEMM family)", "bound": fam["bound"], "achieved": _r(fam["achieved"]),
+                           "peak": fam["peak"], "unit": fam["unit"], "frac": _r(fam["frac"]), "traffic": _r(fam["traffic"]),
+                           "traffic_ratio": _r(fam.get("traffic_ratio")), "traffic_from_committed_profile": fam.get("traffic_from_committed_profile"),
+                           "frac_survey8d_fp16_bytes": _r(fam["frac_survey8d_fp16_bytes"]), "binding_roof": fam["binding_roof"],
+                           "binding_floor_frac": _r(fam["binding_floor_frac"]), "avg_launch_us": _r(fam["avg_launch_us"]),
+                           "launches_timed": fam["launches_timed"], "four_gemms_per_layer_us": _r(fam["four_gemms_per_layer_us"]),
+                           "per_kind_us": {a: _r(b, 3) for a, b in fam["per_kind_us"].items()},
+                           "share_of_gpu_time": _r(line.get("dominant_share")), "in_run": "HIP events, replay batches in a profile pass"}
+    else:
+        out["roofline"] = None
+    if attn:
+        out["roofline_attention"] = {"frac": _r(attn["frac"]), "achieved": _r(attn["achieved"]), "avg_launch_us": _r(attn["avg_launch_us"]),
+                                     "traffic_ratio": _r(attn.get("traffic_ratio"))}
+    if voc:
+        out["roofline_vocoder"] = {"frac_mfma": _r(voc["frac_mfma"]), "frac_hbm_as_stored": _r(voc["frac_hbm_as_stored"]),
+                                   "frac_hbm_8d_fp16": _r(voc["frac_hbm_8d_fp16"]), "frac_hbm_8d_fp32": _r(voc["frac_hbm_8d_fp32"]),
+                                   "conv_ms_per_batch": _r(voc["ms_per_batch"]),
+                                   "frac_mfma_by_class": {a: _r(b["frac_mfma"], 3) for a, b in voc["by_class"].items()}}
+    if pre:
+        out["prefill_roofline"] = {"frac_f32_peak": _r(pre["frac_f32_peak"]), "matrix_pipe_busy": _r(pre["matrix_pipe_busy"]),
+                                   "ms_per_batch": _r(pre["ms_per_batch"])}
+    ds = line.get("decode_step")
+    if ds:
+        out["decode_step"] = {"ms": _r(ds["ms"]), "frac_as_stored": _r(ds["frac_as_stored"]), "frac_8d_fp16": _r(ds["frac_8d_fp16"])}
+    out["breakdown_ms_per_step"] = {a: _r(b) for a, b in line["breakdown_ms_per_step"].items()}
+    c2 = line.get("c2")
+    if c2 and "error" not in c2:
+        out["c2"] = {"time_to_audio_ms": _r(c2["time_to_audio_ms"]), "rtf": _r(c2["rtf"]), "decode_ms_per_step": _r(c2["decode_step"]["ms"]),
+                     "decode_frac_hbm_as_stored": _r(c2["decode_step"]["frac_as_stored"]), "prefill_ms": _r(c2["prefill_ms"]),
+                     "vocoder_ms": _r(c2["vocoder_ms"])}
+    elif c2:
+        out["c2"] = c2
+    c5 = line.get("c5s")
+    if c5 and "error" not in c5:
+        out["c5s"] = {"chars": c5["chars"], "chunks": c5["chunks"], "samples_per_s": _r(c5["samples_per_s"]), "rtf": _r(c5["rtf"]),
+                      "slot_occupancy": _r(c5["slot_occupancy"]), "first_chunk_s": _r(c5["first_chunk_s"]), "in_order": c5["in_order"]}
+    elif c5:
+        out["c5s"] = c5
+    c4 = line.get("c4")
+    if c4:
+        out["c4"] = {a: (_r(b) if isinstance(b, float) else b) for a, b in c4.items() if a != "workload"}
+    cb = line.get("cpu_baseline")
+    out["cpu_baseline"] = ({"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "host_cores": cb["host_cores"], "kind": cb["kind"],
+                            "rtf": _r(cb["rtf"]), "sample": cb["sample"]} if cb else None)
+    if line.get("multi_gpu"):
+        out["multi_gpu"] = line["multi_gpu"]
+    out["full_report"] = full_path
+    return out
 
 
 def main():
@@ -322,6 +475,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["c3", "c2", "c5s", "c4"], default="c3",
+                    help="c3 (default) = BASELINE configs[2], the headline; c2 / c5s / c4 run only that workload and print its record")
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
     ap.add_argument("--tokens", type=int, default=280, help="mel tokens per utterance (fixed-length mode)")
     ap.add_argument("--layers", type=int, default=30)
@@ -331,23 +486,26 @@ def main():
                     help="paged K/V pool dtype: fp32 = the bit-exact parity mode (default, the reported metric); fp16 = opt-in "
                          "throughput mode (aur_config.kv_fp16), half the attention bytes, ids may differ after a near-tie")
     ap.add_argument("--gemm", choices=["bf16x3", "f32"], default="bf16x3",
-                    help="arithmetic of the decode-regime GEMMs: bf16x3 = exact 3-way bf16 split of the fp32 operands, 6 bf16 MFMAs per "
-                         "product, fp32 accumulate (default, the configuration the parity tests run); f32 = v_mfma_f32_16x16x4_f32 "
-                         "(aur_config.gemm_f32_exact)")
+                    help="GEMM arithmetic: bf16x3 = exact 3-way bf16 split of the fp32 operands, 6 bf16 MFMAs per product, fp32 "
+                         "accumulate (default, what the parity tests run); f32 = v_mfma_f32_*_f32 (aur_config.gemm_f32_exact)")
     ap.add_argument("--bcast", choices=["native", "torch"], default="native",
                     help="multi-GPU launches: native = the ncclBroadcast inside the library on the engine's own RCCL communicator "
                          "(aur_comm_init / aur_broadcast_conditioning, default); torch = torch.distributed.broadcast into a device "
                          "buffer registered with aur_set_conditioning_device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-throughput-mode", action="store_true", help="skip the extra fp16-K/V measurement after the timed run")
+    ap.add_argument("--no-side", action="store_true", help="skip the c2 / c5s (and, N > 1, c4) measurements after the headline")
+    ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--profile-every", type=int, default=8, help="profile pass: replay batches after every n-th decode step")
+    ap.add_argument("--c5-chars", type=int, default=20000)
     ap.add_argument("--pipeline", action="store_true",
-                    help="queue all steps at once so the vocoder of batch k overlaps the GPT of batch k+1 (measured "
-                         "neutral on MI355X in fp32: both stages want the same CUs)")
+                    help="queue all steps at once so the vocoder of batch k overlaps the GPT of batch k+1 (measured neutral)")
     ap.add_argument("--cpu-tokens", type=int, default=280, help="mel tokens of the CPU-baseline utterance (280 = C2 in full)")
+    ap.add_argument("--cpu-c1", action="store_true", help="also time BASELINE configs[0] on the CPU oracle")
+    ap.add_argument("--out", default=os.path.join("gpurun_out", "bench_full.json"))
     args = ap.parse_args()
 
-    # stdout carries exactly ONE line, the JSON record: everything native libraries print to file descriptor 1 (RCCL's version
-    # banner at communicator creation, for one) is sent to stderr instead, and the record goes to the saved descriptor
+    # stdout carries exactly ONE line, the compact JSON record: everything native libraries print to file descriptor 1 (RCCL's
+    # version banner at communicator creation, for one) is sent to stderr instead, and the record goes to the saved descriptor
     sys.stdout.flush()
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
@@ -367,27 +525,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
 
-    from auralis_amd._lib import NativeEngine
-    from auralis_amd.checkpoint import (make_synthetic_conditioning, make_synthetic_gpt, make_synthetic_text_ids,
-                                        make_synthetic_xtts)
-    from auralis_amd.config import XTTSDims
-    from auralis_amd.parallel import broadcast_conditioning
-    from auralis_amd.weights import pack_all
-
-    dims = XTTSDims()
-    _log("building synthetic checkpoint")
-    gpt_sd = make_synthetic_gpt(dims.gpt, seed=1234, n_layer=args.layers)
-    xtts_sd = make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd)
-    eng = NativeEngine(n_layer=args.layers, max_seqs=args.batch, device=local_rank, profile=True,
-                       vocoder_fp16=(args.vocoder == "fp16"), return_latents=False,   # audio + tokens, as TTSOutput
-                       kv_fp16=(args.kv == "fp16"), gemm_f32_exact=(args.gemm == "f32"))
-    packed = pack_all(gpt_sd, xtts_sd)
-    eng.load_weights(packed)
-    _log("weights resident")
+    B = Bench(args, rank, world, local_rank, use_dist)
+    eng, dims, SPK = B.eng, B.dims, B.SPK
 
     # speaker conditioning: computed on rank 0, RCCL-broadcast over xGMI, registered from the device buffer
-    cond, spk = make_synthetic_conditioning(dims)
-    SPK = 1
     multi = {}
     route = args.bcast
     if use_dist and route == "native":
@@ -397,23 +538,24 @@ def main():
         from auralis_amd.parallel import broadcast_conditioning_native
         err = ""
         try:
-            broadcast_conditioning_native(eng, SPK, cond if rank == 0 else None, spk if rank == 0 else None, src=0)
+            broadcast_conditioning_native(eng, SPK, B.cond if rank == 0 else None, B.spk if rank == 0 else None, src=0)
             multi["rccl_ranks"], multi["rccl_rank_of_rank0"] = eng.comm_info()   # what the communicator itself reports
         except Exception as ex:   # noqa: BLE001 - reported in the bench line
             err = f"{type(ex).__name__}: {ex}"
         bad = torch.tensor([1 if err else 0], device=torch.device("cuda", local_rank), dtype=torch.int32)
         torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
+        multi["native_route_failed"] = False
         if int(bad.item()):
             route = "torch"
-            multi["native_route_failed"] = err or "on another rank"
+            multi["native_route_failed"] = (err or "on another rank")[:160]
             _log(f"in-library RCCL route failed ({multi['native_route_failed']}); falling back to torch.distributed.broadcast")
     if use_dist and route == "torch":
-        broadcast_conditioning(eng, SPK, cond if rank == 0 else None, spk if rank == 0 else None, src=0,
+        from auralis_amd.parallel import broadcast_conditioning
+        broadcast_conditioning(eng, SPK, B.cond if rank == 0 else None, B.spk if rank == 0 else None, src=0,
                                device=torch.device("cuda", local_rank))
         multi["rccl_ranks"] = torch.distributed.get_world_size()
     elif not use_dist:
-        eng.set_conditioning(SPK, cond.numpy(), spk.numpy())
-    text_ids = make_synthetic_text_ids(dims, n_text=70, seed=11)
+        eng.set_conditioning(SPK, B.cond.numpy(), B.spk.numpy())
     if use_dist:
         # self-verification of the multi-GPU path, outside the timed region: (1) the voice every rank holds in device memory is
         # byte-identical to rank 0's; (2) the SAME small workload (same prompts, same seeds, greedy and sampled) produces
@@ -421,9 +563,8 @@ def main():
         from auralis_amd.parallel import all_ranks_equal
         multi["bcast_route"] = route
         multi["conditioning_hash_equal_across_ranks"] = all_ranks_equal(eng.conditioning_checksum(SPK))
-        import hashlib
         for k in range(4):
-            eng.submit(make_synthetic_text_ids(dims, n_text=20 + 5 * k, seed=900 + k), SPK, temperature=(0.0 if k < 2 else 0.75),
+            eng.submit(B.make_ids(20 + 5 * k, 900 + k), SPK, temperature=(0.0 if k < 2 else 0.75),
                        top_p=0.85, top_k=50, repetition_penalty=5.0, max_tokens=24, seed=4242 + k, ignore_stop=True)
         outs = sorted(eng.run_until_done(), key=lambda o: o["seq_id"])
         hh = hashlib.blake2b(digest_size=16)
@@ -432,49 +573,45 @@ def main():
             hh.update(np.asarray(o["wav"], np.float32).tobytes())
         multi["output_hash_equal_across_ranks"] = all_ranks_equal(hh.hexdigest())
 
-    def run_steps(first: int, n: int):
-        """n steps = n batches of `batch` utterances, one after the other.  With --pipeline all n batches are queued at
-        once: the continuous batcher admits batch k+1 into the slots batch k frees when its tokens are done, so the
-        HiFi-GAN of batch k (own stream) overlaps the GPT prefill/decode of batch k+1."""
-        total = 0
-        groups = [range(first, first + n)] if args.pipeline else [[k] for k in range(first, first + n)]
-        for grp in groups:
-            for k in grp:
-                for b in range(args.batch):
-                    eng.submit(text_ids, SPK, temperature=0.75, top_p=0.85, top_k=50, repetition_penalty=5.0,
-                               max_tokens=args.tokens, seed=(rank * 100003 + (k + 7) * 1009 + b), ignore_stop=True)
-            # results are consumed in place: views of the engine's pinned result blocks (the D2H copies are part of the step),
-            # released once counted -- the extra host memcpy into owned numpy arrays (80 MB per step) is a binding convenience
-            outs = eng.run_until_done(max_steps=len(grp) * (args.tokens + 16) + 64, copy=False)
-            assert len(outs) == args.batch * len(grp)
-            total += sum(len(o["wav"]) for o in outs)
-            for o in outs:
-                assert o["error"] == 0
-                eng.release(o["seq_id"])
-        return total
+    def side(name, fn):
+        try:
+            t0 = time.perf_counter()
+            r = fn()
+            _log(f"{name} done in {time.perf_counter() - t0:.1f} s")
+            return r
+        except Exception as ex:   # noqa: BLE001 - never lose the headline over a side measurement
+            _log(f"{name} FAILED: {type(ex).__name__}: {ex}")
+            return {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
 
-    def fence():
+    if args.workload != "c3":   # ad-hoc: one workload, its own record
+        if args.warmup:
+            B.run_batches(range(-args.warmup, 0), batch=(1 if args.workload == "c2" else None))
+        rec = {"c2": B.workload_c2, "c5s": lambda: B.workload_c5s(args.c5_chars), "c4": B.workload_c4}[args.workload]()
+        if rank == 0:
+            rec["n_gpus"] = world
+            print(json.dumps(rec), file=json_out, flush=True)
+        eng.close()
         if use_dist:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-        eng.sync()
+            torch.distributed.destroy_process_group()
+        return
 
+    # ---- headline: c3, timed region with the engine as the parity tests run it
     if args.warmup:
-        run_steps(-args.warmup, args.warmup)
+        B.run_batches(range(-args.warmup, 0))
         _log(f"{args.warmup} warmup step(s) done")
     eng.reset_stats()
-    fence()
+    B.fence()
     t0 = time.perf_counter()
-    samples = run_steps(0, args.steps)
+    samples = B.run_batches(range(args.steps))
     _log(f"{args.steps} timed step(s) done at +{time.perf_counter() - t0:.3f}s")
-    fence()
+    B.fence()
     dt = time.perf_counter() - t0
     st = eng.stats()
 
     if use_dist:
         per_rank = [None] * world
         torch.distributed.all_gather_object(per_rank, dt / args.steps * 1e3)
-        multi["per_rank_ms_per_step"] = per_rank
+        multi["per_rank_ms_per_step"] = [_r(v, 5) for v in per_rank]
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -482,60 +619,73 @@ def main():
         torch.distributed.all_reduce(s, op=torch.distributed.ReduceOp.SUM)
         samples = float(s.item())
 
+    # ---- profile pass (every rank runs it, so that the ranks stay in step; rank 0 reports): the same batch once more with profile on
+    kernels = None
+    if not args.no_profile_pass:
+        eng.set_profile(args.profile_every)
+        eng.reset_stats()
+        ps = B.run_batches([args.steps + 1000])
+        eng.sync()
+        pst = eng.stats()
+        eng.set_profile(0)
+        kernels = kernel_rooflines(args, pst, dims, ps)
+        _log("profile pass done")
+
+    line = None
     if rank == 0:
         audio_s = samples / 24000.0
-        line = build_report(args, st, dims, world, samples, dt, audio_s)
+        est = (kernels or {}).get("est_gpu_ms_in_pass") or {}
+        line = {
+            "metric": "audio_samples_per_s (64-way batch; rtf = wall_s / audio_s alongside)",
+            "value": samples / dt, "unit": "audio-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (GPT; GEMMs " + ("exact-f32 MFMA" if args.gemm == "f32" else "as exact bf16x3 splits, f32 acc") + ")"
+                     + ("" if args.vocoder == "fp32" else " + f16-in/f32-acc vocoder") + (" + f16 K/V (NOT the parity mode)" if args.kv == "fp16" else ""),
+            "data": "synthetic", "rtf": dt / audio_s,
+            "config": {"workload": f"BASELINE configs[2]: {args.batch} concurrent 200-char utterances per GPU (70 text tokens -> {args.tokens} mel "
+                                   f"tokens fixed-length -> {dims.voc.samples_for_latents(args.tokens)} samples each), T=0.75 top_p=0.85 top_k=50 "
+                                   "rep_pen=5.0, shared speaker latent, continuous batching"
+                                   + ("; steps pipelined" if args.pipeline else ""),
+                       "utterances_per_gpu": args.batch, "mel_tokens": args.tokens, "gpt_layers": args.layers,
+                       "vocoder_mfma_inputs": args.vocoder, "kv_cache": args.kv, "gemm_arithmetic": args.gemm, "engine_profile_mode_in_timed_region": False,
+                       "parallelism": f"dp{world} (independent utterances, 1 RCCL broadcast of conditioning)"},
+            "kernels": kernels,
+            "dominant_share": (est.get("gemm_rows_kernel", 0.0) / sum(est.values())) if est else None,
+            "decode_step": decode_step_roofline(st),
+            "breakdown_ms_per_step": {"gpt": st["gpt_ms"] / args.steps, "gpt_prefill": st["prefill_ms"] / args.steps,
+                                      "gpt_decode": st["decode_ms"] / args.steps, "vocoder": st["vocoder_ms"] / args.steps,
+                                      "gpt_ms_per_decode_step": st["decode_ms"] / max(1, st["decode_steps"])},
+            "audio_sec_per_wall_sec": audio_s / dt,
+        }
         if use_dist:
             line["multi_gpu"] = multi
+    # ---- side workloads
+    c2 = c5 = c4 = None
+    if not args.no_side:
+        if world == 1:
+            c2 = side("c2", B.workload_c2)
+            c5 = side("c5s", lambda: B.workload_c5s(args.c5_chars))
+        else:
+            c4 = B.workload_c4()   # collective: no try/except around a path every rank must walk together
+    if rank == 0:
+        line["c2"], line["c5s"], line["c4"] = c2, c5, c4
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, args.cpu_tokens)
+            line["cpu_baseline"] = cpu_baseline(B.gpt_sd, B.xtts_sd, dims, B.cond, B.spk, B.text_ids, args.cpu_tokens, args.cpu_c1)
         else:
             line["cpu_baseline"] = None
-    # Once-per-speaker path, outside the timed region: reference audio -> conditioning on the HIP kernels
-    if rank == 0 and world == 1:
+        full_path = args.out
         try:
-            from auralis_amd.weights import pack_conditioning
-            eng.load_weights(pack_conditioning(xtts_sd))
-            rng = np.random.default_rng(5)
-            tt = np.arange(22050 * 6) / 22050.0
-            clip = (0.3 * np.sin(2 * np.pi * 150 * tt) * (1 + 0.5 * np.sin(2 * np.pi * 3 * tt)) + 0.02 * rng.standard_normal(tt.size)).astype(np.float32)
-            eng.compute_conditioning([clip])
-            t0 = time.perf_counter()
-            for _ in range(5):
-                eng.compute_conditioning([clip])
-            sc = {"ms_per_6s_reference": (time.perf_counter() - t0) / 5 * 1e3, "what": "aur_compute_conditioning: mel front-ends, "
-                  "ConditioningEncoder, PerceiverResampler, ResNet-SE speaker encoder (fp32, host copies included)"}
-            if not args.no_cpu_baseline:
-                from oracle import conditioning_oracle as Cn
-                sd_c = {k: v for k, v in xtts_sd.items() if k.startswith(("conditioning_", "hifigan_decoder.speaker_encoder.", "mel_stats"))}
-                t0 = time.perf_counter()
-                Cn.get_conditioning_latents(sd_c, [_f32_wav(clip)], max_ref_length=30, gpt_cond_len=6, gpt_cond_chunk_len=6)
-                sc["cpu_ms"] = (time.perf_counter() - t0) * 1e3
-            line["speaker_conditioning"] = sc
-        except Exception as e:   # never lose the headline line over the side measurement
-            line["speaker_conditioning"] = {"error": str(e)[:200]}
-    # Not the reported metric: the same workload once more with the opt-in fp16 K/V pool (aur_config.kv_fp16; fp32 arithmetic,
-    # 0 id mismatches on the C2 / C3 goldens, tests/test_gpu_baseline_size.py), so that both numbers come from one driver run.
-    if world == 1 and args.kv == "fp32" and not args.no_throughput_mode:
-        eng.close()
-        eng = NativeEngine(n_layer=args.layers, max_seqs=args.batch, device=local_rank, profile=False,
-                           vocoder_fp16=(args.vocoder == "fp16"), return_latents=False, kv_fp16=True,
-                           gemm_f32_exact=(args.gemm == "f32"))
-        eng.load_weights(packed)
-        eng.set_conditioning(SPK, cond.numpy(), spk.numpy())
-        run_steps(-1, 1)
-        fence()
-        t0 = time.perf_counter()
-        s2 = run_steps(0, args.steps)
-        fence()
-        dt2 = time.perf_counter() - t0
-        line["throughput_mode_kv_fp16"] = {
-            "value": s2 / dt2, "unit": "audio-samples/s", "ms_per_step": dt2 / args.steps * 1e3, "rtf": dt2 / (s2 / 24000.0),
-            "note": "opt-in mode, NOT the headline configuration: paged K/V stored in fp16 (the reference GPU path's KV dtype), "
-                    "everything else as above; NOT exact on the round-3 goldens (57 of 64 sampled sequences and 2 of 3 greedy prompts "
-                    "equal the fp32 CPU oracle for all 280 ids, profiles/r03_kv_fp16_report.json)"}
-    if rank == 0:
-        print(json.dumps(line), file=json_out, flush=True)
+            os.makedirs(os.path.dirname(os.path.abspath(full_path)), exist_ok=True)
+            with open(full_path, "w") as f:
+                json.dump(line, f, indent=1)
+        except OSError as ex:
+            _log(f"could not write {full_path}: {ex}")
+            full_path = None
+        print("[bench full] " + json.dumps(line), file=sys.stderr, flush=True)
+        comp = compact(line, full_path)
+        txt = json.dumps(comp, separators=(",", ":"))
+        _log(f"compact line: {len(txt)} bytes")
+        print(txt, file=json_out, flush=True)
     eng.close()
     if use_dist:
         torch.distributed.destroy_process_group()

@@ -334,3 +334,33 @@ def test_poll_views_of_the_result_block_equal_owned_copies(ctx, dims):
             assert np.array_equal(v["tokens"], o["tokens"]) and np.array_equal(v["wav"], o["wav"])
         for v in views:
             e.release(v["seq_id"])
+
+
+def test_profile_mode_changes_nothing_but_the_statistics(ctx, dims):
+    """aur_set_profile: the replay batches that time the decode kernels write to scratch only — ids, latents and audio of a ragged,
+    over-subscribed, sampled workload are bit-identical with profile mode on and off, and the per-kind statistics are filled."""
+    e, _, _, _ = ctx
+
+    def run():
+        for k in range(5):
+            e.submit(make_synthetic_text_ids(dims, n_text=9 + 7 * k, seed=40 + k), SPK_KEY, temperature=(0.0 if k == 0 else 0.8), top_p=0.9,
+                     top_k=40, repetition_penalty=5.0, max_tokens=12 + 5 * k, seed=77 + k, ignore_stop=True)
+        return sorted(e.run_until_done(), key=lambda o: o["seq_id"])
+    base = run()
+    e.set_profile(2)
+    e.reset_stats()
+    prof = run()
+    st = e.stats()
+    e.set_profile(0)
+    assert len(base) == len(prof) == 5
+    for a, b in zip(base, prof):
+        assert a["tokens"].tolist() == b["tokens"].tolist()
+        assert np.array_equal(a["wav"], b["wav"]) and np.array_equal(a["latents"], b["latents"])
+    n_layer = e.n_layer
+    assert st["attn_launches"] > 0 and st["attn_launches"] % n_layer == 0 and st["attn_ms"] > 0
+    assert all(n > 0 and n % n_layer == 0 for n in st["gemm_kind_launches"]) and all(t > 0 for t in st["gemm_kind_ms"])
+    assert st["conv_launches"] > 0 and st["conv_ms"] > 0
+    e.reset_stats()
+    again = run()
+    assert e.stats()["gemm_launches"] == 0                              # off again
+    assert [o["tokens"].tolist() for o in again] == [o["tokens"].tolist() for o in base]

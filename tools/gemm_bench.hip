@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <vector>
 
+#define AUR_GEMM_ALL_SHAPES 1   // the A/B workgroup shapes (8 waves, wide tiles) exist only in this tool
 #include "../auralis_amd/csrc/gpt_kernels.hip"
 
 using namespace aur;
@@ -33,6 +34,7 @@ struct Shape {
 };
 struct Cfg {
     int mt, nw, ntl, prec;
+    bool nt = false;
 };
 
 template <class F>
@@ -53,39 +55,38 @@ static float time_us(hipStream_t st, int iters, F&& f) {
     return ms * 1000.f / iters;
 }
 
-template <int PREC>
+template <int PREC, bool NT>
 static void launch_variant_p(const GemmRowsArgs& a, const Shape& s, const Cfg& c, hipStream_t st) {
-    if (s.ln && s.epi == kEpiQkv) launch_gemm_rows_mt<1, true, kEpiQkv, PREC>(a, c.mt, c.nw, st, c.ntl);
-    else if (s.ln && s.epi == kEpiBiasGelu) launch_gemm_rows_mt<1, true, kEpiBiasGelu, PREC>(a, c.mt, c.nw, st, c.ntl);
-    else if (s.ln && s.epi == kEpiBias) launch_gemm_rows_mt<1, true, kEpiBias, PREC>(a, c.mt, c.nw, st, c.ntl);
-    else if (s.K == 1024 && s.epi == kEpiResidual) launch_gemm_rows_mt<1, false, kEpiResidual, PREC>(a, c.mt, c.nw, st, c.ntl);
-    else if (s.K == 4096 && s.epi == kEpiResidual) launch_gemm_rows_mt<4, false, kEpiResidual, PREC>(a, c.mt, c.nw, st, c.ntl);
-    else if (s.K == 1024 && s.epi == kEpiBias) launch_gemm_rows_mt<1, false, kEpiBias, PREC>(a, c.mt, c.nw, st, c.ntl);
-    else launch_gemm_rows_mt<4, false, kEpiBias, PREC>(a, c.mt, c.nw, st, c.ntl);
+    if (s.ln && s.epi == kEpiQkv) launch_gemm_rows_mt<1, true, kEpiQkv, PREC, NT>(a, c.mt, c.nw, st, c.ntl);
+    else if (s.ln && s.epi == kEpiBiasGelu) launch_gemm_rows_mt<1, true, kEpiBiasGelu, PREC, NT>(a, c.mt, c.nw, st, c.ntl);
+    else if (s.ln && s.epi == kEpiBias) launch_gemm_rows_mt<1, true, kEpiBias, PREC, NT>(a, c.mt, c.nw, st, c.ntl);
+    else if (s.K == 1024 && s.epi == kEpiResidual) launch_gemm_rows_mt<1, false, kEpiResidual, PREC, NT>(a, c.mt, c.nw, st, c.ntl);
+    else if (s.K == 4096 && s.epi == kEpiResidual) launch_gemm_rows_mt<4, false, kEpiResidual, PREC, NT>(a, c.mt, c.nw, st, c.ntl);
+    else if (s.K == 1024 && s.epi == kEpiBias) launch_gemm_rows_mt<1, false, kEpiBias, PREC, NT>(a, c.mt, c.nw, st, c.ntl);
+    else launch_gemm_rows_mt<4, false, kEpiBias, PREC, NT>(a, c.mt, c.nw, st, c.ntl);
     HIP_CHECK(hipGetLastError());
 }
 static void launch_variant(const GemmRowsArgs& a, const Shape& s, const Cfg& c, hipStream_t st) {
-    if (c.prec) launch_variant_p<1>(a, s, c, st);
-    else launch_variant_p<0>(a, s, c, st);
+    if (c.nt) {
+        if (c.prec) launch_variant_p<1, true>(a, s, c, st);
+        else launch_variant_p<0, true>(a, s, c, st);
+    } else {
+        if (c.prec) launch_variant_p<1, false>(a, s, c, st);
+        else launch_variant_p<0, false>(a, s, c, st);
+    }
 }
-
-// Side-stream weight warmer (experiment): one wave per workgroup streams a slice of the next layer's weights
-// with 16-byte loads and drops them; the loads allocate in the Infinity Cache, so the next layer's GEMMs find their tiles there.
-__global__ __launch_bounds__(64) void warm_kernel(const float4* __restrict__ a, long na, const float4* __restrict__ b, long nb,
-                                                  const float4* __restrict__ c, long nc, const float4* __restrict__ d, long nd,
-                                                  float* sink) {
-    float acc = 0.f;
-    const long stride = (long)gridDim.x * 64, t0 = (long)blockIdx.x * 64 + threadIdx.x;
-    auto sweep = [&](const float4* p, long n) {
-        long i = t0;
-        for (; i + 3 * stride < n; i += 4 * stride) {
-            const float4 v0 = p[i], v1 = p[i + stride], v2 = p[i + 2 * stride], v3 = p[i + 3 * stride];
-            acc += v0.x + v1.y + v2.z + v3.w;
-        }
-        for (; i < n; i += stride) acc += p[i].x;
-    };
-    sweep(a, na); sweep(b, nb); sweep(c, nc); sweep(d, nd);
-    if (acc == 1.2345e30f) *sink = acc;
+// the shapes the engine used until round 3 at any M (for the small-M A/B): QKV 16 x 48, FC 16 x 32 at M <= 16, 16 x 16 otherwise
+static Cfg r03_policy(int M, const Shape& s, int prec) {
+    Cfg c{1, 16, 1, prec, false};
+    if (s.ln) {
+        if (s.N % 48 == 0 && s.N < 4096) c.ntl = 3;
+        else if (s.N % 32 == 0) { c.ntl = 2; c.mt = M > 16 ? 2 : 1; }
+    }
+    return c;
+}
+static Cfg r04_policy(int M, const Shape& s, int prec) {
+    const GemmRowsShape g = gemm_rows_shape(M, s.N, s.K, s.ln);
+    return Cfg{g.mt, g.nw, g.ntl, prec, g.nt};
 }
 
 int main(int argc, char** argv) {
@@ -176,6 +177,10 @@ int main(int argc, char** argv) {
             if (s.K == 1024 && s.N % 32 == 0) cfgs.push_back({1, 16, 2, 0});
             if (s.K == 1024 && s.N % 32 == 0) cfgs.push_back({1, 16, 2, 1});
         }
+        if (M <= 16) {   // one row group: every weight tile has one reader -> non-temporal weight loads
+            cfgs.push_back({1, 16, 1, 1, true});
+            cfgs.push_back({1, 16, 1, 0, true});
+        }
         std::vector<float> ref;
         for (const Cfg& c : cfgs) {
             GemmRowsArgs a{};
@@ -227,8 +232,8 @@ int main(int argc, char** argv) {
                 en_us.push_back((double)(hp[g * 8 + 5] - t_min) / 100.0);
             }
             std::sort(en_us.begin(), en_us.end());
-            printf("%s M=%d rows/wg=%2d cols/wg=%2d waves=%2d prec=%d wgs=%4d : %6.2f us/launch | max|d| vs ref %.2e (max|ref| %.2e) | 10-ns ticks: span %5lld issue %4.0f ln+wait %5.0f mfma %5.0f bar %4.0f epi %4.0f | ends p10 %.2f p50 %.2f max %.2f\n",
-                   s.name, M, 16 * c.mt, 16 * c.ntl, c.nw, c.prec, nwg, us, maxd, maxr, t_max - t_min, ph[0], ph[1], ph[2], ph[3], ph[4],
+            printf("%s M=%d rows/wg=%2d cols/wg=%2d waves=%2d prec=%d nt=%d wgs=%4d : %6.2f us/launch | max|d| vs ref %.2e (max|ref| %.2e) | 10-ns ticks: span %5lld issue %4.0f ln+wait %5.0f mfma %5.0f bar %4.0f epi %4.0f | ends p10 %.2f p50 %.2f max %.2f\n",
+                   s.name, M, 16 * c.mt, 16 * c.ntl, c.nw, c.prec, (int)c.nt, nwg, us, maxd, maxr, t_max - t_min, ph[0], ph[1], ph[2], ph[3], ph[4],
                    en_us[en_us.size() / 10], en_us[en_us.size() / 2], en_us.back());
             fflush(stdout);
         }
@@ -253,54 +258,39 @@ int main(int argc, char** argv) {
         float* act = dalloc((size_t)256 * 4096, 0.5f, 22);
         float* att = dalloc((size_t)256 * 1024, 0.5f, 23);
         float* qb = dalloc((size_t)256 * 1024, 0.f, 24);
-        hipStream_t st2;
-        HIP_CHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
-        std::vector<hipEvent_t> evl(n_layers);
-        for (auto& e : evl) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        int warm_wgs = 0;   // 0 = no warmer; otherwise workgroups (one wave each) of the warmer launched per layer on st2
+        Cfg (*policy)(int, const Shape&, int) = r04_policy;
         auto chain = [&](bool attn, int prec) {
             for (int l = 0; l < n_layers; ++l) {
-                if (warm_wgs && l + 1 < n_layers) {   // at the start of layer l: warm layer l + 1's weights on the side stream
-                    HIP_CHECK(hipEventRecord(evl[l], st));
-                    HIP_CHECK(hipStreamWaitEvent(st2, evl[l], 0));
-                    if (warm_wgs > 0) hipLaunchKernelGGL(warm_kernel, dim3(warm_wgs), dim3(64), 0, st2,
-                                       reinterpret_cast<const float4*>(wq[l + 1]), (long)3072 * 1024 / 4, reinterpret_cast<const float4*>(wp[l + 1]), (long)1024 * 1024 / 4,
-                                       reinterpret_cast<const float4*>(wf[l + 1]), (long)4096 * 1024 / 4, reinterpret_cast<const float4*>(w2[l + 1]), (long)4096 * 1024 / 4, qb);
-                }
                 float* kvl = kv + (size_t)l * kv_blocks * kKvBlockElems;
                 GemmRowsArgs a{};
                 a.M = M; a.prec = prec; a.eps = 1e-5f; a.X = hres; a.xmt = MTT; a.Wt = wq[l]; a.N = 3072; a.K = 1024; a.bias = bias; a.ln_c1 = gamma;
                 a.stats_in = dstats; a.out = qb; a.ldo = 1024; a.kv_layer = kvl; a.row_slot = dslot; a.slot_kvpos = dpos; a.block_tables = dbt; a.row_meta = drm;
                 a.max_blocks = 66;
-                launch_gemm_rows(a, true, kEpiQkv, st);
+                launch_variant(a, shapes[0], policy(M, shapes[0], prec), st);
                 if (attn) launch_paged_attention(qb, kvl, dslot, nullptr, dpos, dbt, 66, att, M, st, MTT, false, drm);
                 a = GemmRowsArgs{};
                 a.M = M; a.prec = prec; a.X = att; a.xmt = MTT; a.Wt = wp[l]; a.N = 1024; a.K = 1024; a.bias = bias; a.out = hres; a.omt = MTT; a.stats_out = dstats + 128 * 64;
-                launch_gemm_rows(a, false, kEpiResidual, st);
+                launch_variant(a, shapes[1], policy(M, shapes[1], prec), st);
                 a = GemmRowsArgs{};
                 a.M = M; a.prec = prec; a.eps = 1e-5f; a.X = hres; a.xmt = MTT; a.Wt = wf[l]; a.N = 4096; a.K = 1024; a.bias = bias; a.ln_c1 = gamma;
                 a.stats_in = dstats; a.out = act; a.omt = MTT;
-                launch_gemm_rows(a, true, kEpiBiasGelu, st);
+                launch_variant(a, shapes[2], policy(M, shapes[2], prec), st);
                 a = GemmRowsArgs{};
                 a.M = M; a.prec = prec; a.X = act; a.xmt = MTT; a.Wt = w2[l]; a.N = 1024; a.K = 4096; a.bias = bias; a.out = hres; a.omt = MTT; a.stats_out = dstats + 128 * 64;
-                launch_gemm_rows(a, false, kEpiResidual, st);
+                launch_variant(a, shapes[3], policy(M, shapes[3], prec), st);
             }
         };
-        for (int ww : {-1, 64, 256}) {   // -1: the event record / wait per layer alone   // the warmer experiment: split arithmetic, attention in the chain
-            warm_wgs = ww;
-            const float us = time_us(st, 20, [&] { chain(true, 1); });
-            HIP_CHECK(hipStreamSynchronize(st2));
-            printf("chain with a side-stream weight warmer (%d waves, one layer ahead): %.1f us per layer (%.3f ms per step)\n", ww, us / n_layers, us / 1000);
-            fflush(stdout);
+        for (int pol = 0; pol < 2; ++pol) {
+            policy = pol ? r04_policy : r03_policy;
+            for (int attn : {0, 1})
+                for (int prec : {0, 1}) {
+                    const float us = time_us(st, 20, [&] { chain(attn != 0, prec); });
+                    printf("chain of 30 x (qkv,%s proj, fc, proj2) M=%d shapes=%s prec=%d: %.1f us per layer (%.3f ms per step)\n",
+                           attn ? " attention," : "", M, pol ? "r04" : "r03", prec, us / n_layers, us / 1000);
+                    fflush(stdout);
+                }
+            if (M > 16) break;   // the two policies differ only at M <= 16
         }
-        warm_wgs = 0;
-        for (int attn : {0, 1})
-            for (int prec : {0, 1}) {
-                const float us = time_us(st, 20, [&] { chain(attn != 0, prec); });
-                printf("chain of 30 x (qkv,%s proj, fc, proj2) M=%d shapes=%s prec=%d: %.1f us per layer (%.3f ms per step)\n",
-                       attn ? " attention," : "", M, getenv("AUR_GEMM_SHAPES") ? getenv("AUR_GEMM_SHAPES") : "r03", prec, us / n_layers, us / 1000);
-                fflush(stdout);
-            }
     }
     return 0;
 }

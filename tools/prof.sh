@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout ${PROF_TIMEOUT:-300} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- \
-    python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-throughput-mode "$@" > $OUT/stdout.log 2>&1
+    python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-side --out $OUT/bench_full.json "$@" > $OUT/stdout.log 2>&1
 echo "rocprofv3 rc=$?"
 grep -h '^{"metric"' $OUT/stdout.log | cut -c1-400
 find $OUT -type f | head -20
