@@ -118,6 +118,18 @@ def make_synthetic_xtts(dims: XTTSDims, seed: int = 1234, gpt_sd: Optional[Dict[
     return sd
 
 
+def make_loud_vocoder(xtts_sd: Dict[str, Tensor], up_gain: float = 3.0, post_gain: float = 1.5) -> Dict[str, Tensor]:
+    """The synthetic vocoder at speech amplitude.  Default conv init gives a quiet waveform (RMS ~0.04), where the "1 % of the
+    signal" bar binds before the north-star 1e-3 absolute one; here the weight-norm gains of the four transposed convs are raised
+    (every stage's activations grow by `up_gain`) and `conv_post` by `post_gain`, which brings the output to the RMS of real
+    speech (0.12 with the defaults, peaks 0.5) and the fp16-stored residual stream / MRF sums to correspondingly larger magnitudes.  Returns a copy."""
+    sd = {k: v.clone() for k, v in xtts_sd.items()}
+    for i in range(4):
+        sd[VOC_PREFIX + f"ups.{i}.parametrizations.weight.original0"] *= up_gain
+    sd[VOC_PREFIX + "conv_post.weight"] *= post_gain
+    return sd
+
+
 def conditioning_param_shapes(dims: XTTSDims) -> Dict[str, tuple]:
     """Names/shapes of the once-per-speaker modules inside xtts-v2.safetensors:
     conditioning_encoder (Conv1d 80->1024 + 6 attention blocks), conditioning_perceiver (32 latents, 2 x (cross-attn

@@ -141,3 +141,52 @@ def test_vocoder_lds_dma_staging_equals_register_staging(ctx16, monkeypatch):
             assert np.array_equal(x, y)
     finally:
         e_reg.close()
+
+
+# ---- the reference class at the BASELINE utterance length, and at speech amplitude --------------------------------------
+def test_vocoder_reference_golden_at_baseline_length(ctx, ctx16):
+    """tests/golden/vocoder_ref_T280.npz: the waveform the reference's own HifiDecoder produces for 280 latent frames (312 064
+    samples).  Exact-f32 mode ~1e-8; the default fp16 mode (fp16 MFMA inputs, ResBlock tensors stored as halves, fused rounds)
+    inside the north-star bar — the fp16 path pinned to the reference itself at the size the bench runs."""
+    from tests.test_oracle_vocoder import golden_T280_latents
+    lat, g = golden_T280_latents()
+    e32, _, _ = ctx
+    e16, _, _ = ctx16
+    w32 = e32.vocode(lat.numpy(), None, SPK_KEY)[0]
+    err32, _ = _check(w32, g["wav"])
+    assert err32 < 1e-5, err32
+    w16 = e16.vocode(lat.numpy(), None, SPK_KEY)[0]
+    err16, sig = _check(w16, g["wav"])
+    print(f"fp16 vocoder vs reference class at T=280: rms err {err16:.3e} signal rms {sig:.3e} ratio {err16 / sig:.3e}")
+
+
+def test_vocoder_at_speech_amplitude(monkeypatch):
+    """checkpoint.make_loud_vocoder: output RMS 0.12 (peaks 0.5), where the north-star 1e-3 ABSOLUTE bar is the binding one.
+    Golden from the reference's HifiDecoder on the same weights.  The default fp16 mode stores the residual stream and the MRF
+    sums as halves (the reference keeps the MRF sum fp32, hifigan_decoder.py:253-255); AUR_XT_F16=0 keeps them fp32 — both are
+    measured against the reference and both must pass."""
+    from auralis_amd._lib import NativeEngine
+    from auralis_amd.checkpoint import make_loud_vocoder
+    from auralis_amd.weights import pack_all
+    from tests.gpu_util import packed_weights
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vocoder_loud_T47.npz"))
+    _, gpt_sd, xtts_sd = packed_weights(1)
+    packed = pack_all(gpt_sd, make_loud_vocoder(xtts_sd, float(g["up_gain"]), float(g["post_gain"])))
+    errs = {}
+    for name, env, f16 in (("fp32", None, False), ("fp16, halves in HBM", None, True), ("fp16 inputs, fp32 in HBM", "0", True)):
+        if env is not None:
+            monkeypatch.setenv("AUR_XT_F16", env)
+        e = NativeEngine(n_layer=1, max_seqs=2, vocoder_fp16=f16)
+        try:
+            e.load_weights(packed)
+            e.set_conditioning(SPK_KEY, np.zeros((32, 1024), np.float32), g["speaker"].reshape(512))
+            wav = e.vocode(g["latents"], None, SPK_KEY)[0]
+        finally:
+            e.close()
+            monkeypatch.delenv("AUR_XT_F16", raising=False)
+        err, sig = rms(wav - g["wav"]), rms(g["wav"])
+        errs[name] = err
+        assert sig > 0.1
+        assert err <= 1e-3 and err <= 1e-2 * sig, (name, err, sig)
+    print("speech-amplitude vocoder, RMS error against the reference class: " + ", ".join(f"{k}: {v:.3e}" for k, v in errs.items()))
+    assert errs["fp32"] < 1e-5

@@ -65,3 +65,31 @@ def test_oracle_matches_live_reference(xtts_sd, conditioning):
     w = O.vocoder_effective_weights(xtts_sd)
     got = O.hifi_decoder_forward(w, lat, conditioning[1])
     assert (got - ref).abs().max().item() < 1e-6
+
+
+def golden_T280_latents():
+    """The 280-frame latents of tests/golden/vocoder_ref_T280.npz, regenerated from the stored seed and checked against the stored sums."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vocoder_ref_T280.npz"))
+    lat = torch.randn(1, 280, 1024, generator=torch.Generator().manual_seed(int(g["latents_seed"])))
+    assert abs(lat.double().sum().item() - float(g["latents_sum"])) < 1e-6 and abs(lat.double().abs().sum().item() - float(g["latents_abs_sum"])) < 1e-6, \
+        "torch's CPU generator changed: regenerate the fixture (python -m oracle.make_golden)"
+    return lat, g
+
+
+def test_oracle_matches_reference_golden_at_baseline_length(xtts_sd):
+    """280 latent frames -> 312 064 samples: the restatement against the reference class at the size the bench runs."""
+    lat, g = golden_T280_latents()
+    wav = O.hifi_decoder_forward(O.vocoder_effective_weights(xtts_sd), lat, torch.from_numpy(g["speaker"])).reshape(-1)
+    assert wav.numel() == 312064 == g["wav"].size
+    assert (wav - torch.from_numpy(g["wav"])).abs().max().item() < 1e-6
+
+
+def test_oracle_matches_reference_golden_loud(xtts_sd):
+    """speech-amplitude synthetic vocoder (checkpoint.make_loud_vocoder): output RMS 0.12"""
+    from auralis_amd.checkpoint import make_loud_vocoder
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vocoder_loud_T47.npz"))
+    sd = make_loud_vocoder(xtts_sd, float(g["up_gain"]), float(g["post_gain"]))
+    wav = O.hifi_decoder_forward(O.vocoder_effective_weights(sd), torch.from_numpy(g["latents"]), torch.from_numpy(g["speaker"])).reshape(-1)
+    ref = torch.from_numpy(g["wav"])
+    assert ref.pow(2).mean().sqrt().item() > 0.1
+    assert (wav - ref).abs().max().item() < 5e-6
