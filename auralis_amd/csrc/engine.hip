@@ -202,6 +202,9 @@ public:
         voc_cond_.ensure((size_t)cfg_.max_speakers * kCondStride * sizeof(float));
         zero_bias_.ensure(4096 * sizeof(float));
         HIP_CHECK(hipMemsetAsync(zero_bias_.p, 0, 4096 * sizeof(float), st_));
+        ksp_buf_.ensure((size_t)kGemmKspTiles * 16 * 256 * sizeof(float));   // K-split partial tiles of the small-M mlp projection
+        ksp_cnt_.ensure((size_t)kGemmKspTiles * sizeof(unsigned));
+        HIP_CHECK(hipMemsetAsync(ksp_cnt_.p, 0, (size_t)kGemmKspTiles * sizeof(unsigned), st_));
         h_block_tables_.assign((size_t)(S + 1) * kMaxBlocks, 0);
         spk_info_.assign(cfg_.max_speakers, SpeakerInfo{});
         if (const char* e = getenv("AUR_SHARE_PREFIX")) share_prefix_ = atoi(e) != 0;
@@ -609,6 +612,7 @@ public:
         (void)hipStreamSynchronize(st_);
         (void)hipStreamSynchronize(st_voc_);
         (void)hipGetLastError();
+        (void)hipMemsetAsync(ksp_cnt_.p, 0, (size_t)kGemmKspTiles * sizeof(unsigned), st_);   // an aborted K-split launch may have left tickets behind
         infl_.on = false;
         just_finished_.clear();
         last_active_.clear();
@@ -883,6 +887,7 @@ public:
         }
         a.X = dx.as<float>(); a.xmt = mtt; a.Wt = dwt.as<float>(); a.M = M; a.N = N; a.K = K;
         a.eps = 1e-5f; a.prec = gemm_prec_;
+        if ((long)((M + 15) / 16) * (N / 16) <= kGemmKspTiles) { a.ksp_buf = ksp_buf_.as<float>(); a.ksp_cnt = ksp_cnt_.as<unsigned>(); }
         a.stats_in = ln ? dst.as<float2>() : nullptr;
         a.out = dout.as<float>(); a.ldo = N; a.omt = mtt;
         launch_gemm_rows(a, ln, (GemmRowsEpi)epi, st_);
@@ -1156,6 +1161,7 @@ private:
         float* h = w.h.as<float>();
         GemmRowsArgs a{};
         a.M = M; a.prec = gemm_prec_; a.xmt = mtt;
+        a.ksp_buf = ksp_buf_.as<float>(); a.ksp_cnt = ksp_cnt_.as<unsigned>();
         if (kind == 0) {
             a.eps = 1e-5f; a.X = h; a.Wt = L.tqkv; a.N = 3 * kHidden; a.K = kHidden; a.bias = L.qkv_c2;
             a.ln_c1 = L.qkv_c1; a.stats_in = w.stats.as<float2>(); a.out = redirect ? prof_q_.as<float>() : w.qbuf.as<float>(); a.ldo = kHidden;
@@ -1256,6 +1262,9 @@ private:
         return event_overhead_ms_;
     }
     void collect_gemm_events() {
+        // the replay batches sit behind the step's token read-back on the stream (and, with the pipelined decode, the next step's
+        // batches may already be queued behind them): wait for the last one recorded
+        if (n_gemm_events_) HIP_CHECK(hipEventSynchronize(gemm_events_[n_gemm_events_ - 1].b));
         const float ovh = n_gemm_events_ ? event_pair_overhead_ms() : 0.f;
         if (n_gemm_events_) stats_.event_pair_overhead_ms = ovh;
         for (size_t i = 0; i < n_gemm_events_; ++i) {
@@ -2020,6 +2029,7 @@ private:
     size_t n_gemm_events_ = 0;
     int profile_every_ = kProfileEvery;
     DevBuf prof_q_, prof_h_, prof_stats_, prof_act_, prof_kv_;   // output scratch of profile_replay
+    DevBuf ksp_buf_, ksp_cnt_;   // GemmRowsArgs::ksp_buf / ksp_cnt
     double step_kv_tokens_ = 0.0;       // sum of context lengths of the step being launched (profile accounting)
     long decode_step_count_ = 0;
     float event_overhead_ms_ = -1.f;

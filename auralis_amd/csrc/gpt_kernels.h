@@ -67,13 +67,23 @@ struct GemmRowsArgs {
                          // terms, six bf16 MFMAs per product with fp32 accumulation (same accuracy class as an fp32 dot product,
                          // not bitwise an fma chain; 2.7x less matrix-pipe time).  aur_config.gemm_f32_exact selects 0.
     long long* prof;     // optional (tools/gemm_bench): 8 wall_clock64 stamps (100 MHz, device-wide) per workgroup, written by wave 0
+    // K split over kGemmKsp workgroups per output tile (the K = 4096 projection at M <= 16 rows, where one workgroup per tile
+    // leaves 3/4 of the CUs idle): every workgroup runs 16 / kGemmKsp of the 16 K-slices (each slice = the MFMA chain of one wave
+    // of the unsplit kernel, bit for bit), publishes its per-wave partial tiles in ksp_buf, takes a ticket on ksp_cnt[tile], and
+    // the workgroup that draws the last ticket sums the 16 partials in wave order 0..15 -- the unsplit kernel's order -- and runs
+    // the epilogue.  Both null = unsplit.
+    float* ksp_buf;      // [tiles][16][256] floats
+    unsigned* ksp_cnt;   // [tiles], zero before the first launch (the last arriver resets its counter)
 };
+constexpr int kGemmKsp = 4;
+constexpr int kGemmKspTiles = 128;   // output tiles the scratch is sized for: ksp_buf = kGemmKspTiles * 16 * 256 floats, ksp_cnt = kGemmKspTiles
 void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream_t st);
 // Workgroup shape the launcher picks for a GEMM kind at M rows: 16*mt rows x 16*ntl columns, nw waves (K split nw ways);
 // nt: non-temporal weight loads (M <= 16: every weight tile has one reader).
 struct GemmRowsShape {
     int mt, nw, ntl;
     bool nt;
+    int ksp;   // workgroups per output tile along K (1 = unsplit); > 1 needs GemmRowsArgs::ksp_buf / ksp_cnt
 };
 GemmRowsShape gemm_rows_shape(int M, int N, int K, bool ln);
 

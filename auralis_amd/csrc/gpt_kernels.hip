@@ -423,8 +423,20 @@ __device__ __forceinline__ void split3_bf16(const f32x4& x0, const f32x4& x1, bf
 // NT: the packed weight tiles are requested with the non-temporal policy.  For M <= 16 rows a tile is read by exactly one
 // workgroup (one row group): streamed weights that nobody re-reads should not displace the activations in L2.  (At M = 64 the
 // four row groups of a column tile share its weights through L2 and NT measured neutral, profiles/r03_gemm_nt_weights.log.)
-template <int MT, int KCH, bool LN, int EPI, int NW, int NTL = 1, int PREC = 0, bool NT = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, NW == 16 ? 4 : (NW == 8 ? 6 : 8))))
+// KSP: workgroups per output tile along K (GemmRowsArgs::ksp_buf).  The workgroup has NW waves and runs K-slices KSP * ... of the
+// NW * KSP slices: wave w of part p is slice p * NW + w, with exactly the loads and MFMAs wave p * NW + w of the unsplit kernel runs.
+// sc1 (write-through) stores publish the partial tiles, a drained vmcnt and a relaxed agent-scope ticket order them, the last
+// arriver reads them with sc1 loads (MI355X_MICROARCH.md, inter-workgroup visibility: "sc0 sc1 stores and loads both sides").
+__device__ __forceinline__ void store_sc1(float* p, const f32x4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ float load_sc1(const float* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int MT, int KCH, bool LN, int EPI, int NW, int NTL = 1, int PREC = 0, bool NT = false, int KSP = 1>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, NW == 16 ? 4 : (NW == 8 ? 6 : (KSP > 1 ? 2 : 8)))))
 void gemm_rows_kernel(GemmRowsArgs a) {
     // (amdgpu_waves_per_eu: without the cap hipcc schedules for 8 waves per SIMD — 64 VGPRs — and gets there by issuing the tile
     // loads two at a time between the MFMAs: 5-7 dependent memory round trips per launch instead of one.  A 16-wave workgroup
@@ -433,10 +445,12 @@ void gemm_rows_kernel(GemmRowsArgs a) {
     // its L1 are shared by NTL column tiles; the K order of every output element is the same for every NTL (bitwise equal)
     static_assert(!LN || KCH == 1, "LN prologue needs the whole row in one chunk");
     static_assert(NW == 4 || NW == 8 || NW == 16, "waves per workgroup");
-    constexpr int NB = 64 / NW;   // 16-deep K blocks per wave per 1024-deep chunk
+    static_assert(KSP == 1 || (!LN && MT == 1 && NTL == 1 && NW * KSP == 16), "K split: 16 slices, one 16 x 16 tile, no LayerNorm fold");
+    constexpr int NB = 64 / (NW * KSP);   // 16-deep K blocks per wave per 1024-deep chunk
     __shared__ __attribute__((aligned(16))) float red[NW][MT * NTL * 256];
     __shared__ float rs[LN ? 16 * MT : 1][2];   // (mean, rstd) of the workgroup's rows
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wg = KSP > 1 ? (int)blockIdx.y * NW + w : w;   // this wave's K-slice among the NW * KSP slices
     const int j = lane & 15, q = lane >> 4;
     // workgroup -> (column tile, row group): the row groups of one column tile get ids 8 apart (same XCD, adjacent in
     // dispatch order) so that the tile's weights leave HBM once and the other groups hit them in that XCD's L2
@@ -464,7 +478,7 @@ void gemm_rows_kernel(GemmRowsArgs a) {
     // loads in K-block order (for PREC 1 in pairs of blocks): the MFMAs of block b need exactly the first (b + 1) / NB of the
     // chunk's loads, and loads return in order
     auto load_chunk = [&](int c, int buf) {
-        const int kb0 = c * 64 + NB * w;
+        const int kb0 = c * 64 + NB * wg;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
 #pragma unroll
@@ -591,10 +605,43 @@ void gemm_rows_kernel(GemmRowsArgs a) {
     if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 3] = (long long)wall_clock64();
     __syncthreads();
     if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 4] = (long long)wall_clock64();
+    if constexpr (KSP > 1) {
+        // publish this workgroup's NW partial tiles (thread e: element e of every one of them), take a ticket; only the last
+        // arriver goes on.  red[] is reused for the ticket: every wave has read its elements before the barrier below.
+        const int tile = mgrp * n_tiles + ntile;
+        float* pb = a.ksp_buf + ((long)tile * 16 + (long)blockIdx.y * NW) * 256;
+        {
+            const int ww = tid >> 6, l4 = (tid & 63) * 4;   // one float4 (elements l4 .. l4 + 3 of partial ww) per thread
+            store_sc1(pb + ww * 256 + l4, *reinterpret_cast<const f32x4*>(&red[ww][l4]));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) reinterpret_cast<unsigned*>(&rs[0][0])[0] = __hip_atomic_fetch_add(a.ksp_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (reinterpret_cast<const unsigned*>(&rs[0][0])[0] != KSP - 1) return;
+        if (tid == 0) __hip_atomic_store(a.ksp_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
     if (tid < NE) {
-        float t = red[0][e];
+        float t;
+        if constexpr (KSP > 1) {
+            const float* pa = a.ksp_buf + (long)(mgrp * n_tiles + ntile) * 16 * 256 + e;
+            float pv[16];
 #pragma unroll
-        for (int ww = 1; ww < NW; ++ww) t += red[ww][e];
+            for (int ww = 0; ww < 16; ++ww) pv[ww] = load_sc1(pa + ww * 256);
+            // (the loads are asm: the wait must name their destinations, or the sums below may be scheduled in front of it)
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]), "+v"(pv[7]), "+v"(pv[8]),
+                           "+v"(pv[9]), "+v"(pv[10]), "+v"(pv[11]), "+v"(pv[12]), "+v"(pv[13]), "+v"(pv[14]), "+v"(pv[15])
+                         :
+                         : "memory");
+            t = pv[0];
+#pragma unroll
+            for (int ww = 1; ww < 16; ++ww) t += pv[ww];
+        } else {
+            t = red[0][e];
+#pragma unroll
+            for (int ww = 1; ww < NW; ++ww) t += red[ww][e];
+        }
         const bool ok = em < a.M;
         if (LN) t = rs[em - m0][1] * (t - rs[em - m0][0] * ec1);
         t += ebias;
@@ -689,11 +736,18 @@ static void launch_gemm_rows_mt(const GemmRowsArgs& a, int mt, int nw, hipStream
 //   LN GEMMs, N = 4096 (FC) : 32 rows x 32 columns  -> 128 x ceil(M/32)
 //   N = 1024 (proj, proj2), head: 16 rows x 16 columns
 // M <= 16 (one row group; a single utterance is M = 1) — the launch is pure weight streaming and every weight tile has exactly one
-//   reader: 16 x 16 tiles everywhere (QKV 192, FC 256 workgroups instead of 64 / 128) with non-temporal weight loads.
+//   reader: 16 x 16 tiles everywhere (QKV 192, FC 256 workgroups instead of 64 / 128; chain of 30 layers at M = 1: 29.5 vs 34.0 us
+//   per layer, profiles/r04_gemm_bench_m1.log), non-temporal weight loads for the 16.8 MB matrices.
 GemmRowsShape gemm_rows_shape(int M, int N, int K, bool ln) {
-    GemmRowsShape s{1, 16, 1, false};
-    if (M <= 16) {
+    GemmRowsShape s{1, 16, 1, false, 1};
+    if (M <= 16 && K == 4096 && !ln) {
+        // the K = 4096 projection streams 16.8 MB through 64 column tiles: four workgroups of four waves per tile (256
+        // workgroups), partial tiles combined by the last arriver in the unsplit kernel's order (GemmRowsArgs::ksp_buf)
+        s.nw = 4;
+        s.ksp = kGemmKsp;
         s.nt = true;
+    } else if (M <= 16) {
+        s.nt = (long)N * K >= 4L * 1024 * 1024;   // FC, proj2 (-0.3 us each at M = 1; proj and the head measured 0.7 us SLOWER with it)
     } else if (ln) {
         if (N % 48 == 0 && N < 4096) {
             s.ntl = 3;
@@ -704,6 +758,18 @@ GemmRowsShape gemm_rows_shape(int M, int N, int K, bool ln) {
     }
     (void)K;
     return s;
+}
+
+// K = 4096, K split over kGemmKsp workgroups of 4 waves per 16 x 16 output tile (M <= 16 rows)
+template <int PREC>
+static void launch_gemm_rows_ksp(const GemmRowsArgs& a, GemmRowsEpi epi, hipStream_t st) {
+    static_assert(kGemmKsp == 4, "16 K-slices = 4 workgroups of 4 waves");
+    AUR_REQUIRE(a.K == 4096 && a.N % 16 == 0 && a.ksp_buf && a.ksp_cnt, "gemm_rows K split: K == 4096 and the partial-tile scratch");
+    const int n_tiles = a.N / 16, n_grp = (a.M + 15) / 16;
+    const dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * n_grp), kGemmKsp);
+    if (epi == kEpiResidual) hipLaunchKernelGGL((gemm_rows_kernel<1, 4, false, kEpiResidual, 4, 1, PREC, true, kGemmKsp>), grid, dim3(256), 0, st, a);
+    else if (epi == kEpiBias) hipLaunchKernelGGL((gemm_rows_kernel<1, 4, false, kEpiBias, 4, 1, PREC, true, kGemmKsp>), grid, dim3(256), 0, st, a);
+    else throw InvalidArgument("gemm_rows K split: bias or residual epilogue");
 }
 
 template <int PREC, bool NT>
@@ -723,9 +789,17 @@ void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream
     AUR_REQUIRE((epi != kEpiBiasGelu && epi != kEpiResidual) || a.omt >= (a.M + 15) / 16, "gemm_rows: packed output rows");
     AUR_REQUIRE(!ln || (a.K == 1024 && a.stats_in && a.ln_c1 && a.bias), "gemm_rows: a LayerNorm-folded GEMM needs K == 1024, the row statistics, c1 and c2");
     AUR_REQUIRE(!a.stats_out || (epi == kEpiResidual && a.N == 1024), "gemm_rows: statistics are emitted for 1024-wide residual rows");
-    const GemmRowsShape s = gemm_rows_shape(a.M, a.N, a.K, ln);
+    GemmRowsShape s = gemm_rows_shape(a.M, a.N, a.K, ln);
     trace_launch("gemm_rows_kernel");
     AUR_REQUIRE(a.prec == 0 || a.prec == 1, "gemm_rows: prec is 0 (exact f32 MFMA) or 1 (bf16 x 3 split)");
+    if (s.ksp > 1 && !(a.ksp_buf && a.ksp_cnt)) s = GemmRowsShape{1, 16, 1, true, 1};   // no scratch given: the unsplit kernel (same bits)
+    if (s.ksp > 1) {
+        AUR_REQUIRE((long)((a.M + 15) / 16) * (a.N / 16) <= kGemmKspTiles, "gemm_rows K split: more output tiles than the scratch holds");
+        if (a.prec == 1) launch_gemm_rows_ksp<1>(a, epi, st);
+        else launch_gemm_rows_ksp<0>(a, epi, st);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (a.prec == 1) {
         if (s.nt) launch_gemm_rows_prec<1, true>(a, ln, epi, s, st);
         else launch_gemm_rows_prec<1, false>(a, ln, epi, s, st);
@@ -842,13 +916,17 @@ void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, 
 // Paged causal attention: one workgroup per (row, head).  16 lanes x float4 (fp32 pool) or 8 lanes x 8 halves (fp16 pool) span
 // the 64-wide head, so one wave instruction covers 4 / 8 consecutive cached tokens (1 KiB contiguous); 4 waves stride the
 // context.  Scores are reduced with wavefront shuffles; online softmax per lane group; groups merged through LDS.
-template <bool KVH>
+// UN = token steps in flight per workgroup iteration (each step = 16 tokens of the fp32 pool).  4 when the launch fills the chip
+// (8 measured slower at 64 rows: registers); 16 when only a few (row, head) workgroups exist (M <= 16 rows: a single utterance
+// is 16 workgroups), where a launch is a chain of dependent memory round trips -- with 256 tokens per iteration a 243-token
+// context is ONE round trip instead of four.  A partial accumulator (wave, lane group) still sees its tokens in the same order,
+// so the result is bitwise the same for every UN.
+template <bool KVH, int UN>
 __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __restrict__ qbuf, const void* __restrict__ kv_layer_v,
                                                               const int* __restrict__ row_slot, const int* __restrict__ row_pos,
                                                               const int* __restrict__ slot_kvpos,
                                                               const int* __restrict__ block_tables, int max_blocks,
                                                               float* __restrict__ out, int out_mtt, const int* __restrict__ row_meta) {
-    constexpr int UN = 4;                    // token steps in flight per workgroup iteration (8 measured slower: registers)
     constexpr int LPT = KVH ? 8 : 16;        // lanes per token
     constexpr int EPL = kHeadDim / LPT;      // elements per lane
     constexpr int TPW = 64 / LPT;            // tokens per wave instruction
@@ -1068,12 +1146,14 @@ void launch_paged_attention(const float* qbuf, const void* kv_layer, const int* 
                             const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
                             hipStream_t st, int out_mtt, bool kv_half, const int* row_meta) {
     trace_launch("paged_attention_kernel");
-    if (kv_half)
-        hipLaunchKernelGGL(paged_attention_kernel<true>, dim3(M, kHeads), dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos,
-                           slot_kvpos, block_tables, max_blocks, out, out_mtt, row_meta);
-    else
-        hipLaunchKernelGGL(paged_attention_kernel<false>, dim3(M, kHeads), dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos,
-                           slot_kvpos, block_tables, max_blocks, out, out_mtt, row_meta);
+#define AUR_PA(KVH_, UN_) hipLaunchKernelGGL((paged_attention_kernel<KVH_, UN_>), dim3(M, kHeads), dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos, \
+                                             slot_kvpos, block_tables, max_blocks, out, out_mtt, row_meta)
+    if (M <= 16) {
+        if (kv_half) AUR_PA(true, 8); else AUR_PA(false, 16);
+    } else {
+        if (kv_half) AUR_PA(true, 4); else AUR_PA(false, 4);
+    }
+#undef AUR_PA
     HIP_CHECK(hipGetLastError());
 }
 

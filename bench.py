@@ -682,7 +682,7 @@ def main():
             _log(f"could not write {full_path}: {ex}")
             full_path = None
         print("[bench full] " + json.dumps(line), file=sys.stderr, flush=True)
-        comp = compact(line, full_path)
+        comp = compact(line, os.path.relpath(full_path, ROOT) if full_path and os.path.isabs(full_path) else full_path)
         txt = json.dumps(comp, separators=(",", ":"))
         _log(f"compact line: {len(txt)} bytes")
         print(txt, file=json_out, flush=True)

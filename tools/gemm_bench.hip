@@ -35,6 +35,7 @@ struct Shape {
 struct Cfg {
     int mt, nw, ntl, prec;
     bool nt = false;
+    int ksp = 1;
 };
 
 template <class F>
@@ -67,6 +68,12 @@ static void launch_variant_p(const GemmRowsArgs& a, const Shape& s, const Cfg& c
     HIP_CHECK(hipGetLastError());
 }
 static void launch_variant(const GemmRowsArgs& a, const Shape& s, const Cfg& c, hipStream_t st) {
+    if (c.ksp > 1) {
+        if (c.prec) launch_gemm_rows_ksp<1>(a, s.epi, st);
+        else launch_gemm_rows_ksp<0>(a, s.epi, st);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (c.nt) {
         if (c.prec) launch_variant_p<1, true>(a, s, c, st);
         else launch_variant_p<0, true>(a, s, c, st);
@@ -86,7 +93,7 @@ static Cfg r03_policy(int M, const Shape& s, int prec) {
 }
 static Cfg r04_policy(int M, const Shape& s, int prec) {
     const GemmRowsShape g = gemm_rows_shape(M, s.N, s.K, s.ln);
-    return Cfg{g.mt, g.nw, g.ntl, prec, g.nt};
+    return Cfg{g.mt, g.nw, g.ntl, prec, g.nt, g.ksp};
 }
 
 int main(int argc, char** argv) {
@@ -141,6 +148,11 @@ int main(int argc, char** argv) {
     }
     long long* dprof;
     HIP_CHECK(hipMalloc(&dprof, 4096 * 8 * 8));
+    float* ksp_buf;
+    unsigned* ksp_cnt;
+    HIP_CHECK(hipMalloc(&ksp_buf, (size_t)kGemmKspTiles * 16 * 256 * 4));
+    HIP_CHECK(hipMalloc(&ksp_cnt, (size_t)kGemmKspTiles * 4));
+    HIP_CHECK(hipMemset(ksp_cnt, 0, (size_t)kGemmKspTiles * 4));
 
     const Shape shapes[] = {{"qkv ", 3072, 1024, true, kEpiQkv},
                             {"proj", 1024, 1024, false, kEpiResidual},
@@ -180,6 +192,10 @@ int main(int argc, char** argv) {
         if (M <= 16) {   // one row group: every weight tile has one reader -> non-temporal weight loads
             cfgs.push_back({1, 16, 1, 1, true});
             cfgs.push_back({1, 16, 1, 0, true});
+            if (s.K == 4096) {   // K split over 4 workgroups of 4 waves per tile, last arriver combines (bitwise the unsplit result)
+                cfgs.push_back({1, 4, 1, 1, true, kGemmKsp});
+                cfgs.push_back({1, 4, 1, 0, true, kGemmKsp});
+            }
         }
         std::vector<float> ref;
         for (const Cfg& c : cfgs) {
@@ -187,6 +203,7 @@ int main(int argc, char** argv) {
             a.X = X; a.xmt = MTT; a.omt = MTT; a.M = M; a.N = s.N; a.K = s.K; a.bias = bias; a.ln_c1 = s.ln ? gamma : nullptr; a.eps = 1e-5f;
             a.out = (s.epi == kEpiResidual) ? hres : out; a.ldo = (s.epi == kEpiQkv) ? H : s.N;
             a.kv_layer = kv; a.row_slot = dslot; a.slot_kvpos = dpos; a.block_tables = dbt; a.max_blocks = 66; a.stats_in = dstats; a.row_meta = drm;
+            a.ksp_buf = ksp_buf; a.ksp_cnt = ksp_cnt;
             // correctness: one launch on a fresh output, compared element-wise with the reference configuration
             HIP_CHECK(hipMemcpyAsync(hres, hres0, (size_t)256 * 4096 * 4, hipMemcpyDeviceToDevice, st));
             HIP_CHECK(hipMemsetAsync(out, 0, (size_t)256 * 4096 * 4, st));
@@ -208,7 +225,7 @@ int main(int argc, char** argv) {
                 launch_variant(a, s, c, st);
             });
             const int n_grp = (M + 16 * c.mt - 1) / (16 * c.mt);
-            const int nwg = ((s.N / (16 * c.ntl) + 7) / 8 * 8) * n_grp;
+            const int nwg = ((s.N / (16 * c.ntl) + 7) / 8 * 8) * n_grp;   // (K split: the stamps of the 4 parts of a tile overwrite each other)
             HIP_CHECK(hipMemsetAsync(dprof, 0, (size_t)nwg * 64, st));
             a.prof = dprof;
             a.Wt = wt[5];
@@ -232,8 +249,8 @@ int main(int argc, char** argv) {
                 en_us.push_back((double)(hp[g * 8 + 5] - t_min) / 100.0);
             }
             std::sort(en_us.begin(), en_us.end());
-            printf("%s M=%d rows/wg=%2d cols/wg=%2d waves=%2d prec=%d nt=%d wgs=%4d : %6.2f us/launch | max|d| vs ref %.2e (max|ref| %.2e) | 10-ns ticks: span %5lld issue %4.0f ln+wait %5.0f mfma %5.0f bar %4.0f epi %4.0f | ends p10 %.2f p50 %.2f max %.2f\n",
-                   s.name, M, 16 * c.mt, 16 * c.ntl, c.nw, c.prec, (int)c.nt, nwg, us, maxd, maxr, t_max - t_min, ph[0], ph[1], ph[2], ph[3], ph[4],
+            printf("%s M=%d rows/wg=%2d cols/wg=%2d waves=%2d ksp=%d prec=%d nt=%d wgs=%4d : %6.2f us/launch | max|d| vs ref %.2e (max|ref| %.2e) | 10-ns ticks: span %5lld issue %4.0f ln+wait %5.0f mfma %5.0f bar %4.0f epi %4.0f | ends p10 %.2f p50 %.2f max %.2f\n",
+                   s.name, M, 16 * c.mt, 16 * c.ntl, c.nw, c.ksp, c.prec, (int)c.nt, nwg * c.ksp, us, maxd, maxr, t_max - t_min, ph[0], ph[1], ph[2], ph[3], ph[4],
                    en_us[en_us.size() / 10], en_us[en_us.size() / 2], en_us.back());
             fflush(stdout);
         }
@@ -277,6 +294,7 @@ int main(int argc, char** argv) {
                 launch_variant(a, shapes[2], policy(M, shapes[2], prec), st);
                 a = GemmRowsArgs{};
                 a.M = M; a.prec = prec; a.X = act; a.xmt = MTT; a.Wt = w2[l]; a.N = 1024; a.K = 4096; a.bias = bias; a.out = hres; a.omt = MTT; a.stats_out = dstats + 128 * 64;
+                a.ksp_buf = ksp_buf; a.ksp_cnt = ksp_cnt;
                 launch_variant(a, shapes[3], policy(M, shapes[3], prec), st);
             }
         };
