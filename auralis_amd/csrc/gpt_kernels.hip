@@ -916,17 +916,15 @@ void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, 
 // Paged causal attention: one workgroup per (row, head).  16 lanes x float4 (fp32 pool) or 8 lanes x 8 halves (fp16 pool) span
 // the 64-wide head, so one wave instruction covers 4 / 8 consecutive cached tokens (1 KiB contiguous); 4 waves stride the
 // context.  Scores are reduced with wavefront shuffles; online softmax per lane group; groups merged through LDS.
-// UN = token steps in flight per workgroup iteration (each step = 16 tokens of the fp32 pool).  4 when the launch fills the chip
-// (8 measured slower at 64 rows: registers); 16 when only a few (row, head) workgroups exist (M <= 16 rows: a single utterance
-// is 16 workgroups), where a launch is a chain of dependent memory round trips -- with 256 tokens per iteration a 243-token
-// context is ONE round trip instead of four.  A partial accumulator (wave, lane group) still sees its tokens in the same order,
-// so the result is bitwise the same for every UN.
-template <bool KVH, int UN>
+template <bool KVH>
 __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __restrict__ qbuf, const void* __restrict__ kv_layer_v,
                                                               const int* __restrict__ row_slot, const int* __restrict__ row_pos,
                                                               const int* __restrict__ slot_kvpos,
                                                               const int* __restrict__ block_tables, int max_blocks,
                                                               float* __restrict__ out, int out_mtt, const int* __restrict__ row_meta) {
+    // (16 token steps in flight for M <= 16 rows -- one loop iteration per 256 tokens -- measured no gain, 9.6 us per launch at
+    // M = 1 either way: the launch is the dependent chain row_meta -> block ids -> K/V, not the loop; profiles/r04_gemm_bench_m1.log)
+    constexpr int UN = 4;                    // token steps in flight per workgroup iteration (8 measured slower at 64 rows: registers)
     constexpr int LPT = KVH ? 8 : 16;        // lanes per token
     constexpr int EPL = kHeadDim / LPT;      // elements per lane
     constexpr int TPW = 64 / LPT;            // tokens per wave instruction
@@ -1146,14 +1144,12 @@ void launch_paged_attention(const float* qbuf, const void* kv_layer, const int* 
                             const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
                             hipStream_t st, int out_mtt, bool kv_half, const int* row_meta) {
     trace_launch("paged_attention_kernel");
-#define AUR_PA(KVH_, UN_) hipLaunchKernelGGL((paged_attention_kernel<KVH_, UN_>), dim3(M, kHeads), dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos, \
-                                             slot_kvpos, block_tables, max_blocks, out, out_mtt, row_meta)
-    if (M <= 16) {
-        if (kv_half) AUR_PA(true, 8); else AUR_PA(false, 16);
-    } else {
-        if (kv_half) AUR_PA(true, 4); else AUR_PA(false, 4);
-    }
-#undef AUR_PA
+    if (kv_half)
+        hipLaunchKernelGGL(paged_attention_kernel<true>, dim3(M, kHeads), dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos,
+                           slot_kvpos, block_tables, max_blocks, out, out_mtt, row_meta);
+    else
+        hipLaunchKernelGGL(paged_attention_kernel<false>, dim3(M, kHeads), dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos,
+                           slot_kvpos, block_tables, max_blocks, out, out_mtt, row_meta);
     HIP_CHECK(hipGetLastError());
 }
 
