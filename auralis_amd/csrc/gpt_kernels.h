@@ -76,7 +76,7 @@ struct GemmRowsArgs {
     unsigned* ksp_cnt;   // [tiles], zero before the first launch (the last arriver resets its counter)
 };
 constexpr int kGemmKsp = 4;
-constexpr int kGemmKspTiles = 128;   // output tiles the scratch is sized for: ksp_buf = kGemmKspTiles * 16 * 256 floats, ksp_cnt = kGemmKspTiles
+constexpr int kGemmKspTiles = 256;   // output tiles the scratch is sized for: ksp_buf = kGemmKspTiles * 16 * 256 floats, ksp_cnt = kGemmKspTiles
 void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream_t st);
 // Workgroup shape the launcher picks for a GEMM kind at M rows: 16*mt rows x 16*ntl columns, nw waves (K split nw ways);
 // nt: non-temporal weight loads (M <= 16: every weight tile has one reader).

@@ -704,6 +704,7 @@ static void launch_gemm_rows_mt(const GemmRowsArgs& a, int mt, int nw, hipStream
     AUR_GR(1, 16, 1)
     if constexpr (!NT) {
         if constexpr (KCH == 1 && LN) {
+            AUR_GR(1, 16, 2)
             AUR_GR(1, 16, 3)
             AUR_GR(2, 16, 2)
         }
@@ -711,9 +712,9 @@ static void launch_gemm_rows_mt(const GemmRowsArgs& a, int mt, int nw, hipStream
         AUR_GR(2, 16, 1)
         if constexpr (KCH == 1) {
             AUR_GR(4, 16, 1)
-            AUR_GR(1, 16, 2)
             AUR_GR(1, 16, 4)
             if constexpr (!LN) {
+                AUR_GR(1, 16, 2)
                 AUR_GR(1, 16, 3)
                 AUR_GR(2, 16, 2)
             }
@@ -728,35 +729,32 @@ static void launch_gemm_rows_mt(const GemmRowsArgs& a, int mt, int nw, hipStream
 }
 
 // Shape policy.  The waves per workgroup fix the K grouping of the reduction, so they depend on the GEMM kind only (16
-// everywhere), never on M: a row's result must not change with the number of live rows.  Rows x columns per workgroup do not
-// enter the arithmetic (the K order of an output element is the same for every tile shape: bitwise equal).
-// M > 16 — one workgroup per CU when the launch is large enough for it (256 CUs):
-//   LN GEMMs, N = 3072 (QKV): 16 rows x 48 columns  -> 64 x ceil(M/16) workgroups (256 at M = 64); the CU pulls its 16
-//       activation rows once for three column tiles
-//   LN GEMMs, N = 4096 (FC) : 32 rows x 32 columns  -> 128 x ceil(M/32)
-//   N = 1024 (proj, proj2), head: 16 rows x 16 columns
-// M <= 16 (one row group; a single utterance is M = 1) — the launch is pure weight streaming and every weight tile has exactly one
-//   reader: 16 x 16 tiles everywhere (QKV 192, FC 256 workgroups instead of 64 / 128; chain of 30 layers at M = 1: 29.5 vs 34.0 us
-//   per layer, profiles/r04_gemm_bench_m1.log), non-temporal weight loads for the 16.8 MB matrices.
+// everywhere; the K-split form runs the same 16 slices in 4 workgroups), never on M: a row's result must not change with the
+// number of live rows.  Rows x columns per workgroup do not enter the arithmetic (the K order of an output element is the same for
+// every tile shape: bitwise equal).  The shapes aim at 192-256 workgroups (256 CUs) for every number g = ceil(M / 16) of 16-row
+// groups (tools/gemm_bench, profiles/r04_gemm_bench_m{1,16,32,48,64}.log):
+//   LN GEMM, N = 3072 (QKV): 16 rows x 16 g columns for g <= 3 (192 workgroups), 16 x 48 from g = 4 (64 g workgroups)
+//   LN GEMM, N = 4096 (FC) : 16 x 16 (g = 1), 16 x 32 (g = 2), 32 x 32 from g = 3 -- 256 workgroups up to 64 rows
+//   N = 1024, K = 1024 (proj), head: 16 x 16
+//   N = 1024, K = 4096 (proj2): 16 x 16; for g <= 2 split over 4 workgroups of 4 waves per tile (GemmRowsArgs::ksp_buf): 7.9 vs 12.1 us
+//       at 1 row, 9.8 vs 11.9 at 32, 12.4 vs 12.0 at 48
+// g = 1 (a single utterance is M = 1): every weight tile has exactly one reader, the 16.8 MB matrices are streamed with
+// non-temporal loads (-0.3 us each; proj and the head measured 0.7 us SLOWER with them).  Chain of 30 layers without attention at
+// M = 1: 26.7 us per layer against 34.0 with the round-3 shapes, at M = 32: 30.4 against 35.4.
 GemmRowsShape gemm_rows_shape(int M, int N, int K, bool ln) {
     GemmRowsShape s{1, 16, 1, false, 1};
-    if (M <= 16 && K == 4096 && !ln) {
-        // the K = 4096 projection streams 16.8 MB through 64 column tiles: four workgroups of four waves per tile (256
-        // workgroups), partial tiles combined by the last arriver in the unsplit kernel's order (GemmRowsArgs::ksp_buf)
+    const int g = (M + 15) / 16;
+    if (K == 4096 && !ln && g <= 2) {
         s.nw = 4;
         s.ksp = kGemmKsp;
         s.nt = true;
-    } else if (M <= 16) {
-        s.nt = (long)N * K >= 4L * 1024 * 1024;   // FC, proj2 (-0.3 us each at M = 1; proj and the head measured 0.7 us SLOWER with it)
-    } else if (ln) {
-        if (N % 48 == 0 && N < 4096) {
-            s.ntl = 3;
-        } else if (N % 32 == 0) {
-            s.ntl = 2;
-            s.mt = 2;
-        }
+    } else if (ln && N % 48 == 0 && N < 4096) {
+        s.ntl = g >= 3 ? 3 : g;
+    } else if (ln && N % 32 == 0) {
+        s.ntl = g >= 2 ? 2 : 1;
+        s.mt = g >= 3 ? 2 : 1;
+        s.nt = g == 1 && (long)N * K >= 4L * 1024 * 1024;
     }
-    (void)K;
     return s;
 }
 
@@ -792,7 +790,7 @@ void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream
     GemmRowsShape s = gemm_rows_shape(a.M, a.N, a.K, ln);
     trace_launch("gemm_rows_kernel");
     AUR_REQUIRE(a.prec == 0 || a.prec == 1, "gemm_rows: prec is 0 (exact f32 MFMA) or 1 (bf16 x 3 split)");
-    if (s.ksp > 1 && !(a.ksp_buf && a.ksp_cnt)) s = GemmRowsShape{1, 16, 1, true, 1};   // no scratch given: the unsplit kernel (same bits)
+    if (s.ksp > 1 && !(a.ksp_buf && a.ksp_cnt)) s = GemmRowsShape{1, 16, 1, a.M <= 16, 1};   // no scratch given: the unsplit kernel (same bits)
     if (s.ksp > 1) {
         AUR_REQUIRE((long)((a.M + 15) / 16) * (a.N / 16) <= kGemmKspTiles, "gemm_rows K split: more output tiles than the scratch holds");
         if (a.prec == 1) launch_gemm_rows_ksp<1>(a, epi, st);

@@ -192,10 +192,10 @@ int main(int argc, char** argv) {
         if (M <= 16) {   // one row group: every weight tile has one reader -> non-temporal weight loads
             cfgs.push_back({1, 16, 1, 1, true});
             cfgs.push_back({1, 16, 1, 0, true});
-            if (s.K == 4096) {   // K split over 4 workgroups of 4 waves per tile, last arriver combines (bitwise the unsplit result)
-                cfgs.push_back({1, 4, 1, 1, true, kGemmKsp});
-                cfgs.push_back({1, 4, 1, 0, true, kGemmKsp});
-            }
+        }
+        if (s.K == 4096) {   // K split over 4 workgroups of 4 waves per tile, last arriver combines (bitwise the unsplit result)
+            cfgs.push_back({1, 4, 1, 1, true, kGemmKsp});
+            cfgs.push_back({1, 4, 1, 0, true, kGemmKsp});
         }
         std::vector<float> ref;
         for (const Cfg& c : cfgs) {
