@@ -133,7 +133,8 @@ struct RowWs {
     hipStream_t st = nullptr;
     int rows_cap = 0;
     DevBuf h, xn, qbuf, att, act, P, P2, ybuf, stats, row_meta;   // row_meta: per-row K/V addressing of the current decode step   // stats: LayerNorm partials of the packed residual stream [rows][64] float2
-    DevBuf i_row_slot, i_row_pos, i_desc, i_sample_row, i_sample_slot, i_next_kvpos, i_out_tok;
+    DevBuf i_row_slot, i_row_pos, i_desc, i_sample_row, i_sample_slot, i_next_kvpos, i_out_tok, i_qblk;
+    std::vector<int2> h_qblk;   // query blocks of the prompt rows in flight (launch_prompt_attention)
     PinBuf pin;
     std::vector<int> sample_row, sample_slot;
 };
@@ -525,7 +526,7 @@ public:
         HIP_CHECK(hipMemcpyAsync(w.i_row_slot.p, row_slot.data(), 32 * 4, hipMemcpyHostToDevice, w.st));
         HIP_CHECK(hipMemcpyAsync(w.i_row_pos.p, row_pos.data(), 32 * 4, hipMemcpyHostToDevice, w.st));
         launch_embed_prompt(w.i_desc.as<int4>(), spk_table_.as<float>(), text_emb_, text_pos_, wte_, wpe_, w.h.as<float>(), 32, w.st);
-        forward_rows(w, 32, w.i_row_slot.as<int>(), w.i_row_pos.as<int>());
+        forward_rows(w, 32, w.i_row_slot.as<int>(), w.i_row_pos.as<int>(), upload_qblocks(w, row_slot, row_pos));
         HIP_CHECK(hipStreamSynchronize(w.st));
         si.ready = true;
     }
@@ -1291,9 +1292,24 @@ private:
         }
         n_gemm_events_ = 0;
     }
+    // Query blocks of a batch of prompt rows for launch_prompt_attention: runs of consecutive rows of one slot with positions
+    // ascending by one, cut every 32 rows (from the run's first row: a sequence's blocks do not depend on what else is in the batch).
+    int upload_qblocks(RowWs& w, const std::vector<int>& row_slot, const std::vector<int>& row_pos) {
+        w.h_qblk.clear();
+        const int M = (int)row_slot.size();
+        for (int m = 0; m < M;) {
+            int n = 1;
+            while (m + n < M && n < 32 && row_slot[m + n] == row_slot[m] && row_pos[m + n] == row_pos[m] + n) ++n;
+            w.h_qblk.push_back(make_int2(m, n));
+            m += n;
+        }
+        w.i_qblk.ensure(w.h_qblk.size() * sizeof(int2));
+        HIP_CHECK(hipMemcpyAsync(w.i_qblk.p, w.h_qblk.data(), w.h_qblk.size() * sizeof(int2), hipMemcpyHostToDevice, w.st));
+        return (int)w.h_qblk.size();
+    }
     // Prompt rows (prefill, speaker prefix, literal second pass): explicit row positions, LDS-tiled GEMMs in the configured arithmetic
     // (gemm_prec_: bf16 x 3 split by default, exact-f32 MFMA under aur_config.gemm_f32_exact; k ascending for every M => a prompt's rows do not depend on what else was admitted), separate LayerNorm launches.
-    void forward_rows(RowWs& w, int M, const int* d_row_slot, const int* d_row_pos) {
+    void forward_rows(RowWs& w, int M, const int* d_row_slot, const int* d_row_pos, int n_qblk) {
         float* h = w.h.as<float>();
         float* xn = w.xn.as<float>();
         float* P = w.P.as<float>();
@@ -1306,7 +1322,7 @@ private:
             void* kvl = kv_layer(l);
             launch_gemm_tile(xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, w.st, nullptr, gemm_prec_);
             launch_qkv_epilogue(P, 1, L.bqkv, w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, w.st, kv_half_);
-            launch_prompt_attention(w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, bt, kMaxBlocks, w.att.as<float>(), M, w.st, kv_half_);
+            launch_prompt_attention(w.qbuf.as<float>(), kvl, w.i_qblk.as<int2>(), n_qblk, d_row_slot, d_row_pos, bt, kMaxBlocks, w.att.as<float>(), w.st, kv_half_);
             launch_gemm_tile(w.att.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, w.st, nullptr, gemm_prec_);
             launch_rows_ln(P, 1, L.bproj, h, L.ln2w, L.ln2b, xn, M, 1e-5f, w.st);
             const GemmGelu ge{L.bfc, w.act.as<float>(), cfg_.gelu_erf ? 1 : 0};
@@ -1430,7 +1446,7 @@ private:
         HIP_CHECK(hipMemcpyAsync(w.i_row_slot.p, row_slot.data(), (size_t)M * 4, hipMemcpyHostToDevice, w.st));
         HIP_CHECK(hipMemcpyAsync(w.i_row_pos.p, row_pos.data(), (size_t)M * 4, hipMemcpyHostToDevice, w.st));
         launch_embed_prompt(w.i_desc.as<int4>(), spk_table_.as<float>(), text_emb_, text_pos_, wte_, wpe_, w.h.as<float>(), M, w.st);
-        forward_rows(w, M, w.i_row_slot.as<int>(), w.i_row_pos.as<int>());
+        forward_rows(w, M, w.i_row_slot.as<int>(), w.i_row_pos.as<int>(), upload_qblocks(w, row_slot, row_pos));
         for (size_t k = 0; k < seqs.size(); ++k) {
             Seq* s = seqs[k];
             if (latpool_free_.empty()) throw StateError("latent pool exhausted");
@@ -1512,7 +1528,7 @@ private:
                     w.i_desc.p, spk_table_.p, (const void*)text_emb_, (const void*)text_pos_, (const void*)wte_, (const void*)wpe_, w.h.p,
                     desc[0].x, desc[0].y, desc[0].z, desc[M - 1].x, desc[M - 1].y, desc[M - 1].z);
         launch_embed_prompt(w.i_desc.as<int4>(), spk_table_.as<float>(), text_emb_, text_pos_, wte_, wpe_, w.h.as<float>(), M, w.st);
-        forward_rows(w, M, w.i_row_slot.as<int>(), w.i_row_pos.as<int>());
+        forward_rows(w, M, w.i_row_slot.as<int>(), w.i_row_pos.as<int>(), upload_qblocks(w, row_slot, row_pos));
         if (dbg_capture_) {
             dbg_lnf_.ensure((size_t)M * kHidden * 4);
             HIP_CHECK(hipMemcpyAsync(dbg_lnf_.p, w.xn.p, (size_t)M * kHidden * 4, hipMemcpyDeviceToDevice, w.st));

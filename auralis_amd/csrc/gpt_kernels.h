@@ -130,10 +130,10 @@ void launch_paged_attention(const float* qbuf, const void* kv_layer, const int* 
                             const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
                             hipStream_t st, int out_mtt = 0, bool kv_half = false, const int* row_meta = nullptr);
 
-// the same for prompt rows (explicit positions, row-major output): a workgroup takes 32 consecutive rows of one head and each
-// row's 8 lanes walk its context in key order; rows of one sequence share their K/V fetches inside a wave
-void launch_prompt_attention(const float* qbuf, const void* kv_layer, const int* row_slot, const int* row_pos,
-                             const int* block_tables, int max_blocks, float* out, int M, hipStream_t st, bool kv_half = false);
+// prompt rows (explicit positions, row-major output): exact-f32 MFMA score / PV tiles over query blocks of up to 32 consecutive
+// rows of one sequence, qblk[i] = {first row, rows} (row_pos ascends by one inside a block)
+void launch_prompt_attention(const float* qbuf, const void* kv_layer, const int2* qblk, int n_qblk, const int* row_slot, const int* row_pos,
+                             const int* block_tables, int max_blocks, float* out, hipStream_t st, bool kv_half = false);
 
 // prompt rows: desc[m] = {kind, a, b, _}: kind 0 -> spk_cond[b][a][:], 1 -> text_emb[a]+text_pos[b], 2 -> wte[a]+wpe[b]
 void launch_embed_prompt(const int4* desc, const float* spk_cond, const float* text_emb, const float* text_pos,

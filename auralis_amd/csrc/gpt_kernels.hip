@@ -1029,112 +1029,155 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
     }
 }
 
-// Prompt rows (prefill): one workgroup per (32 consecutive rows, head).  A row's 8 lanes span the 64-wide head (8 elements each)
-// and walk the row's whole context key by key -- no cross-group merge, no LDS; the rows of a wave step through the keys
-// together, so rows of one sequence (which is what 32 consecutive prompt rows are) ask for the same K/V addresses in the
-// same instruction and the context is fetched once per wave instead of once per row.  Per row the result depends on nothing
-// but the row (same key order whatever else is in the batch).
+// Prompt rows (prefill): attention on exact-f32 MFMA tiles.  A QUERY BLOCK is up to 32 consecutive prompt rows of one sequence
+// (qblk[i] = {first row, rows}: built by the host, a block never crosses a sequence, positions inside it ascend by one); one wave
+// takes one (query block, head), a workgroup four heads.  Both products keep the queries on the MFMA column axis, so everything
+// per-query (running max, running sum, the rescaling of the output) is lane-local and P never has to be transposed:
+//   S^T[key][query]  = K[key][:] . Q[query][:]     v_mfma_f32_32x32x2_f32 x 32, A = K rows (8 float4 loads per lane straight from the
+//                                                   pages), B = Q rows (kept in registers for the whole kernel); dims split 0..31 /
+//                                                   32..63 over the two lane halves
+//   O^T[dim][query] += V^T[dim][key] . P^T[key][query]   x 16 per 32-dim tile, A from the V tile staged in the wave's 8 KB of LDS, B = the
+//                                                   lane's own 16 probabilities (D layout of S^T: register r of half h is key
+//                                                   (r & 3) + 8 (r >> 2) + 4 h, which is then also the k index of the second product)
+// Keys go in blocks of 32 from key 0 (causal mask per element), online softmax per query.  A row's result depends on its own
+// sequence only: every output element has its own accumulator chain, and the key partition starts at key 0 whatever the row block.
+// (Until round 3 this was a VALU kernel, 8 lanes per row walking the context key by key: 125 us per launch at 4 544 rows.)
 template <bool KVH>
 __global__ __launch_bounds__(256) void prompt_attention_kernel(const float* __restrict__ qbuf, const void* __restrict__ kv_layer_v,
-                                                               const int* __restrict__ row_slot, const int* __restrict__ row_pos,
-                                                               const int* __restrict__ block_tables, int max_blocks,
-                                                               float* __restrict__ out, int M) {
-    constexpr int LPR = 8, EPL = kHeadDim / LPR;   // lanes per row, elements per lane
-    constexpr int UN = 4;                          // keys per loop iteration (their loads are issued together)
+                                                               const int2* __restrict__ qblk, const int* __restrict__ row_slot,
+                                                               const int* __restrict__ row_pos, const int* __restrict__ block_tables,
+                                                               int max_blocks, float* __restrict__ out) {
     using KT = typename std::conditional<KVH, _Float16, float>::type;
-    using RawT = typename std::conditional<KVH, h16x8g, f32x4>::type;
-    constexpr int NR = KVH ? 1 : 2;                // raw loads per 8 elements
-    const int head = blockIdx.y;
-    const int r = blockIdx.x * 32 + (threadIdx.x >> 3), dl = threadIdx.x & 7;
-    const bool live = r < M;
-    const int m = live ? r : M - 1;
-    const int slot = row_slot[m];
-    const int n_keys = live ? row_pos[m] + 1 : 0;
+    constexpr int VP = kHeadDim + 4;   // LDS row pitch of the V tile (floats): b128 writes and b32 reads conflict-free
+    __shared__ __attribute__((aligned(16))) float vs[4][32 * VP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int head = blockIdx.y * 4 + wv;
+    const int2 qb = qblk[blockIdx.x];
+    const int row0 = qb.x, nrows = qb.y;
+    const int slot = row_slot[row0], pos0 = row_pos[row0];
     const int* bt = block_tables + (long)slot * max_blocks;
     const KT* kv_layer = reinterpret_cast<const KT*>(kv_layer_v);
-    float qv[EPL];
+    const int my_pos = pos0 + l31;                 // position of this lane's query (queries >= nrows compute and are dropped)
+    const int max_pos = pos0 + nrows - 1;
+    const int n_kb = (max_pos >> 5) + 1;
+
+    auto load32 = [&](const KT* p, float (&dst)[32]) {   // 32 consecutive elements
+        if constexpr (KVH) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const h16x8g v = *reinterpret_cast<const h16x8g*>(p + 8 * i);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) dst[8 * i + c] = (float)v[c];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * i);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dst[4 * i + c] = v[c];
+            }
+        }
+    };
+    float qreg[32];
     {
-        const float* qp = qbuf + (long)m * kHidden + head * kHeadDim + dl * EPL;
+        const float* qp = qbuf + (long)(row0 + min(l31, nrows - 1)) * kHidden + head * kHeadDim + 32 * hi;
 #pragma unroll
-        for (int c4 = 0; c4 < EPL / 4; ++c4) {
-            const f32x4 q4 = *reinterpret_cast<const f32x4*>(qp + 4 * c4);
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(qp + 4 * i);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) qv[4 * c4 + c] = q4[c];
+            for (int c = 0; c < 4; ++c) qreg[4 * i + c] = v[c];
         }
     }
-    float mi = -INFINITY, li = 0.f, o[EPL];
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 o[2];
 #pragma unroll
-    for (int c = 0; c < EPL; ++c) o[c] = 0.f;
-    // the wave iterates to the longest context among its rows; a row's own keys beyond n_keys are masked (clamped addresses)
-    int n_max = n_keys;
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int sh = 32; sh > 0; sh >>= 1) n_max = max(n_max, __shfl_xor(n_max, sh, 64));
-    // block by block (16 keys): the next block's id is fetched while the current block is processed, so that an iteration waits
-    // for one memory round trip (its K/V rows), not two
-    const int last_blk = max(n_keys - 1, 0) / kKvBlockTokens;
-    int blk_next = bt[0];
-    for (int b0 = 0; b0 * kKvBlockTokens < n_max; ++b0) {
-        const int blk = blk_next;
-        blk_next = bt[min(b0 + 1, last_blk)];
-        const KT* kb = kv_layer + kv_offset(blk, 0, head, 0) + dl * EPL;
-#pragma unroll 1
-        for (int t0 = b0 * kKvBlockTokens; t0 < min((b0 + 1) * kKvBlockTokens, n_max); t0 += UN) {
-            RawT kraw[UN][NR], vraw[UN][NR];
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float* vw = &vs[wv][0];
+
+    for (int kb = 0; kb < n_kb; ++kb) {
+        // K rows of this block as the A operand (keys beyond the block's last needed key are clamped: their scores are masked)
+        float kreg[32];
+        {
+            const int key = min(kb * 32 + l31, max_pos);
+            load32(kv_layer + kv_offset(bt[key / kKvBlockTokens], 0, head, key % kKvBlockTokens) + 32 * hi, kreg);
+        }
+        // V rows of this block: lane -> (key lane >> 1, half lane & 1), 32 elements each
+        float vreg[32];
+        {
+            const int key = min(kb * 32 + (lane >> 1), max_pos);
+            load32(kv_layer + kv_offset(bt[key / kKvBlockTokens], 1, head, key % kKvBlockTokens) + 32 * (lane & 1), vreg);
+        }
+        f32x16 acc;
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                // (a row whose context ended in an earlier block keeps reading this block of its own table entry `blk`: any
-                // mapped address will do, the values are masked)
-                const int tt = min(t0 + u, max(n_keys - 1, 0)) % kKvBlockTokens;
-                const KT* kp = kb + tt * kHeadDim;
-                const KT* vp = kp + (long)kHeads * kKvBlockTokens * kHeadDim;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-                for (int h = 0; h < NR; ++h) {
-                    kraw[u][h] = *reinterpret_cast<const RawT*>(kp + h * (EPL / NR));
-                    vraw[u][h] = *reinterpret_cast<const RawT*>(vp + h * (EPL / NR));
-                }
-            }
+        for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[s], qreg[s], acc, 0, 0, 0);
+        // scores of this lane's query against keys kb*32 + keyl(r), keyl(r) = (r & 3) + 8 (r >> 2) + 4 hi
+        float mb = -INFINITY;
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                float kx[EPL], vx[EPL];
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            acc[r] = key <= my_pos ? acc[r] * 0.125f : -INFINITY;   // 1/sqrt(64)
+            mb = fmaxf(mb, acc[r]);
+        }
+        mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+        const float m_new = fmaxf(m_run, mb);          // finite from the first block on: key 0 is visible to every query
+        const float alpha = expf(m_run - m_new);        // m_run = -inf on the first block -> 0
+        float ps = 0.f;
 #pragma unroll
-                for (int c = 0; c < EPL; ++c) {
-                    kx[c] = (float)kraw[u][c / (EPL / NR)][c % (EPL / NR)];
-                    vx[c] = (float)vraw[u][c / (EPL / NR)][c % (EPL / NR)];
-                }
-                float sc = ((qv[0] * kx[0] + qv[1] * kx[1]) + (qv[2] * kx[2] + qv[3] * kx[3])) +
-                           ((qv[4] * kx[4] + qv[5] * kx[5]) + (qv[6] * kx[6] + qv[7] * kx[7]));
+        for (int r = 0; r < 16; ++r) {
+            acc[r] = expf(acc[r] - m_new);              // masked: exp(-inf) = 0
+            ps += acc[r];
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
 #pragma unroll
-                for (int sh = LPR / 2; sh > 0; sh >>= 1) sc += __shfl_xor(sc, sh, 64);
-                sc *= 0.125f;   // 1/sqrt(64)
-                if (t0 + u < n_keys) {
-                    const float mn = fmaxf(mi, sc);
-                    const float alpha = expf(mi - mn);   // mi = -inf on first use -> 0
-                    const float pw = expf(sc - mn);
-                    li = li * alpha + pw;
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int c = 0; c < EPL; ++c) o[c] = o[c] * alpha + pw * vx[c];
-                    mi = mn;
-                }
-            }
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        // stage the V tile (the previous block's reads are complete: same wave, LDS executes in order; the wave barriers keep the
+        // compiler from moving accesses of different lanes across the phases)
+        __builtin_amdgcn_wave_barrier();
+        {
+            float* dst = vw + (lane >> 1) * VP + 32 * (lane & 1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(dst + 4 * i) = f32x4{vreg[4 * i], vreg[4 * i + 1], vreg[4 * i + 2], vreg[4 * i + 3]};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float* vrow = vw + ((s & 3) + 8 * (s >> 2) + 4 * hi) * VP + l31;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * t], acc[s], o[t], 0, 0, 0);
         }
     }
-    if (live) {
-        float* op = out + (long)m * kHidden + head * kHeadDim + dl * EPL;
-        const float inv = 1.0f / li;
+    if (l31 < nrows) {
+        const float inv = 1.0f / l_run;
+        float* op = out + (long)(row0 + l31) * kHidden + head * kHeadDim + 4 * hi;
 #pragma unroll
-        for (int c4 = 0; c4 < EPL / 4; ++c4)
-            *reinterpret_cast<f32x4*>(op + 4 * c4) = f32x4{o[4 * c4] * inv, o[4 * c4 + 1] * inv, o[4 * c4 + 2] * inv, o[4 * c4 + 3] * inv};
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<f32x4*>(op + 32 * t + 8 * g4) =
+                    f32x4{o[t][4 * g4] * inv, o[t][4 * g4 + 1] * inv, o[t][4 * g4 + 2] * inv, o[t][4 * g4 + 3] * inv};
     }
 }
 
-void launch_prompt_attention(const float* qbuf, const void* kv_layer, const int* row_slot, const int* row_pos,
-                             const int* block_tables, int max_blocks, float* out, int M, hipStream_t st, bool kv_half) {
+void launch_prompt_attention(const float* qbuf, const void* kv_layer, const int2* qblk, int n_qblk, const int* row_slot, const int* row_pos,
+                             const int* block_tables, int max_blocks, float* out, hipStream_t st, bool kv_half) {
     trace_launch("prompt_attention_kernel");
-    const dim3 grid((M + 31) / 32, kHeads);
+    static_assert(kHeads % 4 == 0 && kHeadDim == 64, "prompt attention: four heads per workgroup, 64-wide heads");
+    const dim3 grid(n_qblk, kHeads / 4);
     if (kv_half)
-        hipLaunchKernelGGL(prompt_attention_kernel<true>, grid, dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos, block_tables, max_blocks, out, M);
+        hipLaunchKernelGGL(prompt_attention_kernel<true>, grid, dim3(256), 0, st, qbuf, kv_layer, qblk, row_slot, row_pos, block_tables, max_blocks, out);
     else
-        hipLaunchKernelGGL(prompt_attention_kernel<false>, grid, dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos, block_tables, max_blocks, out, M);
+        hipLaunchKernelGGL(prompt_attention_kernel<false>, grid, dim3(256), 0, st, qbuf, kv_layer, qblk, row_slot, row_pos, block_tables, max_blocks, out);
     HIP_CHECK(hipGetLastError());
 }
 
