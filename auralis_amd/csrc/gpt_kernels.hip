@@ -1421,24 +1421,54 @@ __device__ __forceinline__ float ord2f(unsigned o) {
     return __uint_as_float(u);
 }
 
-// block-wide argmax with "first index wins" tie rule
+// block-wide argmax with "first index wins" tie rule (a total order on (value, index): any reduction tree gives the same
+// winner, so the waves reduce with shuffles and meet once in LDS instead of eight barrier-separated LDS levels)
 __device__ __forceinline__ int block_argmax(float val, int idx, float* sv, int* si) {
     const int tid = threadIdx.x;
-    sv[tid] = val;
-    si[tid] = idx;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) {
-            const float ov = sv[tid + s];
-            const int oi = si[tid + s];
-            if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) {
-                sv[tid] = ov;
-                si[tid] = oi;
-            }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) {
+        const float ov = __shfl_xor(val, sh, 64);
+        const int oi = __shfl_xor(idx, sh, 64);
+        if (ov > val || (ov == val && oi < idx)) {
+            val = ov;
+            idx = oi;
         }
-        __syncthreads();
     }
-    const int r = si[0];
+    if ((tid & 63) == 0) {
+        sv[tid >> 6] = val;
+        si[tid >> 6] = idx;
+    }
+    __syncthreads();
+    float bv = sv[0];
+    int bi = si[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) {
+            bv = sv[w];
+            bi = si[w];
+        }
+    __syncthreads();
+    return bi;
+}
+
+// sum of one value per thread in the order of the binary tree sv[t] += sv[t + s], s = 128, 64, .., 1 (the order this kernel has
+// always used: the softmax denominator's bits feed the sampling race): the two cross-wave levels go through LDS, the six levels
+// inside wave 0 are shuffles over the same pairs (t, t + s)
+__device__ __forceinline__ float block_sum_tree(float v, float* sv) {
+    const int tid = threadIdx.x;
+    sv[tid] = v;
+    __syncthreads();
+    if (tid < 128) sv[tid] += sv[tid + 128];
+    __syncthreads();
+    float x = 0.f;
+    if (tid < 64) {
+        x = sv[tid] + sv[tid + 64];
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) x += __shfl_down(x, sh, 64);   // lane t: x[t] + x[t + sh]; lane 0 ends with the tree's root
+        if (tid == 0) sv[0] = x;
+    }
+    __syncthreads();
+    const float r = sv[0];
     __syncthreads();
     return r;
 }
@@ -1493,22 +1523,27 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
         // give identical tokens; it replaces 66 barrier-separated passes over 2048 keys.
         bool sorted = false;
         if (topk > 0 && topk <= 64 && topk < V && !a.force_full_sort) {
-            unsigned ov[5];
+            // every wave runs the whole search on its own copy of the row (17 values per lane): a step is 17 compares + ballots and
+            // scalar adds, no LDS and no barrier (with the row split over the four waves it was 32 barriers, ~11 of the kernel's 25 us)
+            unsigned wvv[17];
 #pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                const int v = tid + 256 * u;
-                ov[u] = (v < V) ? f2ord(z[v] + 0.0f) : 0u;   // (-0 -> +0: equal floats, equal images); 0 sorts below every float
+            for (int u = 0; u < 17; ++u) {
+                const int v = (tid & 63) + 64 * u;
+                wvv[u] = (v < V) ? f2ord(z[v] + 0.0f) : 0u;   // (-0 -> +0: equal floats, equal images); 0 sorts below every float
             }
             unsigned lo = 0u;
             for (int bit = 31; bit >= 0; --bit) {
                 const unsigned x = lo | (1u << bit);
                 int c = 0;
 #pragma unroll
-                for (int u = 0; u < 5; ++u) c += __popcll(__ballot(ov[u] >= x));
-                if ((tid & 63) == 0) si[(bit & 1) * 4 + (tid >> 6)] = c;
-                __syncthreads();
-                const int* cc = &si[(bit & 1) * 4];
-                if ((cc[0] + cc[1]) + (cc[2] + cc[3]) >= topk) lo = x;
+                for (int u = 0; u < 17; ++u) c += __popcll(__ballot(wvv[u] >= x));
+                if (c >= topk) lo = x;
+            }
+            unsigned ov[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int v = tid + 256 * u;
+                ov[u] = (v < V) ? f2ord(z[v] + 0.0f) : 0u;
             }
             // lo = image of the k-th largest logit; survivors: everything >= lo
             if (tid == 0) sh_i[1] = 0;
@@ -1612,14 +1647,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
         // softmax over the survivors, then argmax(probs / Exp(1))
         float part = 0.f;
         for (int v = tid; v < V; v += 256) part += expf(z[v] - maxv);
-        sv[tid] = part;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if (tid < s) sv[tid] += sv[tid + s];
-            __syncthreads();
-        }
-        const float sum2 = sv[0];
-        __syncthreads();
+        const float sum2 = block_sum_tree(part, sv);
         const unsigned seed = a.seed[slot];
         const unsigned step = (unsigned)a.slot_ngen[slot];
         float bv = -INFINITY;
