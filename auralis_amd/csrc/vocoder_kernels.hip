@@ -897,206 +897,6 @@ __global__ __launch_bounds__(64 * (C / 32) * (NT1 / 32 / WN)) void resblock_roun
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Fused ResBlock round, 32 channels: PERSISTENT and WEIGHT-STATIONARY.  The kernel above re-streams the round's weights through
-// LDS for every tile behind 2 * C/16 barriers and stages its input window before it starts computing; at 32 channels both convs'
-// weights are 4 * KS A-fragments per wave (176 VGPRs at k = 11), so here they are loaded ONCE into registers, one workgroup per CU
-// loops over the tiles, and a dedicated LOADER wave stages the next tile's window by LDS-DMA (two window buffers) while seven
-// consumer waves (32 channels x 32 positions each, 224 conv1 positions per tile) run conv1 -> h -> conv2 -> epilogue on the current
-// one.  The consumers never wait for memory they did not ask for (their stores stay in flight across the barriers; only the
-// loader drains vmcnt), and a tile costs two barriers.  Same chunk / tap order of the MFMAs as the kernel above: bit-identical.
-template <int KS, int DIL>
-__global__ __launch_bounds__(512) void resblock_round32_ws_kernel(RoundArgs a, int n_tx, int n_tiles) {
-    constexpr int C = 32, NCH = 2, NCW = 7, NT1 = 32 * NCW;
-    constexpr int P1 = (KS - 1) / 2 * DIL, P2 = (KS - 1) / 2;
-    constexpr int NT2 = NT1 - (KS - 1);
-    constexpr int XROW = (NT1 + (KS - 1) * DIL + 31) / 32 * 32;
-    constexpr int HROW = (NT1 + (KS - 1) + 31) / 32 * 32;
-    constexpr int WCH = KS * C * 32;   // bytes of one weight chunk [KS][C][16 halves]
-    constexpr int XI = XROW / 32;      // 1-KiB copies per window chunk
-    __shared__ __attribute__((aligned(1024))) char xs[2][NCH * XROW * 32];
-    __shared__ __attribute__((aligned(1024))) char hs[NCH * HROW * 32];
-    constexpr bool W2L = KS > 7;   // k = 11: 176 VGPRs of weights do not fit next to the rest -> conv2's fragments come from LDS
-    __shared__ __attribute__((aligned(1024))) char w2s[W2L ? NCH * WCH : 16];
-    __shared__ __attribute__((aligned(16))) float bsm[2][C];   // b1, b2 (in LDS: with the weights in registers a lane has none to spare)
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    const int wvs = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wvs == NCW;
-    const unsigned xs_l = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)&xs[0][0];
-
-    struct Tile { int t, b, q0, len; };
-    auto tile_of = [&](int t) {   // first tile >= t (in this workgroup's stride) that has outputs
-        const int stride = (int)gridDim.x;
-        Tile r{t, 0, 0, 0};
-        for (; r.t < n_tiles; r.t += stride) {
-            r.b = r.t / n_tx;
-            r.q0 = (r.t - r.b * n_tx) * NT2;
-            r.len = a.base_len[r.b] * a.len_mul;
-            if (r.q0 < r.len) break;
-        }
-        return r;
-    };
-    auto issue_window = [&](int b, int q0, int len, int buf) {   // loader wave: row i <-> position q0 - P2 - P1 + i
-        const _Float16* yb = reinterpret_cast<const _Float16*>(a.y) + (long)b * a.bstride;
-#pragma unroll 1
-        for (int ii = 0; ii < NCH * XI; ++ii) {
-            const int c = ii / XI, s2 = (ii - c * XI) * 64 + lane, row = s2 >> 1, h = (s2 & 1) ^ ((row >> 3) & 1);
-            const int t = q0 - P2 - P1 + row;
-            const char* src = (t >= 0 && t < len) ? reinterpret_cast<const char*>(yb + ((long)c * a.stride + t) * 16 + 8 * h)
-                                                  : reinterpret_cast<const char*>(a.zeros);
-            glds16(src, __builtin_amdgcn_readfirstlane(xs_l + (unsigned)buf * (NCH * XROW * 32) + (unsigned)ii * 1024));
-        }
-    };
-
-    // the round's weights as A fragments (lane: output channel l31, input channels 8 hi .. 8 hi + 7 of the chunk)
-    h16x8 w1f[NCH][KS], w2f[W2L ? 1 : NCH][W2L ? 1 : KS];
-    if constexpr (W2L) {   // image of w2 with the two 16-byte halves of row i swapped when bit 3 of i is set (conflict-free b128 reads)
-        for (int u = tid; u < NCH * KS * C * 2; u += 512) {
-            const int row = u >> 1, hh = u & 1;
-            *reinterpret_cast<h16x8*>(&w2s[row * 32 + 16 * (hh ^ ((row >> 3) & 1))]) =
-                *reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(a.w2) + (long)u * 16);
-        }
-    }
-    if (tid < C) {
-        bsm[0][tid] = a.b1[tid];
-        bsm[1][tid] = a.b2[tid];
-    }
-    if (!loader) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int j = 0; j < KS; ++j) {
-                const long off = (long)c * WCH + ((j * C + l31) * 2 + hi) * 16;
-                w1f[c][j] = *reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(a.w1) + off);
-                if constexpr (!W2L) w2f[c][j] = *reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(a.w2) + off);
-            }
-    }
-
-    Tile cur = tile_of((int)blockIdx.x);
-    if (loader && cur.t < n_tiles) {
-        issue_window(cur.b, cur.q0, cur.len, 0);
-        wait_vmcnt<0>();
-    }
-    int buf = 0;
-    while (cur.t < n_tiles) {
-        const Tile nxt = tile_of(cur.t + (int)gridDim.x);
-        const int b = cur.b, q0 = cur.q0, len = cur.len;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // A: this tile's window has landed; everybody is done with the previous tile
-        f32x16 acc;
-        if (loader) {
-            if (nxt.t < n_tiles) issue_window(nxt.b, nxt.q0, nxt.len, buf ^ 1);
-        } else {
-            // ---- conv1 over the NT1 positions q0 - P2 .. of the tile
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const char* xb = &xs[buf][0];
-#pragma unroll
-            for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                for (int j = 0; j < KS; ++j) {
-                    const int i = wvs * 32 + l31 + j * DIL;
-                    const h16x8 bv = *reinterpret_cast<const h16x8*>(xb + ((long)c * XROW + i) * 32 + swz16(i, hi));
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1f[c][j], bv, acc, 0, 0, 0);
-                }
-            // h = fp16(lrelu(. + b1)), zero outside the utterance (conv2 pads the conv1 OUTPUT with zeros)
-            const int p = wvs * 32 + l31, pg = q0 - P2 + p;
-            const bool in = pg >= 0 && pg < len;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int c = 4 * hi + 8 * g4;
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(&bsm[0][c]);
-                h16x4v hv;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) hv[k] = (_Float16)(in ? lrelu(acc[4 * g4 + k] + bb[k], 0.1f) : 0.f);
-                *reinterpret_cast<h16x4v*>(hs + ((long)(c >> 4) * HROW + p) * 32 + swz16(p, (c & 15) >> 3) + (c & 7) * 2) = hv;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // B: h is complete
-        if (loader) {
-            wait_vmcnt<0>();            // the next tile's window, in flight under the consumers' conv1 / conv2
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                for (int j = 0; j < KS; ++j) {
-                    const int i = wvs * 32 + l31 + j;
-                    const h16x8 bv = *reinterpret_cast<const h16x8*>(hs + ((long)c * HROW + i) * 32 + swz16(i, hi));
-                    h16x8 av;
-                    if constexpr (W2L) av = *reinterpret_cast<const h16x8*>(&w2s[((c * KS + j) * C + l31) * 32 + 16 * (hi ^ ((l31 >> 3) & 1))]);
-                    else av = w2f[c][j];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
-                }
-            // ---- epilogue: + b2 + residual (the window's own rows, un-activated) -> stream / MRF
-            const long ob = (long)b * a.bstride;
-            const int p = wvs * 32 + l31, q = q0 + p;
-            const bool ok = p < NT2 && q < len;
-            const int qc = min(q, len - 1), i = min(p, NT2 - 1) + P2 + P1;
-            h16x4v mold[4];
-            if (a.mrf_mode >= 2) {
-                const _Float16* mb = reinterpret_cast<const _Float16*>(a.mrf) + ob;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int c = 4 * hi + 8 * g4;
-                    mold[g4] = *reinterpret_cast<const h16x4v*>(mb + ((long)(c >> 4) * a.stride + qc) * 16 + (c & 15));
-                }
-            }
-            if (ok) {
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int c = 4 * hi + 8 * g4;
-                    const h16x4v yv = *reinterpret_cast<const h16x4v*>(&xs[buf][0] + ((long)(c >> 4) * XROW + i) * 32 + swz16(i, (c & 15) >> 3) + (c & 7) * 2);
-                    const f32x4 bb = *reinterpret_cast<const f32x4*>(&bsm[1][c]);
-                    float val[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float yk = (float)yv[k];
-                        val[k] = acc[4 * g4 + k] + bb[k] + (yk < 0.f ? yk * 10.0f : yk);
-                    }
-                    const long off = ((long)(c >> 4) * a.stride + q) * 16 + (c & 15);
-                    h16x4v o;
-                    if (a.mrf_mode == 0) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) o[k] = (_Float16)lrelu(val[k], 0.1f);
-                        *reinterpret_cast<h16x4v*>(reinterpret_cast<_Float16*>(a.out) + ob + off) = o;
-                    } else if (a.mrf_mode == 1 || a.mrf_mode == 2) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) o[k] = (_Float16)(a.mrf_mode == 2 ? val[k] + (float)mold[g4][k] : val[k]);
-                        *reinterpret_cast<h16x4v*>(reinterpret_cast<_Float16*>(a.mrf) + ob + off) = o;
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) o[k] = (_Float16)lrelu(((float)mold[g4][k] + val[k]) / 3.0f, a.e_slope);
-                        *reinterpret_cast<h16x4v*>(reinterpret_cast<_Float16*>(a.e_out) + ob + off) = o;
-                    }
-                }
-            }
-        }
-        cur = nxt;
-        buf ^= 1;
-    }
-}
-
-template <int KS, int DIL>
-static void launch_round32_ws(const RoundArgs& a, hipStream_t st) {
-    constexpr int nt2 = 224 - (KS - 1);
-    const int n_tx = (a.max_len + nt2 - 1) / nt2, n_tiles = n_tx * a.B;
-    int cus = 256;
-    {
-        static int cached = 0;
-        if (!cached) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cached = prop.multiProcessorCount;
-            else cached = 256;
-        }
-        cus = cached;
-    }
-    hipLaunchKernelGGL((resblock_round32_ws_kernel<KS, DIL>), dim3((unsigned)std::min(n_tiles, cus)), dim3(512), 0, st, a, n_tx, n_tiles);
-}
-
 template <int KS, int DIL>
 static void launch_round_c(const RoundArgs& a, hipStream_t st) {
     trace_launch("resblock_round_f16_kernel");
@@ -1108,13 +908,14 @@ static void launch_round_c(const RoundArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((resblock_round_f16_kernel<KS, DIL, 64, 1, 128>), dim3((a.max_len + nt2 - 1) / nt2, a.B), dim3(512), 0, st, a);
         return;
     }
-    if (a.C == 32) {   // persistent, weight-stationary (the per-tile kernel at 32 channels: 256 positions, 32 per wave, 9.6 ms per stage)
-        launch_round32_ws<KS, DIL>(a, st);
-        return;
-    }
+    // (A persistent, weight-stationary form of the 32-channel round -- both convs' weights as A fragments in registers, a loader
+    // wave double- / triple-buffering the window by LDS-DMA, seven consumer waves, two barriers per tile -- measured SLOWER than
+    // this per-tile kernel in every variant: 10.6 ms per stage with one tile of lead, 11.2 with two, 10.2 with two workgroups
+    // per CU for k = 3 / 7, against 9.6; bit-identical results.  DESIGN section 7.)
     constexpr int nt2 = 256 - (KS - 1);
     const dim3 grid((a.max_len + nt2 - 1) / nt2, a.B);
     if (a.C == 64) hipLaunchKernelGGL((resblock_round_f16_kernel<KS, DIL, 64, 2, 256>), grid, dim3(512), 0, st, a);
+    else if (a.C == 32) hipLaunchKernelGGL((resblock_round_f16_kernel<KS, DIL, 32, 1, 256>), grid, dim3(512), 0, st, a);
     else throw InvalidArgument("resblock round: 64 or 32 channels");
 }
 
