@@ -278,7 +278,8 @@ def read_checkpoint_config(root: str, gpt_sd: Optional[Dict[str, Tensor]] = None
     nested = (xj or {}).get("gpt_config") or {}
 
     def get(key, default):
-        return gj.get(key, nested.get(key, default))
+        v = gj.get(key, nested.get(key))
+        return default if v is None else v   # an explicit JSON null means "not given"
 
     def need(key, default, want, what):
         v = get(key, default)
@@ -298,7 +299,12 @@ def read_checkpoint_config(root: str, gpt_sd: Optional[Dict[str, Tensor]] = None
     eps = float(get("layer_norm_epsilon", 1e-5))
     if abs(eps - g.ln_eps) > 1e-12:
         raise CheckpointConfigError(f"gpt/config.json: layer_norm_epsilon = {eps!r}, kernels use {g.ln_eps!r}")
-    act = get("activation_function", "gelu")
+    act = get("activation_function", None)
+    if act is None:   # neither config names it: XTTSGPTConfig's class default (xttsv2_gpt_config.py:184), and say so
+        import logging
+        logging.getLogger("auralis_amd").warning("gpt/config.json has no activation_function: using the XTTSGPTConfig default 'gelu' "
+                                                 "(erf form); checkpoints written by the reference's converter say 'gelu_new'")
+        act = "gelu"
     if act in ("gelu_new", "gelu_pytorch_tanh"):
         act = "gelu_new"
     elif act != "gelu":

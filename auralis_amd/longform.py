@@ -111,12 +111,16 @@ def stream_sharded(tts, requests: Sequence[TTSRequest], window: int = 8, paragra
     local_q: "queue.Queue" = queue.Queue()
     _END = object()
 
+    stop = threading.Event()   # set when this rank stops consuming: the producer drops what it still has instead of synthesising on
+
     def produce():
         """(paragraph, pcm) per chunk and (paragraph, None) once per OWNED paragraph, in index order, also for a paragraph that
         produced no chunk at all; an exception travels through the queue"""
         try:
             done = 0                                               # paragraphs of `mine` already terminated
             for local_i, chunk in stream_longform(tts, [requests[i] for i in mine], window):
+                if stop.is_set():
+                    return
                 while done < local_i:
                     local_q.put((mine[done], None))
                     done += 1
@@ -160,11 +164,15 @@ def stream_sharded(tts, requests: Sequence[TTSRequest], window: int = 8, paragra
                     if pcm.shape[0]:
                         dist.send(torch.from_numpy(pcm).to(dev), dst=dst)
         except BaseException as e:                                 # tell dst instead of leaving it in recv forever
-            msg = f"rank {rank}: {type(e).__name__}: {e}".encode("utf-8", "replace")[:4096]
-            send_hdr(-1, _ERROR, len(msg))
-            dist.send(torch.frombuffer(bytearray(msg), dtype=torch.uint8).to(dev), dst=dst)
+            # ... unless the failure IS the channel (a send that raised: peer gone, communicator aborted): a second blocking send
+            # on it would hang where the first one failed
+            if not isinstance(e, (dist.DistBackendError, dist.DistNetworkError, ConnectionError, BrokenPipeError)):
+                msg = f"rank {rank}: {type(e).__name__}: {e}".encode("utf-8", "replace")[:4096]
+                send_hdr(-1, _ERROR, len(msg))
+                dist.send(torch.frombuffer(bytearray(msg), dtype=torch.uint8).to(dev), dst=dst)
             raise
         finally:
+            stop.set()
             th.join(timeout=5.0)
         return
 
@@ -221,7 +229,8 @@ def stream_sharded(tts, requests: Sequence[TTSRequest], window: int = 8, paragra
                         break
             except RuntimeError:
                 pass                                               # that rank's stream has ended with its own error
-        th.join(timeout=5.0)
+        stop.set()                                                 # (the drain above blocks until the other ranks have sent what they
+        th.join(timeout=5.0)                                       # had queued: they stop at their next chunk, not at once)
 
 
 def synthesize_sharded(tts, requests: Sequence[TTSRequest], window: int = 8, paragraphs_per_block: int = 8,

@@ -489,10 +489,13 @@ def main():
     ap.add_argument("--gemm", choices=["bf16x3", "f32"], default="bf16x3",
                     help="GEMM arithmetic: bf16x3 = exact 3-way bf16 split of the fp32 operands, 6 bf16 MFMAs per product, fp32 "
                          "accumulate (default, what the parity tests run); f32 = v_mfma_f32_*_f32 (aur_config.gemm_f32_exact)")
-    ap.add_argument("--bcast", choices=["native", "torch"], default="native",
-                    help="multi-GPU launches: native = the ncclBroadcast inside the library on the engine's own RCCL communicator "
-                         "(aur_comm_init / aur_broadcast_conditioning, default); torch = torch.distributed.broadcast into a device "
-                         "buffer registered with aur_set_conditioning_device")
+    ap.add_argument("--bcast", choices=["native", "torch"], default="torch",
+                    help="multi-GPU launches, conditioning broadcast BEFORE the measurements: torch (default) = torch.distributed.broadcast "
+                         "into a device buffer registered with aur_set_conditioning_device; native = the ncclBroadcast inside the library on "
+                         "the engine's own RCCL communicator (aur_comm_init / aur_broadcast_conditioning).  The native route has only run at "
+                         "world size 1 in the build environment, and a collective that hangs cannot be fallen back from: with the default it "
+                         "is exercised AFTER the measurements instead, under a watchdog, and reported as multi_gpu.native_route")
+    ap.add_argument("--native-check-timeout", type=float, default=90.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the c2 / c5s (and, N > 1, c4) measurements after the headline")
     ap.add_argument("--no-profile-pass", action="store_true")
@@ -668,6 +671,33 @@ def main():
             c5 = side("c5s", lambda: B.workload_c5s(args.c5_chars))
         else:
             c4 = B.workload_c4()   # collective: no try/except around a path every rank must walk together
+    # ---- the in-library RCCL route, after every measurement is in hand: a second voice key is broadcast with aur_comm_init /
+    # aur_broadcast_conditioning on the engine's own communicator and must arrive byte-identical to the first one.  Under a
+    # watchdog: a hang ends in "timeout" in the line (and a hard exit after it has been printed), not in a lost run.
+    hard_exit = False
+    if use_dist and route == "torch":
+        import threading
+        from auralis_amd.parallel import broadcast_conditioning_native
+        res = {}
+
+        def native():
+            try:
+                broadcast_conditioning_native(eng, SPK + 1, B.cond if rank == 0 else None, B.spk if rank == 0 else None, src=0)
+                res["ranks"], res["rank0"] = eng.comm_info()
+                res["same_bytes"] = eng.conditioning_checksum(SPK + 1) == eng.conditioning_checksum(SPK)
+                res["status"] = "ok" if res["same_bytes"] and res["ranks"] == world else "mismatch"
+            except Exception as ex:   # noqa: BLE001 - reported in the bench line
+                res["status"] = f"failed: {type(ex).__name__}: {str(ex)[:120]}"
+        th = threading.Thread(target=native, daemon=True)
+        th.start()
+        th.join(args.native_check_timeout)
+        if th.is_alive():
+            res["status"] = "timeout"
+            hard_exit = True
+        multi["native_route"] = res.get("status")
+        multi["native_rccl_ranks"] = res.get("ranks")
+        if line is not None:
+            line["multi_gpu"] = multi
     if rank == 0:
         line["c2"], line["c5s"], line["c4"] = c2, c5, c4
         if world == 1 and not args.no_cpu_baseline:
@@ -687,6 +717,9 @@ def main():
         txt = json.dumps(comp, separators=(",", ":"))
         _log(f"compact line: {len(txt)} bytes")
         print(txt, file=json_out, flush=True)
+    if hard_exit:   # a rank is stuck inside the native collective: nothing below would return
+        sys.stderr.flush()
+        os._exit(0)
     eng.close()
     if use_dist:
         torch.distributed.destroy_process_group()
