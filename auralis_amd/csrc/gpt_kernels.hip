@@ -920,8 +920,9 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
                                                               const int* __restrict__ slot_kvpos,
                                                               const int* __restrict__ block_tables, int max_blocks,
                                                               float* __restrict__ out, int out_mtt, const int* __restrict__ row_meta) {
-    // (16 token steps in flight for M <= 16 rows -- one loop iteration per 256 tokens -- measured no gain, 9.6 us per launch at
-    // M = 1 either way: the launch is the dependent chain row_meta -> block ids -> K/V, not the loop; profiles/r04_gemm_bench_m1.log)
+    // (16 token steps in flight for M <= 16 rows -- one loop iteration per 256 tokens: at one row 8.2 vs 9.0 us at 244 tokens, but
+    // 6.3 vs 4.9 at 64 and 12.5 vs 12.2 at 384, profiles/r04_gemm_bench_attention.log.  The launch is 3.5 us + 1.5 us per 64 tokens: one
+    // CU per (row, head) pulls its K/V at 21-25 KB/us whatever the unroll.  Not kept.)
     constexpr int UN = 4;                    // token steps in flight per workgroup iteration (8 measured slower at 64 rows: registers)
     constexpr int LPT = KVH ? 8 : 16;        // lanes per token
     constexpr int EPL = kHeadDim / LPT;      // elements per lane

@@ -298,6 +298,37 @@ int main(int argc, char** argv) {
                 launch_variant(a, shapes[3], policy(M, shapes[3], prec), st);
             }
         };
+        // decode attention alone, by context length (all rows at the same position): intercept = the launch's fixed chain, slope = per
+        // 64-token iteration
+        for (int pos : {0, 63, 127, 243, 383, 639}) {
+            std::vector<int> hp(256, pos);
+            std::vector<int> hrm2((size_t)256 * kRowMetaStride, 0);
+            for (int i = 0; i < 256; ++i) {
+                int* rm = &hrm2[(size_t)i * kRowMetaStride];
+                rm[0] = pos;
+                rm[1] = hslot[i];
+                rm[kRowMetaWblk] = hbt[hslot[i] * 66 + pos / kKvBlockTokens];
+                for (int j = 0; j < 66; ++j) rm[kRowMetaBt + j] = hbt[hslot[i] * 66 + j];
+            }
+            HIP_CHECK(hipMemcpy(drm, hrm2.data(), hrm2.size() * 4, hipMemcpyHostToDevice));
+            int l = 0;
+            const float us = time_us(st, 120, [&] {
+                float* kvl = kv + (size_t)(l++ % n_layers) * kv_blocks * kKvBlockElems;
+                launch_paged_attention(qb, kvl, dslot, nullptr, dpos, dbt, 66, att, M, st, MTT, false, drm);
+            });
+            printf("paged attention alone M=%d context %3d tokens: %.2f us per launch\n", M, pos + 1, us);
+        }
+        {   // restore the chain's positions
+            std::vector<int> hrm2((size_t)256 * kRowMetaStride, 0);
+            for (int i = 0; i < 256; ++i) {
+                int* rm = &hrm2[(size_t)i * kRowMetaStride];
+                rm[0] = hpos[i];
+                rm[1] = hslot[i];
+                rm[kRowMetaWblk] = hbt[hslot[i] * 66 + hpos[i] / kKvBlockTokens];
+                for (int j = 0; j < 66; ++j) rm[kRowMetaBt + j] = hbt[hslot[i] * 66 + j];
+            }
+            HIP_CHECK(hipMemcpy(drm, hrm2.data(), hrm2.size() * 4, hipMemcpyHostToDevice));
+        }
         for (int pol = 0; pol < 2; ++pol) {
             policy = pol ? r04_policy : r03_policy;
             for (int attn : {0, 1})
