@@ -222,6 +222,7 @@ public:
         xt_f16_ = cfg_.vocoder_fp16 != 0;   // fp16 storage of the ResBlock intermediates and residual stream (see ConvArgs)
         if (const char* e = getenv("AUR_XT_F16")) xt_f16_ = xt_f16_ && atoi(e) != 0;
         if (const char* e = getenv("AUR_CONV_DMA")) conv_dma_ = atoi(e) != 0;   // 0: register-staged ResBlock convs (A/B only)
+        if (const char* e = getenv("AUR_GEMM_BDMA")) gemm_bdma_ = atoi(e) != 0; // 0: prompt-row GEMMs split their weights per tile (A/B only)
         if (const char* e = getenv("AUR_DECODE_PIPELINE")) pipeline_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_SAMPLER_FULL_SORT")) sampler_full_sort_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_TEST_FAIL_STEP")) fail_at_step_ = atoi(e);
@@ -821,7 +822,12 @@ public:
         dp.ensure((size_t)M * N * 4);
         HIP_CHECK(hipMemcpy(dx.p, X, (size_t)M * K * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(dw.p, Wm, (size_t)K * N * 4, hipMemcpyHostToDevice));
-        launch_gemm_tile(dx.as<float>(), K, dw.as<float>(), dp.as<float>(), M, N, K, st_, nullptr, gemm_prec_);
+        DevBuf ds;   // the pre-split weight operand, as ensure_gpt() prepares it for the prompt-row GEMMs
+        if (gemm_prec_ == 1 && gemm_bdma_ && N % 128 == 0) {
+            ds.ensure((size_t)3 * K * N * 2);
+            launch_pack_wsplit(dw.as<float>(), N, ds.p, K, N, st_);
+        }
+        launch_gemm_tile(dx.as<float>(), K, dw.as<float>(), dp.as<float>(), M, N, K, st_, nullptr, gemm_prec_, 1, ds.p);
         HIP_CHECK(hipStreamSynchronize(st_));
         HIP_CHECK(hipMemcpy(out, dp.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     }
@@ -1043,6 +1049,7 @@ private:
     };
     struct LayerW {
         const float *ln1w, *ln1b, *wqkv, *bqkv, *wproj, *bproj, *ln2w, *ln2b, *wfc, *bfc, *wproj2, *bproj2;
+        const void *sqkv, *sproj, *sfc, *sproj2;    // launch_pack_wsplit copies for the prefill-regime GEMM (three bf16 planes, DMA-staged)
         const float *tqkv, *tproj, *tfc, *tproj2;   // pack_wt16 copies for the decode-regime GEMM (gemm_rows_kernel); tqkv / tfc
                                                     // have LayerNorm folded in (launch_fold_ln)
         const float *qkv_c1, *qkv_c2, *fc_c1, *fc_c2;   // ... with these epilogue vectors
@@ -1054,6 +1061,15 @@ private:
         b.ensure((size_t)K * N * sizeof(float));
         launch_pack_wt16(Wm, ldw, b.as<float>(), K, N, st_);
         return b.as<float>();
+    }
+    // pre-split copy of one [K][N] matrix for the prompt-row GEMM (only the split arithmetic uses it)
+    const void* split_copy(const float* Wm, int K, int N) {
+        if (gemm_prec_ != 1 || !gemm_bdma_) return nullptr;
+        packed_.emplace_back(new DevBuf());
+        DevBuf& b = *packed_.back();
+        b.ensure((size_t)3 * K * N * 2);
+        launch_pack_wsplit(Wm, N, b.p, K, N, st_);
+        return b.p;
     }
     // LayerNorm-folded packed copy of a [K][N] matrix plus its two epilogue vectors (launch_fold_ln)
     const float* folded_copy(const float* Wm, const float* gamma, const float* beta, const float* bias, int K, int N,
@@ -1084,6 +1100,7 @@ private:
             l.wfc = W(p + "mlp.c_fc.w", (int64_t)H * 4 * H); l.bfc = W(p + "mlp.c_fc.b", 4 * H);
             l.wproj2 = W(p + "mlp.c_proj.w", (int64_t)4 * H * H); l.bproj2 = W(p + "mlp.c_proj.b", H);
             l.tqkv = l.tproj = l.tfc = l.tproj2 = nullptr;
+            l.sqkv = l.sproj = l.sfc = l.sproj2 = nullptr;
             l.qkv_c1 = l.qkv_c2 = l.fc_c1 = l.fc_c2 = nullptr;
             layers_.push_back(l);
         }
@@ -1094,6 +1111,10 @@ private:
                 l.tproj = packed_copy(l.wproj, H, H, H);
                 l.tfc = folded_copy(l.wfc, l.ln2w, l.ln2b, l.bfc, H, 4 * H, &l.fc_c1, &l.fc_c2);
                 l.tproj2 = packed_copy(l.wproj2, H, 4 * H, H);
+                l.sqkv = split_copy(l.wqkv, H, 3 * H);
+                l.sproj = split_copy(l.wproj, H, H);
+                l.sfc = split_copy(l.wfc, H, 4 * H);
+                l.sproj2 = split_copy(l.wproj2, 4 * H, H);
             }
         }
         wte_ = W("gpt.wte", (int64_t)kMelVocab * H);
@@ -1320,16 +1341,16 @@ private:
         for (int l = 0; l < cfg_.n_layer; ++l) {
             const LayerW& L = layers_[l];
             void* kvl = kv_layer(l);
-            launch_gemm_tile(xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, w.st, nullptr, gemm_prec_);
+            launch_gemm_tile(xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, w.st, nullptr, gemm_prec_, 1, L.sqkv);
             launch_qkv_epilogue(P, 1, L.bqkv, w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, w.st, kv_half_);
             launch_prompt_attention(w.qbuf.as<float>(), kvl, w.i_qblk.as<int2>(), n_qblk, d_row_slot, d_row_pos, bt, kMaxBlocks, w.att.as<float>(), w.st, kv_half_);
-            launch_gemm_tile(w.att.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, w.st, nullptr, gemm_prec_);
+            launch_gemm_tile(w.att.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, w.st, nullptr, gemm_prec_, 1, L.sproj);
             launch_rows_ln(P, 1, L.bproj, h, L.ln2w, L.ln2b, xn, M, 1e-5f, w.st);
             const GemmGelu ge{L.bfc, w.act.as<float>(), cfg_.gelu_erf ? 1 : 0};
-            launch_gemm_tile(xn, kHidden, L.wfc, P, M, 4 * kHidden, kHidden, w.st, &ge, gemm_prec_);
+            launch_gemm_tile(xn, kHidden, L.wfc, P, M, 4 * kHidden, kHidden, w.st, &ge, gemm_prec_, 1, L.sfc);
             // K = 4096 against N = 1024: four K-slabs (4x the workgroups of a GEMM that otherwise fills one round of CUs with
             // 256 dependent k-steps); rows_ln sums them in a fixed order
-            launch_gemm_tile(w.act.as<float>(), 4 * kHidden, L.wproj2, P, M, kHidden, 4 * kHidden, w.st, nullptr, gemm_prec_, kProj2Slabs);
+            launch_gemm_tile(w.act.as<float>(), 4 * kHidden, L.wproj2, P, M, kHidden, 4 * kHidden, w.st, nullptr, gemm_prec_, kProj2Slabs, L.sproj2);
             const bool last = (l + 1 == cfg_.n_layer);
             launch_rows_ln(P, kProj2Slabs, L.bproj2, h, last ? lnfw_ : layers_[l + 1].ln1w, last ? lnfb_ : layers_[l + 1].ln1b,
                            xn, M, 1e-5f, w.st);
@@ -2046,6 +2067,7 @@ private:
     int profile_every_ = kProfileEvery;
     DevBuf prof_q_, prof_h_, prof_stats_, prof_act_, prof_kv_;   // output scratch of profile_replay
     DevBuf ksp_buf_, ksp_cnt_;   // GemmRowsArgs::ksp_buf / ksp_cnt
+    bool gemm_bdma_ = true;      // prompt-row GEMMs: weights pre-split at load time and staged by LDS-DMA
     double step_kv_tokens_ = 0.0;       // sum of context lengths of the step being launched (profile accounting)
     long decode_step_count_ = 0;
     float event_overhead_ms_ = -1.f;

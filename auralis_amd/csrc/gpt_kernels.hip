@@ -169,16 +169,30 @@ __device__ __forceinline__ void split3_bf16x4(const f32x4& x, bf16x4& h, bf16x4&
     }
 }
 
-template <int BM, int BN, bool GELU>
+// BD: the weight operand comes PRE-SPLIT (launch_pack_wsplit: the three bf16 planes of W, per 128-column tile and k step one
+// contiguous 12 KB block [plane][128 n][16 k]) and is staged by LDS-DMA (global_load_lds_dwordx4, three 1-KiB copies per wave and k
+// step for a 128-wide tile) straight into the buffer the NEXT step reads: no staging registers, no split arithmetic (weights
+// are static: half of the kernel's VALU work and of its LDS writes was splitting the same weights again for every row tile of
+// every prefill), no ds_write.  A DMA lands lane-linear, so the B rows are unpadded 32-byte rows whose two 16-byte halves are
+// swapped when bit 3 of the row index is set -- on the source address of the copy and on the fragment read (conflict-free b128
+// reads, as in the vocoder's conv1d_dma_f16_kernel).  Same split, same MFMA order: bitwise the register-staged result.
+__device__ __forceinline__ void glds16_g(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;   // M0 carries the LDS destination; hipcc owns M0, so save / restore it inside the statement
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int BM, int BN, bool GELU, bool BD = false>
 __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W,
-                                                                 float* __restrict__ P, int M, int N, int K, GemmGelu ep) {
+                                                                 float* __restrict__ P, int M, int N, int K, GemmGelu ep,
+                                                                 const __bf16* __restrict__ Wsp = nullptr) {
     static_assert((BM == 128 || BM == 64) && (BN == 128 || BN == 64), "tile shapes");
     constexpr int BK = 16, RS = 24;              // bf16 per LDS row: 16 k + 8 pad
     constexpr int MI = BM / 64, NI = BN / 64;    // 32 x 32 MFMA tiles per wave (waves form a 2 x 2 grid over the tile)
     constexpr int LA = BM / 64;                  // float4 loads (4 k of one row) per thread and K step
     constexpr int LB = BN / 64;                  // k-quads of one column per thread and K step (4 dword loads each)
+    constexpr int RB = BD ? 16 : RS;             // B rows: unpadded (DMA) or padded (register-staged)
     __shared__ __attribute__((aligned(16))) __bf16 As[2][3][BM * RS];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][3][BN * RS];
+    __shared__ __attribute__((aligned(1024))) __bf16 Bs[2][3][BN * RB];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5, wm = wv >> 1, wn = wv & 1;
     const int n_nt = N / BN, n_mt = (M + BM - 1) / BM;
@@ -197,8 +211,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
     const int m0 = mtile * BM, n0 = ntile * BN;
     // split-K slabs (grid.y): slab s multiplies columns [s*K, (s+1)*K) of X with the matching rows of W into P[s] (K = slab depth)
     X += (long)blockIdx.y * K;
-    W += (long)blockIdx.y * K * N;
+    if constexpr (!BD) W += (long)blockIdx.y * K * N;
     P += (long)blockIdx.y * M * N;
+    // pre-split weights: block (128-column tile t, k step s) of 3 x 128 x 16 bf16 at ((t * ksteps_total) + s) * 6144 elements
+    const int ks_total = (int)gridDim.y * (K / BK), ks0 = (int)blockIdx.y * (K / BK);
+    const __bf16* wsp_tile = BD ? Wsp + ((long)(n0 / 128) * ks_total + ks0) * (3 * 128 * 16) + (n0 % 128) * 16 : nullptr;
+    const unsigned bs_l = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)&Bs[0][0][0];
+    auto b_dma = [&](int st, int buf) {   // the B tile of k step st into Bs[buf]: 3 * BN / 32 copies of 1 KiB, wave w takes w, w + 4, ..
+        constexpr int NC = 3 * BN / 32;
+#pragma unroll
+        for (int k = 0; k < (NC + 3) / 4; ++k) {
+            const int ii = __builtin_amdgcn_readfirstlane(wv) + 4 * k;
+            if (ii < NC) {
+                const int p = ii / (BN / 32), r = ii - p * (BN / 32);
+                const int row = 32 * r + (lane >> 1), h = (lane & 1) ^ ((row >> 3) & 1);
+                const char* src = reinterpret_cast<const char*>(wsp_tile + (long)st * (3 * 128 * 16) + p * (128 * 16)) + row * 32 + h * 16;
+                glds16_g(src, __builtin_amdgcn_readfirstlane(bs_l + (unsigned)((buf * 3 + p) * BN * 32 + r * 1024)));
+            }
+        }
+    };
     const int a_row = tid >> 2, a_kq = tid & 3;          // A: rows a_row (+64), k-quad a_kq
     const int b_n = tid % BN, b_kq = tid / BN;           // B: column b_n, k-quads b_kq (+ 256 / BN)
     const float* ap[LA];
@@ -215,10 +246,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
     auto g_load = [&](f32x4 (&a4)[LA], f32x4 (&b4)[LB], int k0) {
 #pragma unroll
         for (int i = 0; i < LA; ++i) a4[i] = *reinterpret_cast<const f32x4*>(ap[i] + k0);
+        if constexpr (!BD) {
 #pragma unroll
-        for (int i = 0; i < LB; ++i)
+            for (int i = 0; i < LB; ++i)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) b4[i][c] = bp[(long)(k0 + 4 * (b_kq + (256 / BN) * i) + c) * N];
+                for (int c = 0; c < 4; ++c) b4[i][c] = bp[(long)(k0 + 4 * (b_kq + (256 / BN) * i) + c) * N];
+        }
     };
     auto s_store = [&](const f32x4 (&a4)[LA], const f32x4 (&b4)[LB], int buf) {
 #pragma unroll
@@ -230,14 +263,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
             *reinterpret_cast<bf16x4*>(&As[buf][1][o]) = m;
             *reinterpret_cast<bf16x4*>(&As[buf][2][o]) = l;
         }
+        if constexpr (!BD) {
 #pragma unroll
-        for (int i = 0; i < LB; ++i) {
-            bf16x4 h, m, l;
-            split3_bf16x4(b4[i], h, m, l);
-            const int o = b_n * RS + 4 * (b_kq + (256 / BN) * i);
-            *reinterpret_cast<bf16x4*>(&Bs[buf][0][o]) = h;
-            *reinterpret_cast<bf16x4*>(&Bs[buf][1][o]) = m;
-            *reinterpret_cast<bf16x4*>(&Bs[buf][2][o]) = l;
+            for (int i = 0; i < LB; ++i) {
+                bf16x4 h, m, l;
+                split3_bf16x4(b4[i], h, m, l);
+                const int o = b_n * RS + 4 * (b_kq + (256 / BN) * i);
+                *reinterpret_cast<bf16x4*>(&Bs[buf][0][o]) = h;
+                *reinterpret_cast<bf16x4*>(&Bs[buf][1][o]) = m;
+                *reinterpret_cast<bf16x4*>(&Bs[buf][2][o]) = l;
+            }
         }
     };
     f32x16 acc[MI][NI], lo[MI][NI];
@@ -248,14 +283,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = lo[mi][ni][r] = 0.f;
     const int n_steps = K / BK;
+    if constexpr (BD) b_dma(0, 0);
     g_load(ga[0], gb[0], 0);
     if (n_steps > 1) g_load(ga[1], gb[1], BK);
     s_store(ga[0], gb[0], 0);
+    if constexpr (BD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int ao = (wm * (BM / 2) + l31) * RS + 8 * hi, bo = (wn * (BN / 2) + l31) * RS + 8 * hi;
+    const int ao = (wm * (BM / 2) + l31) * RS + 8 * hi;
+    // B fragment of column tile ni: row wn * BN/2 + 32 ni + l31 (k-half hi); unpadded rows carry the half swap of the DMA
+    const int brow = wn * (BN / 2) + l31;
+    const int bo = BD ? brow * 16 + 8 * (hi ^ ((brow >> 3) & 1)) : brow * RS + 8 * hi;
     // step st: LDS buffer st & 1 holds it, register set (st + 1) & 1 holds step st + 1, set st & 1 is free for step st + 2
     auto step = [&](auto PAR, int st) {
         constexpr int par = decltype(PAR)::value;
+        // the weights of step st + 1 go straight into the buffer step st - 1 has just been read from (everybody is past that step's
+        // barrier); issued BEFORE the activation loads of step st + 2, so that "all but the newest LA loads have returned" at the
+        // end of this step covers them
+        if constexpr (BD) {
+            if (st + 1 < n_steps) b_dma(st + 1, par ^ 1);
+        }
         if (st + 2 < n_steps) g_load(ga[par], gb[par], (st + 2) * BK);
         __builtin_amdgcn_sched_barrier(0);   // those loads are in flight before this step's MFMAs
         bf16x8 a[3][MI], b[3][NI];
@@ -264,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) a[p][mi] = *reinterpret_cast<const bf16x8*>(&As[par][p][ao + 32 * mi * RS]);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[p][ni] = *reinterpret_cast<const bf16x8*>(&Bs[par][p][bo + 32 * ni * RS]);
+            for (int ni = 0; ni < NI; ++ni) b[p][ni] = *reinterpret_cast<const bf16x8*>(&Bs[par][p][bo + 32 * ni * RB]);
         }
         // term order per accumulator as in gemm_rows_kernel (l*h.. first, h*h into its own accumulator); the tiles are the
         // inner loop so that back-to-back MFMAs never share an accumulator
@@ -274,6 +320,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
         AUR_TERM(lo, 0, 2) AUR_TERM(lo, 2, 0) AUR_TERM(lo, 1, 1) AUR_TERM(lo, 0, 1) AUR_TERM(lo, 1, 0) AUR_TERM(acc, 0, 0)
 #undef AUR_TERM
         if (st + 1 < n_steps) s_store(ga[par ^ 1], gb[par ^ 1], par ^ 1);
+        if constexpr (BD) {   // this wave's copies of step st + 1 have landed (only the LA activation loads of step st + 2 may be outstanding)
+            if (st + 2 < n_steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
     };
     for (int st = 0; st < n_steps; st += 2) {
@@ -299,8 +349,32 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
         }
 }
 
+// W[K][ldw] fp32 -> the three bf16 planes of its exact split, blocked for gemm_tile_split_kernel<.., BD = true>:
+// out[((n / 128) * (K / 16) + k / 16) * 3 + plane][n % 128][k % 16]
+__global__ __launch_bounds__(256) void pack_wsplit_kernel(const float* __restrict__ W, int ldw, __bf16* __restrict__ out, int K, int N) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // one (n, k-quad)
+    if (idx >= (long)N * (K / 4)) return;
+    const int n = (int)(idx % N), kq = (int)(idx / N);
+    const int k = 4 * kq;
+    const float* src = W + (long)k * ldw + n;
+    const f32x4 v = {src[0], src[ldw], src[2L * ldw], src[3L * ldw]};
+    bf16x4 h, m, l;
+    split3_bf16x4(v, h, m, l);
+    __bf16* o = out + (((long)(n / 128) * (K / 16) + k / 16) * 3) * (128 * 16) + (n % 128) * 16 + (k % 16);
+    *reinterpret_cast<bf16x4*>(o) = h;
+    *reinterpret_cast<bf16x4*>(o + 128 * 16) = m;
+    *reinterpret_cast<bf16x4*>(o + 2 * 128 * 16) = l;
+}
+void launch_pack_wsplit(const float* W, int ldw, void* out, int K, int N, hipStream_t st) {
+    AUR_REQUIRE(N % 128 == 0 && K % 16 == 0 && ldw >= N, "pack_wsplit: N % 128, K % 16");
+    trace_launch("pack_wsplit_kernel");
+    const long total = (long)N * (K / 4);
+    hipLaunchKernelGGL(pack_wsplit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, ldw, reinterpret_cast<__bf16*>(out), K, N);
+    HIP_CHECK(hipGetLastError());
+}
+
 void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, int N, int Kfull, hipStream_t st,
-                      const GemmGelu* gelu, int prec, int slabs) {
+                      const GemmGelu* gelu, int prec, int slabs, const void* wsplit) {
     AUR_REQUIRE(slabs >= 1 && Kfull % slabs == 0 && (slabs == 1 || !gelu), "gemm_tile: slabs");
     const int K = Kfull / slabs;
     AUR_REQUIRE(N % 64 == 0 && K % 16 == 0 && ldx % 4 == 0 && M >= 1, "gemm_tile: shape");
@@ -313,7 +387,15 @@ void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, 
     const bool small = N <= 1024 || N % 128 != 0;
 #define AUR_GT(KERN, BM_, BN_, GE) \
     hipLaunchKernelGGL((KERN<BM_, BN_, GE>), dim3((unsigned)((N / BN_) * ((M + BM_ - 1) / BM_)), (unsigned)slabs), dim3(256), 0, st, X, ldx, W, P, M, N, K, g)
-    if (prec) {
+#define AUR_GTD(BM_, BN_, GE) \
+    hipLaunchKernelGGL((gemm_tile_split_kernel<BM_, BN_, GE, true>), dim3((unsigned)((N / BN_) * ((M + BM_ - 1) / BM_)), (unsigned)slabs), dim3(256), 0, st, X, ldx, W, P, M, N, K, g, \
+                       reinterpret_cast<const __bf16*>(wsplit))
+    if (prec && wsplit && N % 128 == 0) {   // pre-split weights staged by LDS-DMA (same tile policy as below)
+        const long n128 = (long)slabs * (N / 128) * ((M + 127) / 128), n64 = (long)slabs * (N / 64) * ((M + 127) / 128);
+        if (!small || n128 >= 200) { if (gelu) AUR_GTD(128, 128, true); else AUR_GTD(128, 128, false); }
+        else if (n64 >= 200) { if (gelu) AUR_GTD(128, 64, true); else AUR_GTD(128, 64, false); }
+        else { if (gelu) AUR_GTD(64, 64, true); else AUR_GTD(64, 64, false); }
+    } else if (prec) {
         // split arithmetic, narrow GEMMs (N <= 1024): the largest tile that still gives every CU a workgroup -- 128 x 128 for a
         // 64-prompt prefill (288 workgroups, one round: 34.8 ms per prefill against 36.4 on 128 x 64 = 576 workgroups on 512
         // slots), 128 x 64 and 64 x 64 for smaller batches.  The k order of an output element is the same for every shape.
@@ -326,6 +408,7 @@ void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, 
         else { if (gelu) AUR_GT(gemm_tile_kernel, 128, 128, true); else AUR_GT(gemm_tile_kernel, 128, 128, false); }
     }
 #undef AUR_GT
+#undef AUR_GTD
     HIP_CHECK(hipGetLastError());
 }
 

@@ -64,6 +64,23 @@ def test_gemm_tile_is_batch_invariant_bitwise(eng):
         assert np.array_equal(big2[:m], eng.dbg_gemm(X2[:m].numpy(), W2.numpy())), m
 
 
+def test_gemm_tile_dma_staged_weights_equal_register_staged(eng, monkeypatch):
+    """Prompt-row GEMMs take their weights pre-split (three bf16 planes, packed at load time) and stage them by LDS-DMA;
+    AUR_GEMM_BDMA=0 selects the kernel that splits them again per tile.  Same split, same MFMA order: equal bit for bit, on
+    every tile shape (128 x 128, 128 x 64, 64 x 64) and with K slabs of different depth."""
+    monkeypatch.setenv("AUR_GEMM_BDMA", "0")
+    e_reg, *_ = make_engine(1, max_seqs=8)
+    try:
+        g = torch.Generator().manual_seed(21)
+        for M, N, K in [(71, 3072, 1024), (300, 1024, 1024), (2000, 1024, 1024), (4544, 1024, 1024), (513, 4096, 1024), (150, 1024, 4096), (1, 1024, 1024)]:
+            X = torch.randn(M, K, generator=g)
+            W = torch.randn(K, N, generator=g) * 0.05
+            a, b = eng.dbg_gemm(X.numpy(), W.numpy()), e_reg.dbg_gemm(X.numpy(), W.numpy())
+            assert np.array_equal(a, b), (M, N, K, np.abs(a - b).max())
+    finally:
+        e_reg.close()
+
+
 def _gelu_new(x):
     return 0.5 * x * (1.0 + np.tanh(np.sqrt(2.0 / np.pi) * (x + 0.044715 * x ** 3)))
 

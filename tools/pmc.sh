@@ -11,6 +11,6 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "util SQ_WAVE_CYCLES SQ_BUSY_C
   OUT=$R/gpurun_out/pmc_$TAG/$name
   mkdir -p $OUT
   timeout ${PMC_TIMEOUT:-150} rocprofv3 --pmc "$@" --kernel-include-regex "${PMC_KERNELS:-conv1d_mfma}" --output-format csv -d $OUT -o pmc -- \
-      python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-throughput-mode $PMC_BENCH_ARGS > $OUT/stdout.log 2>&1
+      python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-side --no-profile-pass --out /tmp/pmc_bench_full.json $PMC_BENCH_ARGS > $OUT/stdout.log 2>&1
   echo "pass $name rc=$?"
 done

@@ -1,8 +1,9 @@
-"""Fold the rocprofv3 PMC passes of the default bench command into profiles/hbm_traffic.json["r03_decode"] / ["r03_conv"].
+"""Fold the rocprofv3 PMC passes of the default bench command into profiles/hbm_traffic.json["<round>_decode"] / ["<round>_conv"]
+(round tag from PMC_ROUND, default r04; bench.py reads the newest keys it finds).
 
   PMC_PASSES='fetch write' PMC_KERNELS='paged_attention_kernel|gemm_rows_kernel' PMC_BENCH_ARGS='--tokens 40' tools/pmc.sh r03dec
   PMC_PASSES='fetch write' PMC_KERNELS='conv1d_|resblock_round' tools/pmc.sh r03conv
-  python tools/pmc_r03_summary.py gpurun_out/pmc_r03dec 40 gpurun_out/pmc_r03conv
+  python tools/pmc_round_summary.py gpurun_out/pmc_r03dec 40 gpurun_out/pmc_r03conv
 
 Units and corrections (MI355X_MICROARCH.md §HBM): Counter_Value is KiB per dispatch; FETCH_SIZE reports 1/2 of the bytes of a
 wide coalesced streaming read (16 B per lane), other access widths are uncalibrated, WRITE_SIZE is taken as reported.
@@ -44,7 +45,7 @@ def decode_summary(d, T):
         return g
     f, w = load(os.path.join(d, "fetch", "pmc_counter_collection.csv")), load(os.path.join(d, "write", "pmc_counter_collection.csv"))
     out = {"command": f"PMC_PASSES='fetch write' PMC_KERNELS='paged_attention_kernel|gemm_rows_kernel' PMC_BENCH_ARGS='--tokens {T}' "
-                      f"tools/pmc.sh r03dec; python tools/pmc_r03_summary.py ...",
+                      f"tools/pmc.sh <tag>; python tools/pmc_round_summary.py ...",
            "fetch_correction": "x2 (16 B per lane streaming reads, MI355X_MICROARCH.md §HBM); WRITE_SIZE as reported"}
     for key, _, alg in DECODE:
         if key not in f:
@@ -110,16 +111,19 @@ def conv_summary(d):
                     "docstring); WRITE_SIZE as reported"}
 
 
+RND = os.environ.get("PMC_ROUND", "r04")
+
+
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "profiles", "hbm_traffic.json")
     j = json.load(open(path))
     if len(sys.argv) > 2 and os.path.isdir(sys.argv[1]):
-        j["r03_decode"] = decode_summary(sys.argv[1], int(sys.argv[2]))
-        print(json.dumps({k: (v if not isinstance(v, dict) else {"ratio": v.get("ratio_to_algorithmic")}) for k, v in j["r03_decode"].items()}, indent=0))
+        j[RND + "_decode"] = decode_summary(sys.argv[1], int(sys.argv[2]))
+        print(json.dumps({k: (v if not isinstance(v, dict) else {"ratio": v.get("ratio_to_algorithmic")}) for k, v in j[RND + "_decode"].items()}, indent=0))
     if len(sys.argv) > 3 and os.path.isdir(sys.argv[3]):
-        j["r03_conv"] = conv_summary(sys.argv[3])
-        print(json.dumps({k: v for k, v in j["r03_conv"].items() if k != "note"}, indent=0))
+        j[RND + "_conv"] = conv_summary(sys.argv[3])
+        print(json.dumps({k: v for k, v in j[RND + "_conv"].items() if k != "note"}, indent=0))
     json.dump(j, open(path, "w"), indent=1)
 
 
