@@ -222,7 +222,7 @@ public:
         xt_f16_ = cfg_.vocoder_fp16 != 0;   // fp16 storage of the ResBlock intermediates and residual stream (see ConvArgs)
         if (const char* e = getenv("AUR_XT_F16")) xt_f16_ = xt_f16_ && atoi(e) != 0;
         if (const char* e = getenv("AUR_CONV_DMA")) conv_dma_ = atoi(e) != 0;   // 0: register-staged ResBlock convs (A/B only)
-        if (const char* e = getenv("AUR_GEMM_BDMA")) gemm_bdma_ = atoi(e) != 0; // 0: prompt-row GEMMs split their weights per tile (A/B only)
+        if (const char* e = getenv("AUR_GEMM_PRESPLIT")) gemm_presplit_ = atoi(e) != 0; // 0: prompt-row GEMMs split their weights per tile instead of reading the planes packed at load time (A/B only)
         if (const char* e = getenv("AUR_DECODE_PIPELINE")) pipeline_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_SAMPLER_FULL_SORT")) sampler_full_sort_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_TEST_FAIL_STEP")) fail_at_step_ = atoi(e);
@@ -823,7 +823,7 @@ public:
         HIP_CHECK(hipMemcpy(dx.p, X, (size_t)M * K * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(dw.p, Wm, (size_t)K * N * 4, hipMemcpyHostToDevice));
         DevBuf ds;   // the pre-split weight operand, as ensure_gpt() prepares it for the prompt-row GEMMs
-        if (gemm_prec_ == 1 && gemm_bdma_ && N % 128 == 0) {
+        if (gemm_prec_ == 1 && gemm_presplit_ && N % 128 == 0) {
             ds.ensure((size_t)3 * K * N * 2);
             launch_pack_wsplit(dw.as<float>(), N, ds.p, K, N, st_);
         }
@@ -1049,7 +1049,7 @@ private:
     };
     struct LayerW {
         const float *ln1w, *ln1b, *wqkv, *bqkv, *wproj, *bproj, *ln2w, *ln2b, *wfc, *bfc, *wproj2, *bproj2;
-        const void *sqkv, *sproj, *sfc, *sproj2;    // launch_pack_wsplit copies for the prefill-regime GEMM (three bf16 planes, DMA-staged)
+        const void *sqkv, *sproj, *sfc, *sproj2;    // launch_pack_wsplit copies for the prefill-regime GEMM (the three bf16 planes of the split)
         const float *tqkv, *tproj, *tfc, *tproj2;   // pack_wt16 copies for the decode-regime GEMM (gemm_rows_kernel); tqkv / tfc
                                                     // have LayerNorm folded in (launch_fold_ln)
         const float *qkv_c1, *qkv_c2, *fc_c1, *fc_c2;   // ... with these epilogue vectors
@@ -1064,7 +1064,7 @@ private:
     }
     // pre-split copy of one [K][N] matrix for the prompt-row GEMM (only the split arithmetic uses it)
     const void* split_copy(const float* Wm, int K, int N) {
-        if (gemm_prec_ != 1 || !gemm_bdma_) return nullptr;
+        if (gemm_prec_ != 1 || !gemm_presplit_) return nullptr;
         packed_.emplace_back(new DevBuf());
         DevBuf& b = *packed_.back();
         b.ensure((size_t)3 * K * N * 2);
@@ -2067,7 +2067,7 @@ private:
     int profile_every_ = kProfileEvery;
     DevBuf prof_q_, prof_h_, prof_stats_, prof_act_, prof_kv_;   // output scratch of profile_replay
     DevBuf ksp_buf_, ksp_cnt_;   // GemmRowsArgs::ksp_buf / ksp_cnt
-    bool gemm_bdma_ = true;      // prompt-row GEMMs: weights pre-split at load time and staged by LDS-DMA
+    bool gemm_presplit_ = true;  // prompt-row GEMMs read their weights as the three bf16 planes packed at load time (launch_pack_wsplit)
     double step_kv_tokens_ = 0.0;       // sum of context lengths of the step being launched (profile accounting)
     long decode_step_count_ = 0;
     float event_overhead_ms_ = -1.f;

@@ -111,7 +111,7 @@ void launch_final_rows(const float* h, int mtt, const int* sample_slot, const fl
 // slabs > 1: split-K, slab s = K / slabs consecutive k, written to P + s * M * N (the consumer sums the slabs in a fixed order,
 // rows_ln / qkv_epilogue's S); the slab count is a property of the call site, never of M, so results stay batch-invariant.
 // wsplit (prec = 1, N % 128 == 0): W pre-split into its three bf16 planes by launch_pack_wsplit (3 * K * N * 2 bytes); the kernel
-// then stages the weight tiles by LDS-DMA instead of splitting them again per row tile.  Bitwise the same result.
+// then reads 16-byte pieces of the planes instead of splitting the fp32 weights again per row tile.  Bitwise the same result.
 void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, int N, int K, hipStream_t st,
                       const GemmGelu* gelu = nullptr, int prec = 0, int slabs = 1, const void* wsplit = nullptr);
 void launch_pack_wsplit(const float* W, int ldw, void* out, int K, int N, hipStream_t st);

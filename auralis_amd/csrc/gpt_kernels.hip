@@ -170,17 +170,14 @@ __device__ __forceinline__ void split3_bf16x4(const f32x4& x, bf16x4& h, bf16x4&
 }
 
 // BD: the weight operand comes PRE-SPLIT (launch_pack_wsplit: the three bf16 planes of W, per 128-column tile and k step one
-// contiguous 12 KB block [plane][128 n][16 k]) and is staged by LDS-DMA (global_load_lds_dwordx4, three 1-KiB copies per wave and k
-// step for a 128-wide tile) straight into the buffer the NEXT step reads: no staging registers, no split arithmetic (weights
-// are static: half of the kernel's VALU work and of its LDS writes was splitting the same weights again for every row tile of
-// every prefill), no ds_write.  A DMA lands lane-linear, so the B rows are unpadded 32-byte rows whose two 16-byte halves are
-// swapped when bit 3 of the row index is set -- on the source address of the copy and on the fragment read (conflict-free b128
-// reads, as in the vocoder's conv1d_dma_f16_kernel).  Same split, same MFMA order: bitwise the register-staged result.
-__device__ __forceinline__ void glds16_g(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;   // M0 carries the LDS destination; hipcc owns M0, so save / restore it inside the statement
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
+// contiguous 12 KB block [plane][128 n][16 k]).  Weights are static, and half of this kernel's VALU work and LDS-write
+// instructions was splitting the same weights again for every row tile of every prefill: with BD a thread fetches three 16-byte
+// pieces (8 consecutive k of one column, one per plane; consecutive threads, consecutive addresses) and writes them to LDS as
+// they are -- 3 x global_load_dwordx4 + 3 x ds_write_b128 instead of 8 x global_load_dword + the split + 6 x ds_write_b64; the
+// two-steps-ahead register pipeline, the padded rows and the fragment reads are unchanged.  Same split, same MFMA order: bitwise the
+// result of splitting on the fly.  (Staging the planes by LDS-DMA instead measured SLOWER than no pre-split at all: 30.8 ms per
+// prefill with one k step of lead, 34.0 with two and three buffers, against 29.4 -- three 1-KiB copies per wave and step cost
+// more issue time inside the MFMA stream than they save)
 template <int BM, int BN, bool GELU, bool BD = false>
 __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W,
                                                                  float* __restrict__ P, int M, int N, int K, GemmGelu ep,
@@ -190,9 +187,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
     constexpr int MI = BM / 64, NI = BN / 64;    // 32 x 32 MFMA tiles per wave (waves form a 2 x 2 grid over the tile)
     constexpr int LA = BM / 64;                  // float4 loads (4 k of one row) per thread and K step
     constexpr int LB = BN / 64;                  // k-quads of one column per thread and K step (4 dword loads each)
-    constexpr int RB = BD ? 16 : RS;             // B rows: unpadded (DMA) or padded (register-staged)
     __shared__ __attribute__((aligned(16))) __bf16 As[2][3][BM * RS];
-    __shared__ __attribute__((aligned(1024))) __bf16 Bs[2][3][BN * RB];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][3][BN * RS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5, wm = wv >> 1, wn = wv & 1;
     const int n_nt = N / BN, n_mt = (M + BM - 1) / BM;
@@ -216,20 +212,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
     // pre-split weights: block (128-column tile t, k step s) of 3 x 128 x 16 bf16 at ((t * ksteps_total) + s) * 6144 elements
     const int ks_total = (int)gridDim.y * (K / BK), ks0 = (int)blockIdx.y * (K / BK);
     const __bf16* wsp_tile = BD ? Wsp + ((long)(n0 / 128) * ks_total + ks0) * (3 * 128 * 16) + (n0 % 128) * 16 : nullptr;
-    const unsigned bs_l = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)&Bs[0][0][0];
-    auto b_dma = [&](int st, int buf) {   // the B tile of k step st into Bs[buf]: 3 * BN / 32 copies of 1 KiB, wave w takes w, w + 4, ..
-        constexpr int NC = 3 * BN / 32;
-#pragma unroll
-        for (int k = 0; k < (NC + 3) / 4; ++k) {
-            const int ii = __builtin_amdgcn_readfirstlane(wv) + 4 * k;
-            if (ii < NC) {
-                const int p = ii / (BN / 32), r = ii - p * (BN / 32);
-                const int row = 32 * r + (lane >> 1), h = (lane & 1) ^ ((row >> 3) & 1);
-                const char* src = reinterpret_cast<const char*>(wsp_tile + (long)st * (3 * 128 * 16) + p * (128 * 16)) + row * 32 + h * 16;
-                glds16_g(src, __builtin_amdgcn_readfirstlane(bs_l + (unsigned)((buf * 3 + p) * BN * 32 + r * 1024)));
-            }
-        }
-    };
+    // pre-split B: piece j of this thread = plane (tid + 256 j) / (2 BN), column ((tid + 256 j) / 2) % BN, k half (tid & 1)
+    constexpr int LBD = 3 * BN * 2 / 256;        // 16-byte pieces per thread and k step (3 at BN = 128; 1.5 -> 2 with a guard at BN = 64)
+    constexpr int LBDc = (3 * BN * 2 + 255) / 256;
     const int a_row = tid >> 2, a_kq = tid & 3;          // A: rows a_row (+64), k-quad a_kq
     const int b_n = tid % BN, b_kq = tid / BN;           // B: column b_n, k-quads b_kq (+ 256 / BN)
     const float* ap[LA];
@@ -242,18 +227,30 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
     // Two register sets: the global loads of step s + 2 are issued before the MFMAs of step s and parked until step s + 1 has
     // been computed -- two steps of cover for the operand latency (the activation panel streams from HBM / Infinity Cache and a
     // step's 24 MFMAs last only ~0.3 us; with one step of cover the kernel ran at a quarter of the matrix pipe).
-    f32x4 ga[2][LA], gb[2][LB];
-    auto g_load = [&](f32x4 (&a4)[LA], f32x4 (&b4)[LB], int k0) {
+    // (with BD the register set of B holds the 16-byte pieces of the planes, bit-cast into the same f32x4 slots)
+    constexpr int LBR = BD ? LBDc : LB;
+    f32x4 ga[2][LA], gb[2][LBR];
+    auto g_load = [&](f32x4 (&a4)[LA], f32x4 (&b4)[LBR], int k0) {
 #pragma unroll
         for (int i = 0; i < LA; ++i) a4[i] = *reinterpret_cast<const f32x4*>(ap[i] + k0);
-        if constexpr (!BD) {
+        if constexpr (BD) {
+            const __bf16* blk = wsp_tile + (long)(k0 / BK) * (3 * 128 * 16);
+#pragma unroll
+            for (int j = 0; j < LBDc; ++j) {
+                const int u = tid + 256 * j;   // piece index in [0, 3 * BN * 2)
+                if (LBD * 256 == 3 * BN * 2 || u < 3 * BN * 2) {
+                    const int p = u / (2 * BN), r = u - p * (2 * BN);
+                    b4[j] = *reinterpret_cast<const f32x4*>(blk + p * (128 * 16) + (r >> 1) * 16 + (r & 1) * 8);
+                }
+            }
+        } else {
 #pragma unroll
             for (int i = 0; i < LB; ++i)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) b4[i][c] = bp[(long)(k0 + 4 * (b_kq + (256 / BN) * i) + c) * N];
         }
     };
-    auto s_store = [&](const f32x4 (&a4)[LA], const f32x4 (&b4)[LB], int buf) {
+    auto s_store = [&](const f32x4 (&a4)[LA], const f32x4 (&b4)[LBR], int buf) {
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             bf16x4 h, m, l;
@@ -263,7 +260,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
             *reinterpret_cast<bf16x4*>(&As[buf][1][o]) = m;
             *reinterpret_cast<bf16x4*>(&As[buf][2][o]) = l;
         }
-        if constexpr (!BD) {
+        if constexpr (BD) {
+#pragma unroll
+            for (int j = 0; j < LBDc; ++j) {
+                const int u = tid + 256 * j;
+                if (LBD * 256 == 3 * BN * 2 || u < 3 * BN * 2) {
+                    const int p = u / (2 * BN), r = u - p * (2 * BN);
+                    *reinterpret_cast<f32x4*>(&Bs[buf][p][(r >> 1) * RS + (r & 1) * 8]) = b4[j];
+                }
+            }
+        } else {
 #pragma unroll
             for (int i = 0; i < LB; ++i) {
                 bf16x4 h, m, l;
@@ -283,25 +289,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = lo[mi][ni][r] = 0.f;
     const int n_steps = K / BK;
-    if constexpr (BD) b_dma(0, 0);
     g_load(ga[0], gb[0], 0);
     if (n_steps > 1) g_load(ga[1], gb[1], BK);
     s_store(ga[0], gb[0], 0);
-    if constexpr (BD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int ao = (wm * (BM / 2) + l31) * RS + 8 * hi;
-    // B fragment of column tile ni: row wn * BN/2 + 32 ni + l31 (k-half hi); unpadded rows carry the half swap of the DMA
-    const int brow = wn * (BN / 2) + l31;
-    const int bo = BD ? brow * 16 + 8 * (hi ^ ((brow >> 3) & 1)) : brow * RS + 8 * hi;
+    const int ao = (wm * (BM / 2) + l31) * RS + 8 * hi, bo = (wn * (BN / 2) + l31) * RS + 8 * hi;
     // step st: LDS buffer st & 1 holds it, register set (st + 1) & 1 holds step st + 1, set st & 1 is free for step st + 2
     auto step = [&](auto PAR, int st) {
         constexpr int par = decltype(PAR)::value;
-        // the weights of step st + 1 go straight into the buffer step st - 1 has just been read from (everybody is past that step's
-        // barrier); issued BEFORE the activation loads of step st + 2, so that "all but the newest LA loads have returned" at the
-        // end of this step covers them
-        if constexpr (BD) {
-            if (st + 1 < n_steps) b_dma(st + 1, par ^ 1);
-        }
         if (st + 2 < n_steps) g_load(ga[par], gb[par], (st + 2) * BK);
         __builtin_amdgcn_sched_barrier(0);   // those loads are in flight before this step's MFMAs
         bf16x8 a[3][MI], b[3][NI];
@@ -310,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) a[p][mi] = *reinterpret_cast<const bf16x8*>(&As[par][p][ao + 32 * mi * RS]);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[p][ni] = *reinterpret_cast<const bf16x8*>(&Bs[par][p][bo + 32 * ni * RB]);
+            for (int ni = 0; ni < NI; ++ni) b[p][ni] = *reinterpret_cast<const bf16x8*>(&Bs[par][p][bo + 32 * ni * RS]);
         }
         // term order per accumulator as in gemm_rows_kernel (l*h.. first, h*h into its own accumulator); the tiles are the
         // inner loop so that back-to-back MFMAs never share an accumulator
@@ -320,10 +315,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
         AUR_TERM(lo, 0, 2) AUR_TERM(lo, 2, 0) AUR_TERM(lo, 1, 1) AUR_TERM(lo, 0, 1) AUR_TERM(lo, 1, 0) AUR_TERM(acc, 0, 0)
 #undef AUR_TERM
         if (st + 1 < n_steps) s_store(ga[par ^ 1], gb[par ^ 1], par ^ 1);
-        if constexpr (BD) {   // this wave's copies of step st + 1 have landed (only the LA activation loads of step st + 2 may be outstanding)
-            if (st + 2 < n_steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LA) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
         __syncthreads();
     };
     for (int st = 0; st < n_steps; st += 2) {

@@ -64,11 +64,11 @@ def test_gemm_tile_is_batch_invariant_bitwise(eng):
         assert np.array_equal(big2[:m], eng.dbg_gemm(X2[:m].numpy(), W2.numpy())), m
 
 
-def test_gemm_tile_dma_staged_weights_equal_register_staged(eng, monkeypatch):
-    """Prompt-row GEMMs take their weights pre-split (three bf16 planes, packed at load time) and stage them by LDS-DMA;
-    AUR_GEMM_BDMA=0 selects the kernel that splits them again per tile.  Same split, same MFMA order: equal bit for bit, on
-    every tile shape (128 x 128, 128 x 64, 64 x 64) and with K slabs of different depth."""
-    monkeypatch.setenv("AUR_GEMM_BDMA", "0")
+def test_gemm_tile_presplit_weights_equal_split_on_the_fly(eng, monkeypatch):
+    """Prompt-row GEMMs read their weights as the three bf16 planes of the exact split, packed at load time (launch_pack_wsplit);
+    AUR_GEMM_PRESPLIT=0 selects the kernel that splits the fp32 weights again per tile.  Same split, same MFMA order: equal bit for
+    bit, on every tile shape (128 x 128, 128 x 64, 64 x 64) and for every K."""
+    monkeypatch.setenv("AUR_GEMM_PRESPLIT", "0")
     e_reg, *_ = make_engine(1, max_seqs=8)
     try:
         g = torch.Generator().manual_seed(21)
