@@ -1,10 +1,6 @@
 #!/bin/bash
+# round-4 evidence run: driver sequence (tests, smoke, bench, torchrun bench, rocprofv3 stats) + PMC fetch / write passes of the decode kernels
 exec < /dev/null
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_gpt.py -m gpu -x -q -p no:cacheprovider > gpurun_out/r04j_tests.log 2>&1; echo "tests rc=$?"; grep -v "^Extension modules" gpurun_out/r04j_tests.log | tail -4
-for i in 1 2; do
-timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-side --no-profile-pass --out gpurun_out/r04j_dma.json 2>/dev/null | cut -c1-120; python -c "
-import json; d=json.load(open('gpurun_out/r04j_dma.json')); print('pre-split planes:', d['breakdown_ms_per_step'])"
-AUR_GEMM_PRESPLIT=0 timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-side --no-profile-pass --out gpurun_out/r04j_reg.json 2>/dev/null | cut -c1-120; python -c "
-import json; d=json.load(open('gpurun_out/r04j_reg.json')); print('split on the fly:', d['breakdown_ms_per_step'])"
-done
+bash tools/gpu_round_check.sh r04final
+PMC_TIMEOUT=200 PMC_PASSES='fetch write' PMC_KERNELS='paged_attention_kernel|gemm_rows_kernel' PMC_BENCH_ARGS='--tokens 40' bash tools/pmc.sh r04dec
+ls gpurun_out/pmc_r04dec/*/ | head; find gpurun_out/pmc_r04dec -name "*.csv" -size +30M -delete
