@@ -224,7 +224,6 @@ public:
         if (const char* e = getenv("AUR_CONV_DMA")) conv_dma_ = atoi(e) != 0;   // 0: register-staged ResBlock convs (A/B only)
         if (const char* e = getenv("AUR_GEMM_PRESPLIT")) gemm_presplit_ = atoi(e) != 0; // 0: prompt-row GEMMs split their weights per tile instead of reading the planes packed at load time (A/B only)
         if (const char* e = getenv("AUR_DECODE_PIPELINE")) pipeline_ = atoi(e) != 0;
-        if (const char* e = getenv("AUR_ZERO_COPY_TOKENS")) zero_copy_tokens_ = atoi(e) != 0;   // 0: D2H copy of the tokens per step (A/B)
         if (const char* e = getenv("AUR_SAMPLER_FULL_SORT")) sampler_full_sort_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_TEST_FAIL_STEP")) fail_at_step_ = atoi(e);
         if (const char* e = getenv("AUR_TEST_FAIL_VOC")) fail_at_voc_ = atoi(e);
@@ -1401,15 +1400,12 @@ private:
     }
     // decode tail of the gemm_rows chain: rows are the live sequences in order (sample_row = identity), w.h holds the
     // residual stream: ln_f + final_norm (+ second final_norm into the latent stash) -> mel_head GEMM (+ bias) -> sampler
-    // out_tok: where the sampler writes (token | finished bit) per row -- in the decode loop the pinned host block itself (a
-    // 256-byte zero-copy write at the end of the sampler instead of a copy kernel + two boundaries on the stream between steps)
-    void sample_kernels_decode(RowWs& w, int Ms, int* out_tok = nullptr) {
+    void sample_kernels_decode(RowWs& w, int Ms) {
         const int mtt = w.rows_cap / 16;
         launch_final_rows(w.h.as<float>(), mtt, w.i_sample_slot.as<int>(), lnfw_, lnfb_, fnw_, fnb_, w.ybuf.as<float>(),
                           latents_.as<float>(), (long)kMaxLatRows * kHidden, slot_ngen_.as<int>(), kMaxLatRows, Ms, 1e-5f, w.st);
         launch_gemm_rows(head_gemm_args(w, Ms, false), false, kEpiBias, w.st);
         SamplerArgs sa = sampler_args(w, w.P2.as<float>(), 1, Ms, kHeadPad, zero_bias_.as<float>(), nullptr);
-        if (out_tok) sa.out_tok = out_tok;
         launch_sampler(sa, w.st);
     }
     void sample_readback(RowWs& w, int Ms, hipStream_t st, int* pin = nullptr) {
@@ -1567,12 +1563,12 @@ private:
     // One decode step: embed -> 30 x (QKV GEMM, attention, proj, FC, proj2) -> final norms -> head GEMM -> sampler, 154
     // launches that depend only on device-resident state (hipGraph replay of the chain was measured within noise in round 2:
     // the launches are already back to back).
-    void decode_kernels(RowWs& w, int Mk, int* out_tok = nullptr) {
+    void decode_kernels(RowWs& w, int Mk) {
         launch_embed_decode(w.i_row_slot.as<int>(), slot_tok_.as<int>(), slot_pos_.as<int>(), wte_, wpe_, w.h.as<float>(), Mk, w.st,
                             w.rows_cap / 16, w.stats.as<float2>(), w.row_meta.as<int>(), slot_kvpos_.as<int>(),
                             block_tables_.as<int>(), kMaxBlocks);
         forward_decode(w, Mk, w.i_row_slot.as<int>());
-        sample_kernels_decode(w, Mk, out_tok);
+        sample_kernels_decode(w, Mk);
     }
     // ---- pipelined decode (default): the step's kernel chain depends only on device-resident state, so step s+1 is
     // enqueued BEFORE the host waits for the token / finished-flag read-back of step s (otherwise the GPU idles for the
@@ -1614,9 +1610,11 @@ private:
         stats_.decode_kv_bytes += (kv_half_ ? 4.0 : 8.0) * kHidden * step_kv_tokens_ * cfg_.n_layer;
         stats_.decode_weight_bytes += 4.0 * ((double)cfg_.n_layer * 12.0 * kHidden * kHidden + (double)kHidden * kMelVocab);
         HIP_CHECK(hipEventRecord(ev_ds_[f.buf], st_));
-        decode_kernels(w, M, zero_copy_tokens_ ? pin_rb_[f.buf].as<int>() : nullptr);
+        decode_kernels(w, M);
         HIP_CHECK(hipEventRecord(ev_de_[f.buf], st_));
-        if (!zero_copy_tokens_) sample_readback(w, M, st_, pin_rb_[f.buf].as<int>());
+        // (the sampler writing the tokens straight into the pinned block instead of this 256-byte copy: 621.3 vs 621.8 ms per bench
+        // step, 1.193 vs 1.194 ms per single-utterance decode step -- the copy is not on the critical path of the pipelined loop)
+        sample_readback(w, M, st_, pin_rb_[f.buf].as<int>());
         HIP_CHECK(hipEventRecord(ev_rb_[f.buf], st_));
         if (f.profiled) profile_replay(w, M, w.i_row_slot.as<int>());   // behind the read-back: the step's tokens do not wait for it
         last_active_ = active;
@@ -2071,7 +2069,6 @@ private:
     int profile_every_ = kProfileEvery;
     DevBuf prof_q_, prof_h_, prof_stats_, prof_act_, prof_kv_;   // output scratch of profile_replay
     DevBuf ksp_buf_, ksp_cnt_;   // GemmRowsArgs::ksp_buf / ksp_cnt
-    bool zero_copy_tokens_ = true;   // decode: the sampler writes the step's tokens into the pinned read-back block itself
     bool gemm_presplit_ = true;  // prompt-row GEMMs read their weights as the three bf16 planes packed at load time (launch_pack_wsplit)
     double step_kv_tokens_ = 0.0;       // sum of context lengths of the step being launched (profile accounting)
     long decode_step_count_ = 0;
