@@ -1029,6 +1029,8 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
     auto load_kv = [&](int t0) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
+            // (clamped to the context, not to the table: making the address independent of the row's position -- one dependent load
+            // less in front of the first K/V loads -- made the masked lanes fetch real, distinct rows: 24.2 vs 22.6 us per launch)
             const int t = min(t0 + 4 * TPW * u + wv * TPW + g, n_keys - 1);
             const int blk = bt[t / kKvBlockTokens];
             const long off = kv_offset(blk, 0, head, t % kKvBlockTokens) + dl * EPL;
