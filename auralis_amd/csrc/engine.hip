@@ -1341,8 +1341,15 @@ private:
         for (int l = 0; l < cfg_.n_layer; ++l) {
             const LayerW& L = layers_[l];
             void* kvl = kv_layer(l);
-            launch_gemm_tile(xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, w.st, nullptr, gemm_prec_, 1, L.sqkv);
-            launch_qkv_epilogue(P, 1, L.bqkv, w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, w.st, kv_half_);
+            if (gemm_prec_ == 1) {   // bias, q rows and the K / V page writes in the GEMM's epilogue (27.50 vs 27.62 ms per prefill)
+                GemmGelu qe{L.bqkv, nullptr, 0};
+                qe.qbuf = w.qbuf.as<float>(); qe.kv_layer = kvl; qe.row_slot = d_row_slot; qe.row_pos = d_row_pos; qe.block_tables = bt;
+                qe.max_blocks = kMaxBlocks; qe.kv_half = kv_half_ ? 1 : 0;
+                launch_gemm_tile(xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, w.st, &qe, gemm_prec_, 1, L.sqkv);
+            } else {
+                launch_gemm_tile(xn, kHidden, L.wqkv, P, M, 3 * kHidden, kHidden, w.st, nullptr, gemm_prec_, 1, L.sqkv);
+                launch_qkv_epilogue(P, 1, L.bqkv, w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, w.st, kv_half_);
+            }
             launch_prompt_attention(w.qbuf.as<float>(), kvl, w.i_qblk.as<int2>(), n_qblk, d_row_slot, d_row_pos, bt, kMaxBlocks, w.att.as<float>(), w.st, kv_half_);
             launch_gemm_tile(w.att.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, w.st, nullptr, gemm_prec_, 1, L.sproj);
             launch_rows_ln(P, 1, L.bproj, h, L.ln2w, L.ln2b, xn, M, 1e-5f, w.st);

@@ -12,10 +12,20 @@ constexpr long kKvBlockElems = 2L * kHeads * kKvBlockTokens * kHeadDim;  // one 
 
 // Optional bias + GELU epilogue of the prefill FC GEMM: act[m][n] = gelu(total + bias[n]) is written instead of the slab.
 // erf: 1 = erf form (config.json "activation_function": "gelu"), 0 = tanh form ("gelu_new").
+// QKV mode (qbuf != nullptr, no gelu; split-arithmetic kernel only): the slab is not written either -- column n of row m plus
+// bias[n] goes to qbuf[m][n] (n < 1024) or into the K / V page of (row_slot[m], row_pos[m]) (the work of qkv_epilogue_kernel, which
+// then is not launched: one launch and one 56 MB write + read per layer less at 4 544 prompt rows).
 struct GemmGelu {
     const float* bias;
     float* act;
     int erf;
+    float* qbuf = nullptr;
+    void* kv_layer = nullptr;
+    const int* row_slot = nullptr;
+    const int* row_pos = nullptr;
+    const int* block_tables = nullptr;
+    int max_blocks = 0;
+    int kv_half = 0;
 };
 
 // ---- decode-regime GEMM (M = live sequences; every weight leaves HBM once per step) ---------------------------------

@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
     constexpr int LB = BN / 64;                  // k-quads of one column per thread and K step (4 dword loads each)
     __shared__ __attribute__((aligned(16))) __bf16 As[2][3][BM * RS];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][3][BN * RS];
+    __shared__ int2 rowkv[BM];   // QKV mode: (K/V block, token in block) of the tile's rows
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5, wm = wv >> 1, wn = wv & 1;
     const int n_nt = N / BN, n_mt = (M + BM - 1) / BM;
@@ -205,6 +206,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
         }
     }
     const int m0 = mtile * BM, n0 = ntile * BN;
+    if (!GELU && ep.qbuf && tid < BM) {   // (read in the epilogue, behind the K loop's barriers)
+        const int r = min(m0 + tid, M - 1), slot = ep.row_slot[r], pos = ep.row_pos[r];
+        rowkv[tid] = make_int2(ep.block_tables[(long)slot * ep.max_blocks + pos / kKvBlockTokens], pos % kKvBlockTokens);
+    }
     // split-K slabs (grid.y): slab s multiplies columns [s*K, (s+1)*K) of X with the matching rows of W into P[s] (K = slab depth)
     X += (long)blockIdx.y * K;
     if constexpr (!BD) W += (long)blockIdx.y * K * N;
@@ -326,15 +331,30 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int col = n0 + wn * (BN / 2) + ni * 32 + l31;
+            const bool qkv = !GELU && ep.qbuf != nullptr;
             float bv = 0.f;
-            if (GELU) bv = ep.bias[col];
+            if (GELU || qkv) bv = ep.bias[col];
+            const int qu = col / kHidden, qd = col - qu * kHidden;   // QKV mode: q / k / v and the column inside it
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int rl = wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, row = m0 + rl;
                 const float v = acc[mi][ni][r] + lo[mi][ni][r];
                 if (row < M) {
-                    if (GELU) ep.act[(long)row * N + col] = ep.erf ? gelu_erf(v + bv) : gelu_new(v + bv);
-                    else P[(long)row * N + col] = v;
+                    if (GELU) {
+                        ep.act[(long)row * N + col] = ep.erf ? gelu_erf(v + bv) : gelu_new(v + bv);
+                    } else if (qkv) {
+                        const float t = v + bv;
+                        if (qu == 0) {
+                            ep.qbuf[(long)row * kHidden + qd] = t;
+                        } else {
+                            const int2 kb = rowkv[rl];
+                            const long off = kv_offset(kb.x, qu - 1, qd / kHeadDim, kb.y) + qd % kHeadDim;
+                            if (ep.kv_half) reinterpret_cast<_Float16*>(ep.kv_layer)[off] = (_Float16)t;
+                            else reinterpret_cast<float*>(ep.kv_layer)[off] = t;
+                        }
+                    } else {
+                        P[(long)row * N + col] = v;
+                    }
                 }
             }
         }
@@ -367,11 +387,14 @@ void launch_pack_wsplit(const float* W, int ldw, void* out, int K, int N, hipStr
 void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, int N, int Kfull, hipStream_t st,
                       const GemmGelu* gelu, int prec, int slabs, const void* wsplit) {
     AUR_REQUIRE(slabs >= 1 && Kfull % slabs == 0 && (slabs == 1 || !gelu), "gemm_tile: slabs");
+    AUR_REQUIRE(!gelu || !gelu->qbuf || (prec == 1 && !gelu->act && N == 3 * kHidden && gelu->bias && gelu->kv_layer && gelu->row_slot && gelu->row_pos && gelu->block_tables),
+                "gemm_tile: the QKV epilogue needs the split arithmetic, N = 3072, bias, K/V pool and row addressing");
     const int K = Kfull / slabs;
     AUR_REQUIRE(N % 64 == 0 && K % 16 == 0 && ldx % 4 == 0 && M >= 1, "gemm_tile: shape");
     trace_launch("gemm_tile_kernel");
     const GemmGelu none{nullptr, nullptr, 0};
     const GemmGelu& g = gelu ? *gelu : none;
+    const bool ge = gelu && gelu->act;   // (a descriptor without `act` is the QKV mode of the plain kernel)
     // N = 1024 GEMMs (attention and MLP projections): 128 x 128 tiles give 8 x ceil(M/128) workgroups — 288 for a 64-prompt
     // prefill, 1.1 per CU, half the chip idle in the second round — so they run on 64 x 64 tiles (1136 workgroups).  The k order
     // of every output element is the same for both shapes.
@@ -383,20 +406,20 @@ void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, 
                        reinterpret_cast<const __bf16*>(wsplit))
     if (prec && wsplit && N % 128 == 0) {   // pre-split weights staged by LDS-DMA (same tile policy as below)
         const long n128 = (long)slabs * (N / 128) * ((M + 127) / 128), n64 = (long)slabs * (N / 64) * ((M + 127) / 128);
-        if (!small || n128 >= 200) { if (gelu) AUR_GTD(128, 128, true); else AUR_GTD(128, 128, false); }
-        else if (n64 >= 200) { if (gelu) AUR_GTD(128, 64, true); else AUR_GTD(128, 64, false); }
-        else { if (gelu) AUR_GTD(64, 64, true); else AUR_GTD(64, 64, false); }
+        if (!small || n128 >= 200) { if (ge) AUR_GTD(128, 128, true); else AUR_GTD(128, 128, false); }
+        else if (n64 >= 200) { if (ge) AUR_GTD(128, 64, true); else AUR_GTD(128, 64, false); }
+        else { if (ge) AUR_GTD(64, 64, true); else AUR_GTD(64, 64, false); }
     } else if (prec) {
         // split arithmetic, narrow GEMMs (N <= 1024): the largest tile that still gives every CU a workgroup -- 128 x 128 for a
         // 64-prompt prefill (288 workgroups, one round: 34.8 ms per prefill against 36.4 on 128 x 64 = 576 workgroups on 512
         // slots), 128 x 64 and 64 x 64 for smaller batches.  The k order of an output element is the same for every shape.
         const long n128 = (long)slabs * (N / 128) * ((M + 127) / 128), n64 = (long)slabs * (N / 64) * ((M + 127) / 128);
-        if (!small || (N % 128 == 0 && n128 >= 200)) { if (gelu) AUR_GT(gemm_tile_split_kernel, 128, 128, true); else AUR_GT(gemm_tile_split_kernel, 128, 128, false); }
-        else if (n64 >= 200) { if (gelu) AUR_GT(gemm_tile_split_kernel, 128, 64, true); else AUR_GT(gemm_tile_split_kernel, 128, 64, false); }
-        else { if (gelu) AUR_GT(gemm_tile_split_kernel, 64, 64, true); else AUR_GT(gemm_tile_split_kernel, 64, 64, false); }
+        if (!small || (N % 128 == 0 && n128 >= 200)) { if (ge) AUR_GT(gemm_tile_split_kernel, 128, 128, true); else AUR_GT(gemm_tile_split_kernel, 128, 128, false); }
+        else if (n64 >= 200) { if (ge) AUR_GT(gemm_tile_split_kernel, 128, 64, true); else AUR_GT(gemm_tile_split_kernel, 128, 64, false); }
+        else { if (ge) AUR_GT(gemm_tile_split_kernel, 64, 64, true); else AUR_GT(gemm_tile_split_kernel, 64, 64, false); }
     } else {
-        if (small) { if (gelu) AUR_GT(gemm_tile_kernel, 64, 64, true); else AUR_GT(gemm_tile_kernel, 64, 64, false); }
-        else { if (gelu) AUR_GT(gemm_tile_kernel, 128, 128, true); else AUR_GT(gemm_tile_kernel, 128, 128, false); }
+        if (small) { if (ge) AUR_GT(gemm_tile_kernel, 64, 64, true); else AUR_GT(gemm_tile_kernel, 64, 64, false); }
+        else { if (ge) AUR_GT(gemm_tile_kernel, 128, 128, true); else AUR_GT(gemm_tile_kernel, 128, 128, false); }
     }
 #undef AUR_GT
 #undef AUR_GTD
