@@ -1351,6 +1351,8 @@ private:
                 launch_qkv_epilogue(P, 1, L.bqkv, w.qbuf.as<float>(), kvl, d_row_slot, d_row_pos, kvpos, bt, kMaxBlocks, M, w.st, kv_half_);
             }
             launch_prompt_attention(w.qbuf.as<float>(), kvl, w.i_qblk.as<int2>(), n_qblk, d_row_slot, d_row_pos, bt, kMaxBlocks, w.att.as<float>(), w.st, kv_half_);
+            // (two K-slabs for this GEMM -- 576 workgroups instead of 288 on 256 CUs: 27.55-27.68 vs 27.82 ms per prefill, four slabs
+            // 27.83-27.93: not worth another slab sum)
             launch_gemm_tile(w.att.as<float>(), kHidden, L.wproj, P, M, kHidden, kHidden, w.st, nullptr, gemm_prec_, 1, L.sproj);
             launch_rows_ln(P, 1, L.bproj, h, L.ln2w, L.ln2b, xn, M, 1e-5f, w.st);
             const GemmGelu ge{L.bfc, w.act.as<float>(), cfg_.gelu_erf ? 1 : 0};
