@@ -30,6 +30,30 @@ def test_prefill_hidden_and_logits(small, dims):
     assert np.abs(logits - z).max() < 2e-4
 
 
+def test_prefill_presplit_operands_equal_split_on_the_fly(small, dims, monkeypatch):
+    """Prompt rows: the GEMMs read their weights as the bf16 planes packed at load time; AUR_GEMM_PRESPLIT=0 splits the fp32 weights
+    inside the GEMM.  Hidden states of every prompt row, the logits, and what the decode steps then read from the K / V pages
+    (written by the QKV GEMM's epilogue) are equal bit for bit."""
+    from tests.gpu_util import make_engine
+    e, *_ = small
+    monkeypatch.setenv("AUR_GEMM_PRESPLIT", "0")
+    e2, *_ = make_engine(e.n_layer, max_seqs=4)
+    try:
+        for n_text in (20, 131):
+            ids = make_synthetic_text_ids(dims, n_text=n_text, seed=3 + n_text)
+            r1, l1 = e.dbg_prefill(ids, SPK_KEY, repetition_penalty=1.0)
+            r2, l2 = e2.dbg_prefill(ids, SPK_KEY, repetition_penalty=1.0)
+            assert np.array_equal(r1, r2) and np.array_equal(l1, l2), n_text
+        ids = make_synthetic_text_ids(dims, n_text=40, seed=8)
+        outs = []
+        for eng in (e, e2):
+            eng.submit(ids, SPK_KEY, temperature=0.8, top_p=0.9, top_k=40, repetition_penalty=5.0, max_tokens=24, seed=5, ignore_stop=True)
+            outs.append(eng.run_until_done()[0])
+        assert outs[0]["tokens"].tolist() == outs[1]["tokens"].tolist() and np.array_equal(outs[0]["latents"], outs[1]["latents"])
+    finally:
+        e2.close()
+
+
 def _greedy_case(e, gpt, cond, dims, n_text, max_tokens, ignore_stop=True):
     from oracle import xtts_oracle as O
     ids = make_synthetic_text_ids(dims, n_text=n_text)
