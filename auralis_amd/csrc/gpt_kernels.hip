@@ -242,11 +242,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
             const __bf16* blk = wsp_tile + (long)(k0 / BK) * (3 * 128 * 16);
 #pragma unroll
             for (int j = 0; j < LBDc; ++j) {
-                const int u = tid + 256 * j;   // piece index in [0, 3 * BN * 2)
-                if (LBD * 256 == 3 * BN * 2 || u < 3 * BN * 2) {
-                    const int p = u / (2 * BN), r = u - p * (2 * BN);
-                    b4[j] = *reinterpret_cast<const f32x4*>(blk + p * (128 * 16) + (r >> 1) * 16 + (r & 1) * 8);
-                }
+                // piece index in [0, 3 * BN * 2); at BN = 64 the upper half of the threads has no second piece and loads the first
+                // one again (not stored): no branch around a load, see the note on the step lambda
+                const int u = (LBD * 256 == 3 * BN * 2 || tid + 256 * j < 3 * BN * 2) ? tid + 256 * j : tid;
+                const int p = u / (2 * BN), r = u - p * (2 * BN);
+                b4[j] = *reinterpret_cast<const f32x4*>(blk + p * (128 * 16) + (r >> 1) * 16 + (r & 1) * 8);
             }
         } else {
 #pragma unroll
@@ -295,14 +295,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = lo[mi][ni][r] = 0.f;
     const int n_steps = K / BK;
     g_load(ga[0], gb[0], 0);
-    if (n_steps > 1) g_load(ga[1], gb[1], BK);
+    g_load(ga[1], gb[1], BK);
     s_store(ga[0], gb[0], 0);
     __syncthreads();
     const int ao = (wm * (BM / 2) + l31) * RS + 8 * hi, bo = (wn * (BN / 2) + l31) * RS + 8 * hi;
     // step st: LDS buffer st & 1 holds it, register set (st + 1) & 1 holds step st + 1, set st & 1 is free for step st + 2
     auto step = [&](auto PAR, int st) {
         constexpr int par = decltype(PAR)::value;
-        if (st + 2 < n_steps) g_load(ga[par], gb[par], (st + 2) * BK);
+        // No branch around the loads or the LDS stores (the last two steps load the last k block again and the last step stores
+        // it where nobody reads): hipcc's waitcnt insertion takes the stricter of the two paths at every join, and with
+        // `if (st + 2 < n_steps)` around g_load it drained vmcnt to 0 ahead of the LDS stores of EVERY step (r04 ISA:
+        // `s_waitcnt vmcnt(4..0)` before the ds_writes, `vmcnt(2..0)` before the next load group) -- the set loaded "two steps
+        // ahead" had one step of cover and each step stalled on its own loads.  Straight-line, the count is exact (vmcnt(LA+LB)).
+        g_load(ga[par], gb[par], min(st + 2, n_steps - 1) * BK);
         __builtin_amdgcn_sched_barrier(0);   // those loads are in flight before this step's MFMAs
         bf16x8 a[3][MI], b[3][NI];
 #pragma unroll
@@ -319,12 +324,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_split_kernel(const float* __
         DST[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][mi], b[PB][ni], DST[mi][ni], 0, 0, 0);
         AUR_TERM(lo, 0, 2) AUR_TERM(lo, 2, 0) AUR_TERM(lo, 1, 1) AUR_TERM(lo, 0, 1) AUR_TERM(lo, 1, 0) AUR_TERM(acc, 0, 0)
 #undef AUR_TERM
-        if (st + 1 < n_steps) s_store(ga[par ^ 1], gb[par ^ 1], par ^ 1);
+        s_store(ga[par ^ 1], gb[par ^ 1], par ^ 1);
         __syncthreads();
     };
-    for (int st = 0; st < n_steps; st += 2) {
+    for (int st = 0; st < n_steps; st += 2) {   // K % 32 == 0 (launcher)
         step(std::integral_constant<int, 0>{}, st);
-        if (st + 1 < n_steps) step(std::integral_constant<int, 1>{}, st + 1);
+        step(std::integral_constant<int, 1>{}, st + 1);
     }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -390,7 +395,7 @@ void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, 
     AUR_REQUIRE(!gelu || !gelu->qbuf || (prec == 1 && !gelu->act && N == 3 * kHidden && gelu->bias && gelu->kv_layer && gelu->row_slot && gelu->row_pos && gelu->block_tables),
                 "gemm_tile: the QKV epilogue needs the split arithmetic, N = 3072, bias, K/V pool and row addressing");
     const int K = Kfull / slabs;
-    AUR_REQUIRE(N % 64 == 0 && K % 16 == 0 && ldx % 4 == 0 && M >= 1, "gemm_tile: shape");
+    AUR_REQUIRE(N % 64 == 0 && K % 16 == 0 && (!prec || K % 32 == 0) && ldx % 4 == 0 && M >= 1, "gemm_tile: shape");
     trace_launch("gemm_tile_kernel");
     const GemmGelu none{nullptr, nullptr, 0};
     const GemmGelu& g = gelu ? *gelu : none;

@@ -159,7 +159,7 @@ int main(int argc, char** argv) {
                             {"fc  ", 4096, 1024, true, kEpiBiasGelu},
                             {"prj2", 1024, 4096, false, kEpiResidual},
                             {"head", 1088, 1024, false, kEpiBias}};
-    const int NREP = 24;   // distinct weight matrices per shape: the stream really comes from HBM
+    const int NREP = getenv("NREP") ? atoi(getenv("NREP")) : 24;   // distinct weight matrices per shape: the stream really comes from HBM (NREP=1: from L2)
     if (!quick)
     for (const Shape& s : shapes) {
         std::vector<float*> wt(NREP);
@@ -228,7 +228,7 @@ int main(int argc, char** argv) {
             const int nwg = ((s.N / (16 * c.ntl) + 7) / 8 * 8) * n_grp;   // (K split: the stamps of the 4 parts of a tile overwrite each other)
             HIP_CHECK(hipMemsetAsync(dprof, 0, (size_t)nwg * 64, st));
             a.prof = dprof;
-            a.Wt = wt[5];
+            a.Wt = wt[5 % NREP];
             launch_variant(a, s, c, st);
             HIP_CHECK(hipStreamSynchronize(st));
             std::vector<long long> hp((size_t)nwg * 8);
@@ -335,7 +335,7 @@ int main(int argc, char** argv) {
                 for (int prec : {0, 1}) {
                     const float us = time_us(st, 20, [&] { chain(attn != 0, prec); });
                     printf("chain of 30 x (qkv,%s proj, fc, proj2) M=%d shapes=%s prec=%d: %.1f us per layer (%.3f ms per step)\n",
-                           attn ? " attention," : "", M, pol ? "r04" : "r03", prec, us / n_layers, us / 1000);
+                           attn ? " attention," : "", M, M > 16 || pol ? "r04" : "r03", prec, us / n_layers, us / 1000);
                     fflush(stdout);
                 }
             if (M > 16) break;   // the two policies differ only at M <= 16
