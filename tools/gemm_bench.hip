@@ -180,12 +180,14 @@ int main(int argc, char** argv) {
                 cfgs.push_back({1, 16, 4, prec});
                 if (M > 16) cfgs.push_back({2, 16, 2, prec});
                 if (M > 16) cfgs.push_back({2, 16, 1, prec});
+                if (M > 48) cfgs.push_back({4, 16, 1, prec});   // 64 rows x 16 columns: every weight line has one reader
                 if (prec) cfgs.push_back({1, 16, 1, prec});
             }
         } else {
             cfgs.push_back({1, 16, 1, 1});
             if (M > 16) cfgs.push_back({2, 16, 1, 0});
             if (M > 16) cfgs.push_back({2, 16, 1, 1});
+            if (M > 48 && s.K == 1024) cfgs.push_back({4, 16, 1, 1});
             if (s.K == 1024 && s.N % 32 == 0) cfgs.push_back({1, 16, 2, 0});
             if (s.K == 1024 && s.N % 32 == 0) cfgs.push_back({1, 16, 2, 1});
         }
