@@ -25,7 +25,7 @@ class aur_config(C.Structure):
     _fields_ = [("n_layer", C.c_int32), ("max_seqs", C.c_int32), ("max_prefill_rows", C.c_int32),
                 ("max_speakers", C.c_int32), ("vocoder_min_batch", C.c_int32), ("profile", C.c_int32),
                 ("vocoder_fp16", C.c_int32), ("second_pass", C.c_int32), ("return_latents", C.c_int32), ("kv_fp16", C.c_int32),
-                ("gemm_f32_exact", C.c_int32), ("gelu_erf", C.c_int32)]
+                ("gemm_f32_exact", C.c_int32), ("gelu_erf", C.c_int32), ("admit_min_batch", C.c_int32)]
 
 
 class aur_tensor_desc(C.Structure):
@@ -63,7 +63,7 @@ class aur_stats(C.Structure):
                 ("attn_bytes", C.c_double), ("decode_steps", C.c_int64), ("decode_ms", C.c_double), ("prefill_ms", C.c_double),
                 ("decode_weight_bytes", C.c_double), ("decode_kv_bytes", C.c_double),
                 ("conv_class_launches", C.c_int64 * 5), ("conv_class_ms", C.c_double * 5), ("conv_class_bytes", C.c_double * 5),
-                ("conv_class_flops", C.c_double * 5)]
+                ("conv_class_flops", C.c_double * 5), ("prefill_batches", C.c_int64)]
 
     def as_dict(self) -> Dict[str, float]:
         out = {}
@@ -169,10 +169,10 @@ class NativeEngine:
     def __init__(self, n_layer: int = 30, max_seqs: int = 64, device: int = 0, max_prefill_rows: int = 0,
                  max_speakers: int = 0, vocoder_min_batch: int = 0, profile: bool = False, vocoder_fp16: bool = False,
                  second_pass: bool = False, return_latents: bool = True, kv_fp16: bool = False,
-                 gemm_f32_exact: bool = False, gelu_erf: bool = False):
+                 gemm_f32_exact: bool = False, gelu_erf: bool = False, admit_min_batch: int = 0):
         self.lib = load_library()
         cfg = aur_config(n_layer, max_seqs, max_prefill_rows, max_speakers, vocoder_min_batch, int(profile),
-                         int(vocoder_fp16), int(second_pass), int(return_latents), int(kv_fp16), int(gemm_f32_exact), int(gelu_erf))
+                         int(vocoder_fp16), int(second_pass), int(return_latents), int(kv_fp16), int(gemm_f32_exact), int(gelu_erf), int(admit_min_batch))
         h = C.c_void_p()
         self._check(self.lib.aur_engine_create(C.byref(cfg), device, C.byref(h)))
         self.h = h

@@ -56,7 +56,8 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
                         vocoder: str = "fp16", **kwargs) -> "XTTSv2Engine":
         """Load a checkpoint directory in the reference's on-disk format (checkpoint.py docstring).  kwargs the
         reference forwards to vLLM (tensor_parallel_size, pipeline_parallel_size, gpt_model, torch_dtype, device_map;
-        XTTSv2.py:235-243) are accepted; tp/pp other than 1 are rejected (the path shards by utterance)."""
+        XTTSv2.py:235-243) are accepted; tp/pp other than 1 are rejected (the path shards by utterance).
+        `admit_min_batch` / `vocoder_min_batch` are the batcher's two grouping knobs (include/auralis_amd.h, aur_config)."""
         from .._lib import NativeEngine
         from ..checkpoint import load_checkpoint, read_checkpoint_config
         from ..weights import pack_all
@@ -69,7 +70,8 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
         # vocoder="fp16": HiFi-GAN convs on fp16-input / fp32-accumulate MFMA (waveform within 1e-5 RMS of the fp32
         # path, the reference's own GPU path autocasts to fp16); vocoder="fp32": exact-f32 MFMA parity mode
         native = NativeEngine(n_layer=ck.n_layer, max_seqs=max(1, max_concurrency), device=device,
-                              vocoder_fp16=(vocoder == "fp16"), return_latents=False, gelu_erf=ck.gelu_erf)
+                              vocoder_fp16=(vocoder == "fp16"), return_latents=False, gelu_erf=ck.gelu_erf,
+                              admit_min_batch=int(kwargs.get("admit_min_batch", 0)), vocoder_min_batch=int(kwargs.get("vocoder_min_batch", 0)))
         native.load_weights(pack_all(gpt_sd, xtts_sd))
         if any(k.startswith("conditioning_encoder.") for k in xtts_sd):
             from ..weights import pack_conditioning

@@ -671,7 +671,16 @@ public:
         {
             std::lock_guard<std::mutex> lk(mu_);
             int rows = 0;
-            while (!waiting_.empty()) {
+            // aur_config.admit_min_batch: a prefill pass costs ~150 launches whatever its rows; with a queue longer than the free
+            // slots, wait until a group of slots is free (the decode step costs the same at 56 rows as at 64)
+            int free_slots = 0;
+            for (int i = 0; i < cfg_.max_seqs; ++i)
+                if (!slot_owner_[i]) ++free_slots;
+            // (default: an eighth of the slots -- the group size that balances the pass's fixed cost against the idle slot-steps grows
+            // with the slot count: g* ~ slots * sqrt(2 * pass_ms / (step_ms * tokens per sequence)) ~ slots / 7 at 30 layers)
+            const int group = std::min(cfg_.admit_min_batch > 0 ? cfg_.admit_min_batch : std::max(1, cfg_.max_seqs / 8), cfg_.max_seqs);
+            const bool hold = free_slots < cfg_.max_seqs && free_slots < std::min(group, (int)waiting_.size());
+            while (!hold && !waiting_.empty()) {
                 Seq* s = waiting_.front();
                 const SpeakerInfo& si = spk_info_[s->spk_row];
                 s->shared_prefix = si.ready && share_prefix_now_;
@@ -709,6 +718,7 @@ public:
             HIP_CHECK(hipEventElapsedTime(&ms, ev_a_, ev_b_));
             stats_.gpt_ms += ms;
             stats_.prefill_ms += ms;
+            stats_.prefill_batches++;
             worked = true;
         }
         // 2. decode step for every running sequence (GPU time is accounted per collected step inside decode)

@@ -13,7 +13,7 @@ same workload once more with aur_set_profile on: HIP events on the stream the ke
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
 Other workloads: `--workload c2` (configs[1]: ONE 200-char utterance, greedy, batch 1: time to audio), `--workload c5s` (configs[4]
-at single-GPU scale: >= 20 k characters of mixed en/fr/de through longform.stream_longform, natural stop, ragged),
+at single-GPU scale: one GPU's eighth of the ~450 k characters, mixed en/fr/de through longform.stream_longform, natural stop, ragged),
 `--workload c4` (configs[3]: 512 utterances dealt 64 at a time to the ranks by parallel.shard_units, strong scaling).  The default
 run also measures c2 and c5s once after the headline (`--no-side` skips them) and, under torchrun with N > 1, c4.
 
@@ -255,7 +255,8 @@ class Bench:
         # profile=False: the engine configuration the parity tests run (tests/test_gpu_baseline_size.py)
         self.eng = NativeEngine(n_layer=args.layers, max_seqs=args.batch, device=local_rank, profile=False,
                                 vocoder_fp16=(args.vocoder == "fp16"), return_latents=False,   # audio + tokens, as TTSOutput
-                                kv_fp16=(args.kv == "fp16"), gemm_f32_exact=(args.gemm == "f32"))
+                                kv_fp16=(args.kv == "fp16"), gemm_f32_exact=(args.gemm == "f32"), admit_min_batch=args.admit_min_batch,
+                                vocoder_min_batch=args.vocoder_min_batch)
         self.packed = pack_all(self.gpt_sd, self.xtts_sd)
         self.eng.load_weights(self.packed)
         _log("weights resident")
@@ -317,12 +318,14 @@ class Bench:
                 "hbm_floor_ms_per_step": (ds["bytes_per_step_as_stored"] / (HBM_PEAK_GBPS * 1e9) * 1e3) if ds else None}
 
     # -- c5s: BASELINE configs[4] at single-GPU scale: mixed-language long form through the facade, natural stop, ragged
-    def workload_c5s(self, chars=20000, window=64):
+    def workload_c5s(self, chars=56250, window=None):
         from auralis_amd import TTS
         from auralis_amd.api.text import XTTSTokenizer
         from auralis_amd.api.xtts_engine import XTTSv2Engine
         from auralis_amd.longform import build_requests, stream_longform
         a, eng = self.args, self.eng
+        inflight = max(a.batch, int(round(a.batch * a.c5_inflight)))   # the facade's semaphore; the engine queues what its slots cannot take
+        window = window or inflight                                      # paragraphs in flight (>= 1 chunk each)
         EN = ("It was a bright cold day in April, and the clocks were striking thirteen. Nobody in the street seemed to notice, "
               "and the wind kept pushing the dust along the old road as if nothing had happened at all. ")
         FR = ("Il était une fois, dans une petite ville que nous ne connaissons pas, un homme qui avait beaucoup d'idées et très peu "
@@ -342,7 +345,7 @@ class Bench:
         reqs = build_requests(paras, [voice], seed=3)   # request defaults: T 0.75 / top_p 0.85 / top_k 50 / rep_pen 5.0
         xe = XTTSv2Engine(eng, XTTSTokenizer(None, vocab_size=self.xtts_sd["text_embedding.weight"].shape[0], synthetic=True),
                           max_concurrency=a.batch)
-        tts = TTS(scheduler_max_concurrency=a.batch).with_engine(xe)
+        tts = TTS(scheduler_max_concurrency=inflight).with_engine(xe)
         try:
             eng.reset_stats()
             self.fence()
@@ -364,14 +367,15 @@ class Bench:
             eng.load_weights({"mel_head.b": np.asarray(self.packed["mel_head.b"], np.float32)})
         occ = st["decode_rows"] / max(1, st["decode_steps"]) / a.batch
         return {"workload": f"BASELINE configs[4] at 1-GPU scale: {sum(len(p) for p in paras)} chars, {len(paras)} paragraphs en/fr/de "
-                            f"(language=auto), {n_chunks} chunks, natural stop (mel_head.bias[1025] = {STOP_BIAS_C5S}), window {window}, "
-                            f"{a.batch} slots, streamed in (paragraph, chunk) order through TTS / longform.stream_longform",
+                            f"(language=auto), {n_chunks} chunks, natural stop (mel_head.bias[1025] = {STOP_BIAS_C5S}), {window} paragraphs / {inflight} chunk "
+                            f"generations in flight on {a.batch} slots (admit_min_batch {a.admit_min_batch or max(1, a.batch // 8)}), streamed in (paragraph, chunk) order "
+                            f"through TTS / longform.stream_longform",
                 "chars": sum(len(p) for p in paras), "paragraphs": len(paras), "chunks": n_chunks, "in_order": bool(order_ok),
                 "wall_s": dt, "first_chunk_s": first, "samples": ns, "audio_s": ns / 24000.0, "samples_per_s": ns / dt, "rtf": dt / max(1e-9, ns / 24000.0),
                 "chars_per_s": sum(len(p) for p in paras) / dt, "slot_occupancy": occ,
                 "tokens_per_chunk": {"mean": float(np.mean(toks)), "min": int(np.min(toks)), "max": int(np.max(toks))} if toks else None,
                 "decode_steps": st["decode_steps"], "decode_ms_per_step": st["decode_ms"] / max(1, st["decode_steps"]),
-                "gpt_ms": st["gpt_ms"], "vocoder_ms": st["vocoder_ms"], "vocoder_batches": st["vocoder_batches"]}
+                "gpt_ms": st["gpt_ms"], "prefill_ms": st.get("prefill_ms"), "vocoder_ms": st["vocoder_ms"], "vocoder_batches": st["vocoder_batches"]}
 
     # -- c4: BASELINE configs[3]: 512 utterances dealt 64 at a time to the ranks (strong scaling; 8 GPUs -> one batch each)
     def workload_c4(self, n_units=512):
@@ -500,7 +504,14 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip the c2 / c5s (and, N > 1, c4) measurements after the headline")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--profile-every", type=int, default=8, help="profile pass: replay batches after every n-th decode step")
-    ap.add_argument("--c5-chars", type=int, default=20000)
+    ap.add_argument("--c5-chars", type=int, default=56250,
+                    help="characters of the c5s long-form text; default = one GPU's eighth of BASELINE configs[4]'s ~450 k characters")
+    ap.add_argument("--admit-min-batch", type=int, default=0,
+                    help="aur_config.admit_min_batch (0 = the engine's default, slots / 8; 1 = admit one by one); matters for c5s only")
+    ap.add_argument("--vocoder-min-batch", type=int, default=0,
+                    help="aur_config.vocoder_min_batch: finished sequences wait for this many before a vocoder batch is launched (0/1 = at once)")
+    ap.add_argument("--c5-inflight", type=float, default=2.0,
+                    help="c5s: chunk generations the facade keeps in flight, as a multiple of the engine's slots (the excess queues inside the engine)")
     ap.add_argument("--pipeline", action="store_true",
                     help="queue all steps at once so the vocoder of batch k overlaps the GPT of batch k+1 (measured neutral)")
     ap.add_argument("--cpu-tokens", type=int, default=280, help="mel tokens of the CPU-baseline utterance (280 = C2 in full)")

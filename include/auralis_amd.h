@@ -59,6 +59,11 @@ typedef struct aur_config {
     int32_t gelu_erf;         /* MLP activation: 0 = tanh form ("gelu_new", what checkpoint_converter.py:197 writes), 1 = erf form
                                  ("gelu", the XTTSGPTConfig class default, xttsv2_gpt_config.py:184); from the checkpoint's
                                  gpt/config.json "activation_function" */
+    int32_t admit_min_batch;  /* continuous batching under saturation: while MORE sequences wait than slots are free (and something
+                                 is running), hold admission until this many slots are free, so that one prefill pass (a fixed
+                                 ~4.5 ms of launches at 30 layers, whatever the rows) serves that many prompts.  A request that finds
+                                 a free slot and no longer queue than free slots is admitted at once, as the reference's vLLM scheduler
+                                 does (two_phase_scheduler.py:168-236 hands every request straight to it).  0 = default max_seqs / 8 (8 at 64 slots); 1 = never hold */
 } aur_config;
 
 /* One named fp32 tensor.  Names are the packed names produced by auralis_amd/weights.py from the
@@ -146,6 +151,7 @@ typedef struct aur_stats {
     double conv_class_ms[5];
     double conv_class_bytes[5];
     double conv_class_flops[5];
+    int64_t prefill_batches;       /* prefill passes (one per aur_step that admitted sequences; aur_config.admit_min_batch groups them) */
 } aur_stats;
 
 const char* aur_last_error(void);

@@ -364,3 +364,39 @@ def test_profile_mode_changes_nothing_but_the_statistics(ctx, dims):
     again = run()
     assert e.stats()["gemm_launches"] == 0                              # off again
     assert [o["tokens"].tolist() for o in again] == [o["tokens"].tolist() for o in base]
+
+
+def test_admission_groups_prefill_passes_and_changes_no_output(dims):
+    """aur_config.admit_min_batch: with a queue longer than the free slots the engine holds admission until a group of slots is
+    free, so that one prefill pass serves several prompts.  24 ragged sequences (natural stop, sampled) on 6 slots: the grouped
+    engine runs fewer prefill passes than the one-by-one engine, every sequence finishes, and ids / latents / audio are equal bit
+    for bit (a sequence never depends on what it was admitted with)."""
+    from auralis_amd._lib import NativeEngine
+    from auralis_amd.checkpoint import make_synthetic_gpt, make_synthetic_xtts
+    from auralis_amd.weights import pack_all
+    gpt_sd = make_synthetic_gpt(dims.gpt, seed=1234, n_layer=2)
+    gpt_sd["mel_head.bias"][1025] = 2.0
+    packed = pack_all(gpt_sd, make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd))
+    cond, spk = make_synthetic_conditioning(dims)
+
+    def run(group):
+        e = NativeEngine(n_layer=2, max_seqs=6, admit_min_batch=group)
+        try:
+            e.load_weights(packed)
+            e.set_conditioning(SPK_KEY, cond.numpy(), spk.numpy())
+            sids = [e.submit(make_synthetic_text_ids(dims, n_text=8 + (5 * k) % 23, seed=60 + k), SPK_KEY, temperature=0.8, top_k=50, top_p=0.85,
+                             repetition_penalty=5.0, max_tokens=4 + (7 * k) % 29, seed=300 + k, ignore_stop=(k % 5 == 0)) for k in range(24)]
+            outs = {o["seq_id"]: o for o in e.run_until_done()}
+            assert sorted(outs) == sorted(sids) and all(o["error"] == 0 for o in outs.values())
+            return [outs[s] for s in sids], e.stats()["prefill_batches"]
+        finally:
+            e.close()
+
+    one, n_one = run(1)
+    grp, n_grp = run(3)
+    dflt, n_dflt = run(9)        # larger than the slot count: capped, i.e. admission only when the engine has drained
+    print("prefill passes: one by one", n_one, "groups of 3", n_grp, "whole engine", n_dflt)
+    assert n_grp < n_one and n_dflt <= n_grp and n_dflt >= 4
+    for a, b, c in zip(one, grp, dflt):
+        assert a["tokens"].tolist() == b["tokens"].tolist() == c["tokens"].tolist()
+        assert np.array_equal(a["wav"], b["wav"]) and np.array_equal(a["wav"], c["wav"]) and np.array_equal(a["latents"], b["latents"])
