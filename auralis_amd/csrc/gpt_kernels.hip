@@ -409,9 +409,10 @@ void launch_gemm_tile(const float* X, int ldx, const float* W, float* P, int M, 
 #define AUR_GTD(BM_, BN_, GE) \
     hipLaunchKernelGGL((gemm_tile_split_kernel<BM_, BN_, GE, true>), dim3((unsigned)((N / BN_) * ((M + BM_ - 1) / BM_)), (unsigned)slabs), dim3(256), 0, st, X, ldx, W, P, M, N, K, g, \
                        reinterpret_cast<const __bf16*>(wsplit))
-    if (prec && wsplit && N % 128 == 0) {   // pre-split weights staged by LDS-DMA (same tile policy as below)
+    if (prec && wsplit && N % 128 == 0) {   // pre-split weight planes: the largest tile shape that still gives ~every CU a workgroup
         const long n128 = (long)slabs * (N / 128) * ((M + 127) / 128), n64 = (long)slabs * (N / 64) * ((M + 127) / 128);
-        if (!small || n128 >= 200) { if (ge) AUR_GTD(128, 128, true); else AUR_GTD(128, 128, false); }
+        // (wide GEMMs too: a 500-row pass of a few prompts is 96 tiles of 128 x 128 on 256 CUs)
+        if (n128 >= 200) { if (ge) AUR_GTD(128, 128, true); else AUR_GTD(128, 128, false); }
         else if (n64 >= 200) { if (ge) AUR_GTD(128, 64, true); else AUR_GTD(128, 64, false); }
         else { if (ge) AUR_GTD(64, 64, true); else AUR_GTD(64, 64, false); }
     } else if (prec) {
