@@ -679,7 +679,11 @@ public:
             // (default: an eighth of the slots -- the group size that balances the pass's fixed cost against the idle slot-steps grows
             // with the slot count: g* ~ slots * sqrt(2 * pass_ms / (step_ms * tokens per sequence)) ~ slots / 7 at 30 layers)
             const int group = std::min(cfg_.admit_min_batch > 0 ? cfg_.admit_min_batch : std::max(1, cfg_.max_seqs / 8), cfg_.max_seqs);
-            const bool hold = free_slots < cfg_.max_seqs && free_slots < std::min(group, (int)waiting_.size());
+            // ... but never for long: with few finishes in sight the free slots would idle while requests wait (kAdmitHoldSteps decode
+            // steps ~ 60 ms at 30 layers, then whatever fits is admitted)
+            bool hold = free_slots < cfg_.max_seqs && free_slots < std::min(group, (int)waiting_.size());
+            if (hold && free_slots > 0 && ++admit_hold_steps_ > kAdmitHoldSteps) hold = false;
+            if (!hold) admit_hold_steps_ = 0;
             while (!hold && !waiting_.empty()) {
                 Seq* s = waiting_.front();
                 const SpeakerInfo& si = spk_info_[s->spk_row];
@@ -748,9 +752,16 @@ public:
             std::lock_guard<std::mutex> lk(mu_);
             n_wait = waiting_.size();
         }
-        const int minb = std::max(1, cfg_.vocoder_min_batch);
-        if (!voc_active_ && !voc_queue_.empty() && ((int)voc_queue_.size() >= minb || (running == 0 && n_wait == 0)))
+        // aur_config.vocoder_min_batch: a vocoder pass of one utterance costs twice per utterance what a pass of eight does (and
+        // slows the decode steps it runs beside); finished sequences wait for company, at most kVocHoldSteps steps
+        const int minb = cfg_.vocoder_min_batch > 0 ? cfg_.vocoder_min_batch : std::max(1, cfg_.max_seqs / 16);
+        if (voc_queue_.empty() || voc_active_) voc_hold_steps_ = 0;
+        else ++voc_hold_steps_;
+        if (!voc_active_ && !voc_queue_.empty() &&
+            ((int)voc_queue_.size() >= minb || (running == 0 && n_wait == 0) || voc_hold_steps_ > kVocHoldSteps)) {
             voc_launch();
+            voc_hold_steps_ = 0;
+        }
         if (running == 0 && n_wait == 0 && voc_active_) voc_poll(true);   // nothing else to do: wait for the batch
         if (running == 0 && n_wait == 0 && !voc_active_ && !voc_queue_.empty()) {
             voc_launch();
@@ -2099,6 +2110,10 @@ private:
     uint64_t next_id_ = 1;
     std::unordered_map<uint64_t, std::unique_ptr<Seq>> seqs_;
     std::deque<Seq*> waiting_, done_;
+    static constexpr int kAdmitHoldSteps = 32;   // longest hold of an admissible request by aur_config.admit_min_batch, in aur_steps
+    int admit_hold_steps_ = 0;
+    static constexpr int kVocHoldSteps = 16;     // longest wait of a finished sequence for a fuller vocoder batch, in aur_steps (~30 ms)
+    int voc_hold_steps_ = 0;
     std::vector<Seq*> slot_owner_;
     std::vector<Seq*> just_finished_;
     int64_t finished_total_ = 0;

@@ -38,7 +38,8 @@ typedef struct aur_config {
     int32_t max_seqs;         /* concurrent sequences (continuous-batching slots) */
     int32_t max_prefill_rows; /* cap on prompt rows prefetched in one step (0 = default 8192) */
     int32_t max_speakers;     /* speaker-conditioning table entries (0 = default 64) */
-    int32_t vocoder_min_batch;/* hold finished sequences until this many are ready (0/1 = vocode at once) */
+    int32_t vocoder_min_batch;/* finished sequences wait until this many are ready for one vocoder pass -- at most 16 steps (~30 ms), and not
+                                 at all when nothing else runs or waits.  0 = default max_seqs / 16 (4 at 64 slots); 1 = vocode at once */
     int32_t profile;          /* 1 = profile mode from the start (see aur_set_profile; every 64th decode step) */
     int32_t vocoder_fp16;     /* 1 = HiFi-GAN convs on fp16-input / fp32-accumulate MFMA (needs the voc16.* tensors);
                                  0 = exact-f32 MFMA parity mode */
@@ -63,7 +64,8 @@ typedef struct aur_config {
                                  is running), hold admission until this many slots are free, so that one prefill pass (a fixed
                                  ~4.5 ms of launches at 30 layers, whatever the rows) serves that many prompts.  A request that finds
                                  a free slot and no longer queue than free slots is admitted at once, as the reference's vLLM scheduler
-                                 does (two_phase_scheduler.py:168-236 hands every request straight to it).  0 = default max_seqs / 8 (8 at 64 slots); 1 = never hold */
+                                 does (two_phase_scheduler.py:168-236 hands every request straight to it).  A hold ends after 32 steps (~60 ms) whatever is
+                                 free by then.  0 = default max_seqs / 8 (8 at 64 slots); 1 = never hold */
 } aur_config;
 
 /* One named fp32 tensor.  Names are the packed names produced by auralis_amd/weights.py from the

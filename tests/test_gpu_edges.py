@@ -400,3 +400,34 @@ def test_admission_groups_prefill_passes_and_changes_no_output(dims):
     for a, b, c in zip(one, grp, dflt):
         assert a["tokens"].tolist() == b["tokens"].tolist() == c["tokens"].tolist()
         assert np.array_equal(a["wav"], b["wav"]) and np.array_equal(a["wav"], c["wav"]) and np.array_equal(a["latents"], b["latents"])
+
+
+def test_admission_hold_is_bounded(dims):
+    """A hold by admit_min_batch ends after 32 steps: one long sequence keeps a slot, the other slot is free, two requests wait for a
+    group of two slots that will not be free for 120 steps -- they are admitted after the bound, not after the long sequence."""
+    from auralis_amd._lib import NativeEngine
+    from auralis_amd.checkpoint import make_synthetic_gpt, make_synthetic_xtts
+    from auralis_amd.weights import pack_all
+    gpt_sd = make_synthetic_gpt(dims.gpt, seed=1234, n_layer=2)
+    packed = pack_all(gpt_sd, make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd))
+    cond, spk = make_synthetic_conditioning(dims)
+
+    def run(group):
+        e = NativeEngine(n_layer=2, max_seqs=2, admit_min_batch=group)
+        try:
+            e.load_weights(packed)
+            e.set_conditioning(SPK_KEY, cond.numpy(), spk.numpy())
+            sids = [e.submit(make_synthetic_text_ids(dims, n_text=10 + k, seed=80 + k), SPK_KEY, temperature=0.0, max_tokens=n, seed=1, ignore_stop=True)
+                    for k, n in enumerate([120, 2, 5, 5])]
+            outs = {o["seq_id"]: o for o in e.run_until_done()}
+            st = e.stats()
+            return [outs[s] for s in sids], st["decode_steps"], st["prefill_batches"]
+        finally:
+            e.close()
+
+    one, steps_one, _ = run(1)
+    grp, steps_grp, passes = run(2)
+    print("decode steps: one by one", steps_one, "groups of two", steps_grp, "prefill passes", passes)
+    assert steps_grp <= 123 and passes >= 3          # without the bound: 120 + 5 steps and the two short requests behind the long one
+    for a, b in zip(one, grp):
+        assert a["tokens"].tolist() == b["tokens"].tolist() and np.array_equal(a["wav"], b["wav"])
