@@ -4,8 +4,8 @@ The reference handles a book as ONE request: `TTS.split_requests` cuts it at 100
 cuts those at the per-language character limit, and chunk outputs are re-emitted in order (core/tts.py:236-355,
 config/tokenizer.py:119-236, two_phase_scheduler.py:308-388).  A request carries one language tag, so mixed-language
 material is fed paragraph by paragraph with `language="auto"`.  This helper does exactly that on top of the facade:
-every paragraph becomes a TTSRequest (language detected per paragraph), up to `window` paragraphs are in flight at a
-time so the engine's continuous batcher stays full, and audio is yielded strictly in (paragraph, chunk) order.
+every paragraph becomes a TTSRequest (language detected per paragraph), up to `window` paragraphs (default: twice the facade's
+concurrency) are in flight at a time so the engine's continuous batcher stays full, and audio is yielded strictly in (paragraph, chunk) order.
 On several GPUs each rank takes the paragraphs `shard_units` deals to it and the chunks stream to one rank in order
 (`stream_sharded` / `synthesize_sharded`, auralis_amd/parallel.py)."""
 from __future__ import annotations
@@ -32,11 +32,17 @@ def build_requests(paragraphs: Sequence[str], speaker_files, seed: Optional[int]
     return reqs
 
 
-async def stream_longform_async(tts, requests: Sequence[TTSRequest], window: int = 8
+def default_window(tts) -> int:
+    """Paragraphs in flight when the caller names none: twice the facade's chunk concurrency (`scheduler_max_concurrency`), so that its
+    semaphore -- and behind it the engine's slots and admission queue -- stays full while finished paragraphs wait to be emitted in order."""
+    return max(8, 2 * int(getattr(tts, "scheduler_max_concurrency", 4) or 4))
+
+
+async def stream_longform_async(tts, requests: Sequence[TTSRequest], window: Optional[int] = None
                                 ) -> AsyncGenerator[Tuple[int, TTSOutput], None]:
-    """Yield (paragraph index, chunk) in order; at most `window` paragraphs are being synthesised ahead."""
+    """Yield (paragraph index, chunk) in order; at most `window` paragraphs (default_window) are being synthesised ahead."""
     queues = [asyncio.Queue() for _ in requests]
-    sem = asyncio.Semaphore(max(1, window))
+    sem = asyncio.Semaphore(max(1, window or default_window(tts)))
     _END = object()
 
     async def run(i: int, req: TTSRequest):
@@ -66,7 +72,7 @@ async def stream_longform_async(tts, requests: Sequence[TTSRequest], window: int
                 t.cancel()
 
 
-def stream_longform(tts, requests: Sequence[TTSRequest], window: int = 8) -> Iterable[Tuple[int, TTSOutput]]:
+def stream_longform(tts, requests: Sequence[TTSRequest], window: Optional[int] = None) -> Iterable[Tuple[int, TTSOutput]]:
     """Synchronous wrapper running on the facade's own event loop."""
     agen = stream_longform_async(tts, requests, window)
     try:
@@ -79,7 +85,7 @@ def stream_longform(tts, requests: Sequence[TTSRequest], window: int = 8) -> Ite
         asyncio.run_coroutine_threadsafe(agen.aclose(), tts._loop).result()
 
 
-def stream_sharded(tts, requests: Sequence[TTSRequest], window: int = 8, paragraphs_per_block: int = 8, dst: int = 0
+def stream_sharded(tts, requests: Sequence[TTSRequest], window: Optional[int] = None, paragraphs_per_block: int = 8, dst: int = 0
                    ) -> Iterable[Tuple[int, np.ndarray]]:
     """Book on several GPUs, STREAMED (one process per GPU, torch.distributed initialised; BASELINE config 5 at 8 x MI355X).
 
@@ -233,7 +239,7 @@ def stream_sharded(tts, requests: Sequence[TTSRequest], window: int = 8, paragra
         th.join(timeout=5.0)                                       # had queued: they stop at their next chunk, not at once)
 
 
-def synthesize_sharded(tts, requests: Sequence[TTSRequest], window: int = 8, paragraphs_per_block: int = 8,
+def synthesize_sharded(tts, requests: Sequence[TTSRequest], window: Optional[int] = None, paragraphs_per_block: int = 8,
                        dst: int = 0) -> Optional[TTSOutput]:
     """The whole book as one TTSOutput on rank `dst` (None elsewhere): stream_sharded, concatenated."""
     import torch.distributed as dist
