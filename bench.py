@@ -322,10 +322,8 @@ class Bench:
         from auralis_amd import TTS
         from auralis_amd.api.text import XTTSTokenizer
         from auralis_amd.api.xtts_engine import XTTSv2Engine
-        from auralis_amd.longform import build_requests, stream_longform
+        from auralis_amd.longform import build_requests, default_window, stream_longform
         a, eng = self.args, self.eng
-        inflight = max(a.batch, int(round(a.batch * a.c5_inflight)))   # the facade's semaphore; the engine queues what its slots cannot take
-        window = window or inflight                                      # paragraphs in flight (>= 1 chunk each)
         EN = ("It was a bright cold day in April, and the clocks were striking thirteen. Nobody in the street seemed to notice, "
               "and the wind kept pushing the dust along the old road as if nothing had happened at all. ")
         FR = ("Il était une fois, dans une petite ville que nous ne connaissons pas, un homme qui avait beaucoup d'idées et très peu "
@@ -345,7 +343,9 @@ class Bench:
         reqs = build_requests(paras, [voice], seed=3)   # request defaults: T 0.75 / top_p 0.85 / top_k 50 / rep_pen 5.0
         xe = XTTSv2Engine(eng, XTTSTokenizer(None, vocab_size=self.xtts_sd["text_embedding.weight"].shape[0], synthetic=True),
                           max_concurrency=a.batch)
-        tts = TTS(scheduler_max_concurrency=inflight).with_engine(xe)
+        tts = TTS(scheduler_max_concurrency=a.batch).with_engine(xe)
+        inflight = tts.scheduler.second_phase_concurrency   # the facade's gate (2 x slots): the engine queues what its slots cannot take
+        window = window or default_window(tts)              # paragraphs in flight (>= 1 chunk each)
         try:
             eng.reset_stats()
             self.fence()
@@ -510,8 +510,6 @@ def main():
                     help="aur_config.admit_min_batch (0 = the engine's default, slots / 8; 1 = admit one by one); matters for c5s only")
     ap.add_argument("--vocoder-min-batch", type=int, default=0,
                     help="aur_config.vocoder_min_batch: finished sequences wait for this many before a vocoder batch is launched (0/1 = at once)")
-    ap.add_argument("--c5-inflight", type=float, default=2.0,
-                    help="c5s: chunk generations the facade keeps in flight, as a multiple of the engine's slots (the excess queues inside the engine)")
     ap.add_argument("--pipeline", action="store_true",
                     help="queue all steps at once so the vocoder of batch k overlaps the GPT of batch k+1 (measured neutral)")
     ap.add_argument("--cpu-tokens", type=int, default=280, help="mel tokens of the CPU-baseline utterance (280 = C2 in full)")
