@@ -112,4 +112,30 @@ class TTSOutput:
         return TTSOutput(array=y.astype(np.float32), sample_rate=self.sample_rate)
 
     def play(self) -> None:
-        raise RuntimeError("audio playback needs sounddevice (not part of the synthesis path)")
+        """Blocking playback on the default sound device (reference: output.py:287-303, sounddevice).  The package is optional."""
+        try:
+            import sounddevice as sd
+        except ImportError as e:
+            raise RuntimeError("audio playback needs the optional package sounddevice (not part of the synthesis path)") from e
+        sd.play(np.clip(np.asarray(self.array, np.float32), -1.0, 1.0), self.sample_rate, blocksize=2048)
+        sd.wait()
+
+    def display(self):
+        """Notebook audio widget (reference: output.py:305-319): returns the IPython Audio object, or None (with a hint) when
+        IPython is not there or the widget cannot be built."""
+        try:
+            from IPython.display import Audio, display
+            widget = Audio(self.to_bytes(format="wav"), rate=self.sample_rate, autoplay=False)
+            display(widget)
+            return widget
+        except Exception as e:
+            print(f"Could not display audio widget: {e}\nTry using .play() method instead")
+            return None
+
+    def preview(self) -> None:
+        """Widget in a notebook, sound device otherwise (reference: output.py:321-329); never raises."""
+        try:
+            if self.display() is None:
+                self.play()
+        except Exception as e:
+            print(f"Error playing audio: {e}")

@@ -58,6 +58,25 @@ def test_output_roundtrip_and_transforms(tmp_path):
         o.to_bytes("ogg-vorbis")          # not in the reference's format list (mp3 / opus / aac / flac: tests/test_codecs.py)
 
 
+def test_output_playback_helpers_degrade_like_the_reference(capsys):
+    """display() returns None with a hint when no notebook widget can be built, preview() falls back to play() and never raises
+    (reference output.py:305-329); play() itself names the optional package it needs."""
+    o = TTSOutput(array=np.zeros(240, np.float32))
+    try:
+        import IPython  # noqa: F401
+        has_ipython = True
+    except ImportError:
+        has_ipython = False
+    if not has_ipython:
+        assert o.display() is None and "play()" in capsys.readouterr().out
+    o.preview()                            # no sound device, no notebook: prints, does not raise
+    try:
+        import sounddevice  # noqa: F401
+    except ImportError:
+        with pytest.raises(RuntimeError, match="sounddevice"):
+            o.play()
+
+
 def test_split_sentence_respects_limit_and_keeps_words():
     text = " ".join([PARA] * 6)
     for lang in ("en", "fr", "de"):
