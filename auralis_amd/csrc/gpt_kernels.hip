@@ -1017,6 +1017,7 @@ void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, 
 // Paged causal attention: one workgroup per (row, head).  16 lanes x float4 (fp32 pool) or 8 lanes x 8 halves (fp16 pool) span
 // the 64-wide head, so one wave instruction covers 4 / 8 consecutive cached tokens (1 KiB contiguous); 4 waves stride the
 // context.  Scores are reduced with wavefront shuffles; online softmax per lane group; groups merged through LDS.
+constexpr int kAttnMaxBlocks = 128;   // block-table entries of a row staged in LDS (the engine's table has 66)
 template <bool KVH>
 __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __restrict__ qbuf, const void* __restrict__ kv_layer_v,
                                                               const int* __restrict__ row_slot, const int* __restrict__ row_pos,
@@ -1047,27 +1048,11 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
         pos = row_pos ? row_pos[m] : slot_kvpos[slot];
         bt = block_tables + (long)slot * max_blocks;
     }
-    const int n_keys = pos + 1;
-    const KT* kv_layer = reinterpret_cast<const KT*>(kv_layer_v);
-
-    // UN steps unrolled: all 2*UN K/V loads of a lane are issued before the first softmax update (addresses are clamped instead
-    // of predicated so that the loads can be hoisted).  The first batch goes out before q is assembled: it does not depend on q.
-    // (the fp16 pool's values stay packed, 4 registers per 8 halves, until they are used: as floats they cost 104 VGPRs)
-    using RawT = typename std::conditional<KVH, h16x8g, f32x4>::type;
-    RawT kraw[UN], vraw[UN];
-    auto load_kv = [&](int t0) {
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            // (clamped to the context, not to the table: making the address independent of the row's position -- one dependent load
-            // less in front of the first K/V loads -- made the masked lanes fetch real, distinct rows: 24.2 vs 22.6 us per launch)
-            const int t = min(t0 + 4 * TPW * u + wv * TPW + g, n_keys - 1);
-            const int blk = bt[t / kKvBlockTokens];
-            const long off = kv_offset(blk, 0, head, t % kKvBlockTokens) + dl * EPL;
-            kraw[u] = *reinterpret_cast<const RawT*>(kv_layer + off);
-            vraw[u] = *reinterpret_cast<const RawT*>(kv_layer + off + (long)kHeads * kKvBlockTokens * kHeadDim);
-        }
-    };
-    load_kv(0);
+    // The row's block table goes to LDS once (issued together with `pos`, it does not depend on it): a token step then costs ONE
+    // dependent memory round trip (its K/V rows) instead of two (table entry, then rows), and the first K/V loads sit two trips
+    // behind the launch instead of three.  Same loads of the same rows in the same order as before: bitwise equal.
+    __shared__ int bt_s[kAttnMaxBlocks];
+    if ((int)threadIdx.x < max_blocks) bt_s[threadIdx.x] = bt[threadIdx.x];   // max_blocks <= kAttnMaxBlocks <= 256 (launcher)
     float qv[EPL];
     {
         const float* qp = qbuf + (long)m * kHidden + head * kHeadDim + dl * EPL;
@@ -1078,6 +1063,28 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
             for (int c = 0; c < 4; ++c) qv[4 * c4 + c] = q4[c];
         }
     }
+    __syncthreads();
+    const int n_keys = pos + 1;
+    const KT* kv_layer = reinterpret_cast<const KT*>(kv_layer_v);
+
+    // UN steps unrolled: all 2*UN K/V loads of a lane are issued before the first softmax update (addresses are clamped instead
+    // of predicated so that the loads can be hoisted).
+    // (the fp16 pool's values stay packed, 4 registers per 8 halves, until they are used: as floats they cost 104 VGPRs)
+    using RawT = typename std::conditional<KVH, h16x8g, f32x4>::type;
+    RawT kraw[UN], vraw[UN];
+    auto load_kv = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            // (clamped to the context, not to the table: making the address independent of the row's position -- one dependent load
+            // less in front of the first K/V loads -- made the masked lanes fetch real, distinct rows: 24.2 vs 22.6 us per launch)
+            const int t = min(t0 + 4 * TPW * u + wv * TPW + g, n_keys - 1);
+            const int blk = bt_s[t / kKvBlockTokens];
+            const long off = kv_offset(blk, 0, head, t % kKvBlockTokens) + dl * EPL;
+            kraw[u] = *reinterpret_cast<const RawT*>(kv_layer + off);
+            vraw[u] = *reinterpret_cast<const RawT*>(kv_layer + off + (long)kHeads * kKvBlockTokens * kHeadDim);
+        }
+    };
+    load_kv(0);
     float mi = -INFINITY, li = 0.f;
     float o[EPL];
 #pragma unroll
@@ -1291,6 +1298,7 @@ void launch_paged_attention(const float* qbuf, const void* kv_layer, const int* 
                             const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
                             hipStream_t st, int out_mtt, bool kv_half, const int* row_meta) {
     trace_launch("paged_attention_kernel");
+    AUR_REQUIRE(max_blocks >= 1 && max_blocks <= kAttnMaxBlocks, "paged attention: block table longer than the kernel's LDS copy");
     if (kv_half)
         hipLaunchKernelGGL(paged_attention_kernel<true>, dim3(M, kHeads), dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos,
                            slot_kvpos, block_tables, max_blocks, out, out_mtt, row_meta);
