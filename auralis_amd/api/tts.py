@@ -22,10 +22,11 @@ from .scheduler import TwoPhaseScheduler
 class TTS:
     def __init__(self, scheduler_max_concurrency: int = 10, vllm_logging_level=None):
         self.scheduler_max_concurrency = scheduler_max_concurrency
-        # scheduler_max_concurrency is what the engine gets as its slot count (the reference hands it to vLLM's max_num_seqs,
-        # XTTSv2.py:235-243); the facade's own gate is twice as wide, so that a saturated engine has a queue to group its
-        # admissions from (aur_config.admit_min_batch) instead of running one prefill pass per freed slot
-        self.scheduler: Optional[TwoPhaseScheduler] = TwoPhaseScheduler(2 * max(1, int(scheduler_max_concurrency)))
+        # the same bound the reference passes (core/tts.py:20-51: TwoPhaseScheduler(scheduler_max_concurrency)); the engine gets the
+        # same number as its slot count (the reference hands it to vLLM's max_num_seqs, XTTSv2.py:235-243).  Phase 1 submits every
+        # chunk of a request to the engine at once, so what the engine cannot seat waits in ITS queue -- which is where grouped
+        # admission (aur_config.admit_min_batch) takes its groups from -- whatever the width of this gate.
+        self.scheduler: Optional[TwoPhaseScheduler] = TwoPhaseScheduler(max(1, int(scheduler_max_concurrency)))
         self.tts_engine: Optional[BaseAsyncTTSEngine] = None
         self.concurrency = scheduler_max_concurrency
         self.max_vllm_memory = None

@@ -11,9 +11,12 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_C")
 LIB = os.path.join(OUT_DIR, "libauralis_amd.so")
 SOURCES = ["vocoder_kernels.hip", "gpt_kernels.hip", "cond_kernels.hip", "engine.hip"]
-HEADERS = ["common.h", "vocoder_kernels.h", "gpt_kernels.h", "cond_kernels.h", "cond_net.h", os.path.join("..", "..", "include", "auralis_amd.h")]
+HEADERS = ["common.h", "vocoder_kernels.h", "gpt_kernels.h", "gemm_rows_kernel.inc", "cond_kernels.h", "cond_net.h", os.path.join("..", "..", "include", "auralis_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# -amdgpu-kernarg-preload-count=16: the leading scalar kernel arguments (up to 14 dwords next to the kernarg pointer) arrive in SGPRs
+# with the wave instead of through dependent s_load round trips; a kernel whose firmware does not preload runs its compatibility
+# prologue (one s_load burst).  The decode kernels order their arguments for it (gemm_rows_kernel.inc, paged_attention_kernel).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 HASH_FILE = LIB + ".srchash"

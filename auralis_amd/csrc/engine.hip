@@ -911,7 +911,11 @@ public:
             a.bias = dvec.as<float>() + N;
         } else {
             launch_pack_wt16(dw.as<float>(), N, dwt.as<float>(), K, N, st_);
-            a.bias = bias ? db.as<float>() : nullptr;
+            if (!bias) {   // the kernel loads its bias unconditionally
+                db.ensure((size_t)N * 4);
+                HIP_CHECK(hipMemsetAsync(db.p, 0, (size_t)N * 4, st_));
+            }
+            a.bias = db.as<float>();
         }
         a.X = dx.as<float>(); a.xmt = mtt; a.Wt = dwt.as<float>(); a.M = M; a.N = N; a.K = K;
         a.eps = 1e-5f; a.prec = gemm_prec_;
@@ -923,6 +927,50 @@ public:
         HIP_CHECK(hipMemcpy(ho.data(), dout.p, ho.size() * 4, hipMemcpyDeviceToHost));
         for (int m = 0; m < M; ++m)
             for (int n = 0; n < N; ++n) out[(size_t)m * N + n] = ho[out_packed ? pk_off(m, n, mtt) : (size_t)m * N + n];
+    }
+    // Stress of the K-split projection's cross-workgroup protocol (gemm_rows_kernel.inc, KSP: write-through partial tiles, drained
+    // vmcnt, device-scope ticket, sc0 sc1 read-back by the last arriver, counter reset for the next launch): `iters` back-to-back
+    // launches of the K = 4096 -> 1024 residual GEMM at M rows, no host synchronisation in between, each compared word for word on
+    // the device with the UNSPLIT kernel's result on the same operands.  A visibility bug shows up as a non-zero count.
+    long long dbg_gemm_rows_ksplit_stress(int M, int iters) {
+        use();
+        const int K = 4 * kHidden, N = kHidden;
+        AUR_REQUIRE(M >= 1 && M <= 32 && iters >= 1, "ksplit stress: the split is used for M <= 32 rows");
+        AUR_REQUIRE(gemm_rows_shape(M, N, K, false).ksp > 1, "ksplit stress: the policy does not split at this M");
+        const int mtt = 4;
+        std::vector<float> hx((size_t)mtt * 16 * K), hw((size_t)K * N), hb(N), hh((size_t)mtt * 16 * N);
+        unsigned sd = 12345u + (unsigned)M;
+        auto rnd = [&] { sd = sd * 1664525u + 1013904223u; return (float)(sd >> 8) * (1.0f / 8388608.0f) - 1.0f; };
+        for (auto& v : hx) v = rnd();
+        for (auto& v : hw) v = 0.05f * rnd();
+        for (auto& v : hb) v = 0.1f * rnd();
+        for (auto& v : hh) v = rnd();
+        DevBuf dx, dw, dwt, db, dh0, dh, dref, dcnt;
+        dx.ensure(hx.size() * 4); dw.ensure(hw.size() * 4); dwt.ensure(hw.size() * 4); db.ensure(hb.size() * 4);
+        dh0.ensure(hh.size() * 4); dh.ensure(hh.size() * 4); dref.ensure(hh.size() * 4); dcnt.ensure(8);
+        HIP_CHECK(hipMemcpy(dx.p, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dw.p, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(db.p, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dh0.p, hh.data(), hh.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemsetAsync(dcnt.p, 0, 8, st_));
+        launch_pack_wt16(dw.as<float>(), N, dwt.as<float>(), K, N, st_);
+        GemmRowsArgs a{};
+        a.X = dx.as<float>(); a.xmt = mtt; a.omt = mtt; a.Wt = dwt.as<float>(); a.M = M; a.N = N; a.K = K; a.bias = db.as<float>(); a.prec = gemm_prec_;
+        a.out = dref.as<float>();   // reference: no scratch -> the unsplit kernel
+        HIP_CHECK(hipMemcpyAsync(dref.p, dh0.p, hh.size() * 4, hipMemcpyDeviceToDevice, st_));
+        launch_gemm_rows(a, false, kEpiResidual, st_);
+        a.out = dh.as<float>(); a.ksp_buf = ksp_buf_.as<float>(); a.ksp_cnt = ksp_cnt_.as<unsigned>();
+        for (int i = 0; i < iters; ++i) {
+            HIP_CHECK(hipMemcpyAsync(dh.p, dh0.p, hh.size() * 4, hipMemcpyDeviceToDevice, st_));
+            launch_gemm_rows(a, false, kEpiResidual, st_);
+            if (i % 3 == 2) launch_gemm_rows(a, false, kEpiResidual, st_), HIP_CHECK(hipMemcpyAsync(dh.p, dh0.p, hh.size() * 4, hipMemcpyDeviceToDevice, st_)),
+                launch_gemm_rows(a, false, kEpiResidual, st_);   // (two split launches with nothing between them: the counter reset is on the path)
+            launch_count_mismatch(dh.p, dref.p, (long)hh.size(), dcnt.as<unsigned long long>(), st_);
+        }
+        unsigned long long bad = 0;
+        HIP_CHECK(hipMemcpyAsync(&bad, dcnt.p, 8, hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipStreamSynchronize(st_));
+        return (long long)bad;
     }
     void dbg_layernorm(const float* h, const float* gamma, const float* beta, float* out, int M) {
         use();
@@ -1208,8 +1256,7 @@ private:
         if (kind == 0) {
             a.eps = 1e-5f; a.X = h; a.Wt = L.tqkv; a.N = 3 * kHidden; a.K = kHidden; a.bias = L.qkv_c2;
             a.ln_c1 = L.qkv_c1; a.stats_in = w.stats.as<float2>(); a.out = redirect ? prof_q_.as<float>() : w.qbuf.as<float>(); a.ldo = kHidden;
-            a.kv_layer = redirect ? prof_kv_.p : kv_layer(l); a.kv_half = kv_half_ ? 1 : 0; a.row_meta = w.row_meta.as<int>(); a.row_slot = d_row_slot;
-            a.slot_kvpos = slot_kvpos_.as<int>(); a.block_tables = block_tables_.as<int>(); a.max_blocks = kMaxBlocks;
+            a.kv_layer = redirect ? prof_kv_.p : kv_layer(l); a.kv_half = kv_half_ ? 1 : 0; a.row_meta = w.row_meta.as<int>();
         } else if (kind == 1) {
             a.X = w.att.as<float>(); a.Wt = L.tproj; a.N = kHidden; a.K = kHidden; a.bias = L.bproj;
             a.out = redirect ? prof_h_.as<float>() : h; a.omt = mtt; a.stats_out = redirect ? prof_stats_.as<float2>() : w.stats.as<float2>();
@@ -1241,8 +1288,7 @@ private:
                 decode_gemm_kind(kind, &ln, &epi);
                 launch_gemm_rows(decode_gemm_args(w, l, kind, M, d_row_slot, false), ln, epi, w.st);
                 if (kind == 0)
-                    launch_paged_attention(w.qbuf.as<float>(), kv_layer(l), d_row_slot, nullptr, slot_kvpos_.as<int>(), block_tables_.as<int>(),
-                                           kMaxBlocks, w.att.as<float>(), M, w.st, mtt, kv_half_, w.row_meta.as<int>());
+                    launch_paged_attention(w.qbuf.as<float>(), kv_layer(l), w.row_meta.as<int>(), kMaxBlocks, w.att.as<float>(), M, w.st, mtt, kv_half_);
             }
         }
     }
@@ -1272,8 +1318,7 @@ private:
                 ConvEvent& ea = prof_event(5, nl * 4.0 * kHidden * step_kv_tokens_, nl * ((kv_half_ ? 4.0 : 8.0) * kHidden * step_kv_tokens_ + 8.0 * kHidden * M), nl);
                 HIP_CHECK(hipEventRecord(ea.a, w.st));
                 for (int l = 0; l < nl; ++l)
-                    launch_paged_attention(w.qbuf.as<float>(), kv_layer(l), d_row_slot, nullptr, slot_kvpos_.as<int>(), block_tables_.as<int>(),
-                                           kMaxBlocks, prof_h_.as<float>(), M, w.st, mtt, kv_half_, w.row_meta.as<int>());
+                    launch_paged_attention(w.qbuf.as<float>(), kv_layer(l), w.row_meta.as<int>(), kMaxBlocks, prof_h_.as<float>(), M, w.st, mtt, kv_half_);
                 HIP_CHECK(hipEventRecord(ea.b, w.st));
             }
         }
@@ -2289,6 +2334,11 @@ int aur_dbg_gemm_rows(aur_engine* e, const float* X, const float* W, const float
     CHECK_PTR(W);
     CHECK_PTR(out);
     return guarded([&] { e->impl.dbg_gemm_rows(X, W, bias, gamma, beta, out, M, N, K, epi, ln != 0); });
+}
+int aur_dbg_gemm_rows_ksplit_stress(aur_engine* e, int32_t M, int32_t iters, int64_t* mismatches_out) {
+    CHECK_PTR(e);
+    CHECK_PTR(mismatches_out);
+    return guarded([&] { *mismatches_out = e->impl.dbg_gemm_rows_ksplit_stress(M, iters); });
 }
 int aur_dbg_layernorm(aur_engine* e, const float* h, const float* gamma, const float* beta, float* out, int32_t M) {
     CHECK_PTR(e);

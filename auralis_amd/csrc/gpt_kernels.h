@@ -51,21 +51,18 @@ struct GemmRowsArgs {
     int xmt;             // 16-row tiles allocated in X (pk_off's mtt); >= ceil(M / 64) * 4
     const float* Wt;     // packed (pack_wt16)
     int M, N, K;
-    const float* bias;   // [N] or nullptr; LayerNorm-folded GEMMs: c2 of launch_fold_ln (required)
+    const float* bias;   // [N], required (zeros for none); LayerNorm-folded GEMMs: c2 of launch_fold_ln
     const float* ln_c1;  // LayerNorm-folded GEMMs (ln != 0, K == 1024): c1 of launch_fold_ln, Wt = its folded packed weights
     float eps;
     float* out;          // kEpiBias: row-major out[m][n] (ldo);  kEpiBiasGelu: packed rows (omt);  kEpiResidual: packed rows,
                          // out[m][n] += total + bias;  kEpiQkv: row-major q rows [M][1024]
     int ldo;
     int omt;             // 16-row tiles allocated in a packed `out`
-    void* kv_layer;      // kEpiQkv: paged K/V of this layer, written at (slot = row_slot[m], pos = slot_kvpos[slot])
+    void* kv_layer;      // kEpiQkv: paged K/V of this layer, written at (position row_meta[m][0], block row_meta[m][kRowMetaWblk])
     int kv_half;         // 1: the K/V pool holds fp16 (aur_config.kv_fp16 throughput mode), else fp32
-    const int* row_slot;
-    const int* slot_kvpos;
-    const int* block_tables;
-    int max_blocks;
-    const int* row_meta; // optional dense per-row copy {pos, slot, .., block table at +kRowMetaBt} (embed_decode_kernel): one memory
-                         // round trip instead of the row_slot -> slot_kvpos -> block_tables chain at the end of the kernel
+    const int* row_meta; // kEpiQkv (required): the step's dense per-row K/V addressing written by embed_decode_kernel
+                         // ([m][kRowMetaStride] ints: position, slot, write block, block table) -- one load per output element
+                         // instead of the row_slot -> slot_kvpos -> block_tables chain
     // LayerNorm statistics travel as per-column-tile partials (mean_t, M2_t = sum (x - mean_t)^2 over the tile's 16 columns):
     // the kernels that WRITE the residual stream (embed_decode, the kEpiResidual epilogue) emit stats[row][tile] for the 64
     // tiles of a 1024-wide row, the LN prologue combines them (Chan's parallel variance, fixed order) instead of reducing the
@@ -76,7 +73,6 @@ struct GemmRowsArgs {
     int prec;            // arithmetic: 0 = exact f32 MFMA (v_mfma_f32_16x16x4_f32); 1 = every operand split exactly into three bf16
                          // terms, six bf16 MFMAs per product with fp32 accumulation (same accuracy class as an fp32 dot product,
                          // not bitwise an fma chain; 2.7x less matrix-pipe time).  aur_config.gemm_f32_exact selects 0.
-    long long* prof;     // optional (tools/gemm_bench): 8 wall_clock64 stamps (100 MHz, device-wide) per workgroup, written by wave 0
     // K split over kGemmKsp workgroups per output tile (the K = 4096 projection at M <= 16 rows, where one workgroup per tile
     // leaves 3/4 of the CUs idle): every workgroup runs 16 / kGemmKsp of the 16 K-slices (each slice = the MFMA chain of one wave
     // of the unsplit kernel, bit for bit), publishes its per-wave partial tiles in ksp_buf, takes a ticket on ksp_cnt[tile], and
@@ -84,6 +80,18 @@ struct GemmRowsArgs {
     // the epilogue.  Both null = unsplit.
     float* ksp_buf;      // [tiles][16][256] floats
     unsigned* ksp_cnt;   // [tiles], zero before the first launch (the last arriver resets its counter)
+};
+// The kernel-side remainder of GemmRowsArgs: what the kernel needs only after its first tile loads are in flight (the leading
+// scalar kernel arguments -- Wt, X, M, N, xmt, omt, bias, ln_c1, out -- are preloaded into SGPRs, gemm_rows_kernel.inc).
+struct GemmRowsTail {
+    const float2* stats_in;
+    float2* stats_out;
+    const int* row_meta;
+    void* kv_layer;
+    float* ksp_buf;
+    unsigned* ksp_cnt;
+    float eps;
+    int ldo, kv_half, gelu_erf;
 };
 constexpr int kGemmKsp = 4;
 constexpr int kGemmKspTiles = 256;   // output tiles the scratch is sized for: ksp_buf = kGemmKspTiles * 16 * 256 floats, ksp_cnt = kGemmKspTiles
@@ -137,11 +145,11 @@ void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, 
                          const int* row_slot, const int* row_pos, const int* slot_kvpos,
                          const int* block_tables, int max_blocks, int M, hipStream_t st, bool kv_half = false);
 
-// causal attention of every row against its sequence's paged K/V (keys 0..pos), 16 heads x 64
+// decode rows: causal attention of every row against its sequence's paged K/V (keys 0..pos), 16 heads x 64.  The row's position
+// and block table come from the step's dense row_meta table (embed_decode_kernel), max_blocks = entries per row.
 // out_mtt > 0: `out` is written as packed rows with that many 16-row tiles (decode chain, A operand of the proj GEMM)
-void launch_paged_attention(const float* qbuf, const void* kv_layer, const int* row_slot, const int* row_pos,
-                            const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
-                            hipStream_t st, int out_mtt = 0, bool kv_half = false, const int* row_meta = nullptr);
+void launch_paged_attention(const float* qbuf, const void* kv_layer, const int* row_meta, int max_blocks, float* out, int M,
+                            hipStream_t st, int out_mtt = 0, bool kv_half = false);
 
 // prompt rows (explicit positions, row-major output): exact-f32 MFMA score / PV tiles over query blocks of up to 32 consecutive
 // rows of one sequence, qblk[i] = {first row, rows} (row_pos ascends by one inside a block)
@@ -156,7 +164,7 @@ void launch_embed_prompt(const int4* desc, const float* spk_cond, const float* t
 // row_meta (optional, [M][kRowMetaStride] ints): the step's per-row K/V addressing, gathered once per step for the 30
 // attention launches and QKV epilogues: [0] = K/V position of the new token (slot_kvpos), [1] = slot,
 // [kRowMetaWblk] = the block that position falls in (where the QKV epilogue writes K/V), [kRowMetaBt ..] = the slot's block table.
-constexpr int kRowMetaStride = 80, kRowMetaBt = 8, kRowMetaWblk = 2;
+constexpr int kRowMetaStride = 96, kRowMetaBt = 8, kRowMetaWblk = 2;   // (66 table entries + the attention kernel's look-ahead)
 void launch_embed_decode(const int* row_slot, const int* slot_tok, const int* slot_pos, const float* wte,
                          const float* wpe, float* h, int M, hipStream_t st, int h_mtt = 0, float2* stats = nullptr,
                          int* row_meta = nullptr, const int* slot_kvpos = nullptr, const int* block_tables = nullptr,
@@ -170,6 +178,9 @@ void launch_final_norm(const float* xn, const int* sample_row, const int* sample
 
 void launch_double_norm_rows(const float* src, float* dst, int n, const float* gamma, const float* beta, float eps,
                              hipStream_t st);
+
+// test support: *cnt += number of 32-bit words in which x and y differ
+void launch_count_mismatch(const void* x, const void* y, long n_words, unsigned long long* cnt, hipStream_t st);
 
 constexpr int kTokFinishedBit = 1 << 30;
 struct SamplerArgs {

@@ -538,299 +538,6 @@ __device__ __forceinline__ float load_sc1(const float* p) {
     asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
-template <int MT, int KCH, bool LN, int EPI, int NW, int NTL = 1, int PREC = 0, bool NT = false, int KSP = 1>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, NW == 16 ? 4 : (NW == 8 ? 6 : (KSP > 1 ? 2 : 8)))))
-void gemm_rows_kernel(GemmRowsArgs a) {
-    // (amdgpu_waves_per_eu: without the cap hipcc schedules for 8 waves per SIMD — 64 VGPRs — and gets there by issuing the tile
-    // loads two at a time between the MFMAs: 5-7 dependent memory round trips per launch instead of one.  A 16-wave workgroup
-    // occupies 4 waves per SIMD anyway.)
-    // NTL = 16-column tiles per workgroup (each wave keeps MT x NTL accumulator tiles): the activation rows a CU pulls through
-    // its L1 are shared by NTL column tiles; the K order of every output element is the same for every NTL (bitwise equal)
-    static_assert(!LN || KCH == 1, "LN prologue needs the whole row in one chunk");
-    static_assert(NW == 4 || NW == 8 || NW == 16, "waves per workgroup");
-    static_assert(KSP == 1 || (!LN && MT == 1 && NTL == 1 && NW * KSP == 16), "K split: 16 slices, one 16 x 16 tile, no LayerNorm fold");
-    constexpr int NB = 64 / (NW * KSP);   // 16-deep K blocks per wave per 1024-deep chunk
-    __shared__ __attribute__((aligned(16))) float red[NW][MT * NTL * 256];
-    __shared__ float rs[LN ? 16 * MT : 1][2];   // (mean, rstd) of the workgroup's rows
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wg = KSP > 1 ? (int)blockIdx.y * NW + w : w;   // this wave's K-slice among the NW * KSP slices
-    const int j = lane & 15, q = lane >> 4;
-    // workgroup -> (column tile, row group): the row groups of one column tile get ids 8 apart (same XCD, adjacent in
-    // dispatch order) so that the tile's weights leave HBM once and the other groups hit them in that XCD's L2
-    const int n_tiles = a.N / (16 * NTL), n_grp = (a.M + 16 * MT - 1) / (16 * MT);
-    int ntile, mgrp;
-    const int L = blockIdx.x;
-    {
-        // (the grid is padded to a multiple of 8 column tiles: the mel head has 68, and with the plain order its four row
-        // groups landed on four XCDs and pulled the weights from HBM four times: PMC 18.7 MB per launch for 4.5 MB of weights)
-        const int xcd = L & 7, slot = L >> 3;
-        mgrp = slot % n_grp;
-        ntile = (slot / n_grp) * 8 + xcd;
-        if (ntile >= n_tiles) return;
-    }
-    const int n0 = ntile * 16 * NTL, m0 = mgrp * 16 * MT;
-    const long wt_tile = (long)(a.K >> 4) * 64;   // float4s of one packed 16-column tile
-    const f32x4* wt = reinterpret_cast<const f32x4*>(a.Wt) + (long)ntile * NTL * wt_tile + lane;
-    // packed rows: the float4 of lane `lane` for (16-row tile t, K block kb) is at ((kb * xmt + t) * 64 + lane); rows >= M of
-    // the last tiles are allocated but undefined: their products stay in their own (never stored) output rows
-    const f32x4* xp = reinterpret_cast<const f32x4*>(a.X) + (long)(mgrp * MT) * 64 + lane;
-    // K = 4096: two chunk buffers (the loads run one 1024-deep chunk ahead of the MFMAs).  Three buffers measured slower
-    // (13.6 vs 12.3 us at M = 64).
-    constexpr int NBUF = (KCH > 1) ? 2 : 1;
-    f32x4 bf[NBUF][NTL][NB], af[NBUF][MT][NB];
-    // loads in K-block order (for PREC 1 in pairs of blocks): the MFMAs of block b need exactly the first (b + 1) / NB of the
-    // chunk's loads, and loads return in order
-    auto load_chunk = [&](int c, int buf) {
-        const int kb0 = c * 64 + NB * wg;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-#pragma unroll
-            for (int t = 0; t < NTL; ++t) {
-                if constexpr (NT) bf[buf][t][b] = __builtin_nontemporal_load(&wt[t * wt_tile + (long)(kb0 + b) * 64]);
-                else bf[buf][t][b] = wt[t * wt_tile + (long)(kb0 + b) * 64];
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) af[buf][mt][b] = xp[((long)(kb0 + b) * a.xmt + mt) * 64];
-            if (PREC == 0 || (b & 1)) __builtin_amdgcn_sched_barrier(0);   // (hipcc reorders the loads among themselves otherwise)
-        }
-        // nothing below may move above this line and no load above may sink below it (hipcc otherwise sinks the tile loads
-        // under the LayerNorm barrier and next to their first use)
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 0] = (long long)wall_clock64();
-    f32x4 acc[MT][NTL], lo[PREC ? MT : 1][PREC ? NTL : 1];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int t = 0; t < NTL; ++t) {
-            acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (PREC) lo[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    // Epilogue inputs first of all: one output element per thread (e = tid), so its bias, residual value and K/V write
-    // position are known now.  Loaded here they arrive with the operands instead of costing one to three dependent memory
-    // round trips after the reduction (loads return in order: these are the oldest).
-    constexpr int NE = MT * NTL * 256;
-    static_assert(NE <= 64 * NW, "one output element per thread");
-    const int e = min(tid, NE - 1);
-    const int ect = (e >> 8) / MT, emt = (e >> 8) - ect * MT;
-    const int em = m0 + 16 * emt + 4 * ((e & 63) >> 4) + ((e >> 6) & 3), en = n0 + 16 * ect + (e & 15);
-    float ebias = 0.f, ec1 = 0.f;
-    if (a.bias) ebias = a.bias[en];   // (a pointer select here compiles to a FLAT load, after which every wait is vmcnt(0))
-    if (LN) ec1 = a.ln_c1[en];
-    float* eptr = nullptr;
-    float eres = 0.f;
-    if (EPI == kEpiResidual) {
-        eptr = a.out + pk_off(em, en, a.omt);
-        eres = *eptr;
-    }
-    int epos = 0, eblk = 0;
-    if (EPI == kEpiQkv) {
-        if (a.row_meta) {
-            epos = a.row_meta[(long)em * kRowMetaStride];
-            eblk = a.row_meta[(long)em * kRowMetaStride + kRowMetaWblk];
-        }
-    }
-    // LayerNorm is folded into the weights (launch_fold_ln): the MFMAs run on the raw rows, nothing in front of them waits
-    // for the statistics or for the other waves, and the epilogue applies  y = rstd * (x W' - mean * c1) + c2.  The partials
-    // of the rows this wave will combine (rows w, w + NW, ...; lane t holds column tile t) are requested first.
-    constexpr int RPW = LN ? (16 * MT + NW - 1) / NW : 1;   // rows per wave
-    float2 pt[RPW];
-    if (LN) {
-#pragma unroll
-        for (int u = 0; u < RPW; ++u) pt[u] = a.stats_in[(long)(m0 + min(w + NW * u, 16 * MT - 1)) * 64 + lane];
-    }
-    load_chunk(0, 0);
-    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 1] = (long long)wall_clock64();
-    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 2] = (long long)wall_clock64();
-#pragma unroll
-    for (int c = 0; c < KCH; ++c) {
-        const int cur = c % NBUF;
-        // (NBUF == 1: chunk 0 is already in flight; round 2 re-issued it here, which made the loads above dead and put the
-        // real ones behind the LayerNorm barrier: one extra memory round trip per LN launch)
-        if (NBUF > 1 && c + NBUF - 1 < KCH) load_chunk(c + NBUF - 1, (c + NBUF - 1) % NBUF);
-        if (!LN) __builtin_amdgcn_sched_barrier(0);   // the next chunks' loads are issued before this chunk's MFMAs
-#pragma unroll
-        for (int b = 0; b < NB; b += (PREC ? 2 : 1)) {
-            if constexpr (PREC == 0) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int t = 0; t < NTL; ++t)
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][mt][b][s], bf[cur][t][b][s], acc[mt][t], 0, 0, 0);
-            } else {
-                bf16x8 ah[MT], am[MT], al[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) split3_bf16(af[cur][mt][b], af[cur][mt][b + 1], ah[mt], am[mt], al[mt]);
-#pragma unroll
-                for (int t = 0; t < NTL; ++t) {
-                    bf16x8 bh, bm, bl;
-                    split3_bf16(bf[cur][t][b], bf[cur][t][b + 1], bh, bm, bl);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        lo[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl, lo[mt][t], 0, 0, 0);
-                        lo[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh, lo[mt][t], 0, 0, 0);
-                        lo[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[mt], bm, lo[mt][t], 0, 0, 0);
-                        lo[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bm, lo[mt][t], 0, 0, 0);
-                        lo[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[mt], bh, lo[mt][t], 0, 0, 0);
-                        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh, acc[mt][t], 0, 0, 0);
-                    }
-                }
-            }
-            // keep the blocks in load order: hipcc otherwise hoists the LayerNorm arithmetic of every block in front of the
-            // first MFMA, which then waits for (almost) the whole tile
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if (LN) {   // Chan's combination of the 64 tile partials of a row, fixed order (one DPP wave reduction each)
-#pragma unroll
-        for (int u = 0; u < RPW; ++u) {
-            const int rr = w + NW * u;
-            const float mu = wave_sum_dpp(pt[u].x) * (1.0f / 64.0f);
-            const float d = pt[u].x - mu;
-            const float m2 = wave_sum_dpp(fmaf(16.0f * d, d, pt[u].y));
-            if (lane == 0 && rr < 16 * MT) {
-                rs[rr][0] = mu;
-                rs[rr][1] = 1.0f / sqrtf(m2 * (1.0f / 1024.0f) + a.eps);
-            }
-        }
-    }
-    // D layout: row = 4*(lane>>4) + r, col = lane&15
-#pragma unroll
-    for (int t = 0; t < NTL; ++t)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                red[w][(t * MT + mt) * 256 + r * 64 + lane] = PREC ? acc[mt][t][r] + lo[mt][t][r] : acc[mt][t][r];
-    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 3] = (long long)wall_clock64();
-    __syncthreads();
-    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 4] = (long long)wall_clock64();
-    if constexpr (KSP > 1) {
-        // publish this workgroup's NW partial tiles (thread e: element e of every one of them), take a ticket; only the last
-        // arriver goes on.  red[] is reused for the ticket: every wave has read its elements before the barrier below.
-        const int tile = mgrp * n_tiles + ntile;
-        float* pb = a.ksp_buf + ((long)tile * 16 + (long)blockIdx.y * NW) * 256;
-        {
-            const int ww = tid >> 6, l4 = (tid & 63) * 4;   // one float4 (elements l4 .. l4 + 3 of partial ww) per thread
-            store_sc1(pb + ww * 256 + l4, *reinterpret_cast<const f32x4*>(&red[ww][l4]));
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) reinterpret_cast<unsigned*>(&rs[0][0])[0] = __hip_atomic_fetch_add(a.ksp_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (reinterpret_cast<const unsigned*>(&rs[0][0])[0] != KSP - 1) return;
-        if (tid == 0) __hip_atomic_store(a.ksp_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    }
-    if (tid < NE) {
-        float t;
-        if constexpr (KSP > 1) {
-            const float* pa = a.ksp_buf + (long)(mgrp * n_tiles + ntile) * 16 * 256 + e;
-            float pv[16];
-#pragma unroll
-            for (int ww = 0; ww < 16; ++ww) pv[ww] = load_sc1(pa + ww * 256);
-            // (the loads are asm: the wait must name their destinations, or the sums below may be scheduled in front of it)
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]), "+v"(pv[7]), "+v"(pv[8]),
-                           "+v"(pv[9]), "+v"(pv[10]), "+v"(pv[11]), "+v"(pv[12]), "+v"(pv[13]), "+v"(pv[14]), "+v"(pv[15])
-                         :
-                         : "memory");
-            t = pv[0];
-#pragma unroll
-            for (int ww = 1; ww < 16; ++ww) t += pv[ww];
-        } else {
-            t = red[0][e];
-#pragma unroll
-            for (int ww = 1; ww < NW; ++ww) t += red[ww][e];
-        }
-        const bool ok = em < a.M;
-        if (LN) t = rs[em - m0][1] * (t - rs[em - m0][0] * ec1);
-        t += ebias;
-        if (EPI == kEpiBias) {
-            if (ok) a.out[(long)em * a.ldo + en] = t;
-        } else if (EPI == kEpiBiasGelu) {
-            if (ok) a.out[pk_off(em, en, a.omt)] = a.gelu_erf ? gelu_erf(t) : gelu_new(t);
-        } else if (EPI == kEpiResidual) {
-            const float v = eres + t;
-            if (ok) *eptr = v;   // (rows >= M of the last tile are allocated)
-            if (a.stats_out) {   // LayerNorm partials of this 16-column tile: the 16 lanes of a row are adjacent
-                float sm = v;
-                sm += __shfl_xor(sm, 8, 64);
-                sm += __shfl_xor(sm, 4, 64);
-                sm += __shfl_xor(sm, 2, 64);
-                sm += __shfl_xor(sm, 1, 64);
-                const float mu = sm * (1.0f / 16.0f);
-                const float d = v - mu;
-                float m2 = d * d;
-                m2 += __shfl_xor(m2, 8, 64);
-                m2 += __shfl_xor(m2, 4, 64);
-                m2 += __shfl_xor(m2, 2, 64);
-                m2 += __shfl_xor(m2, 1, 64);
-                if (ok && (e & 15) == 0) a.stats_out[(long)em * 64 + ntile * NTL + ect] = make_float2(mu, m2);
-            }
-        } else if (ok) {
-            const int u = en / kHidden, d = en - u * kHidden;
-            if (u == 0) {
-                a.out[(long)em * kHidden + d] = t;
-            } else {
-                int pos = epos, blk = eblk;
-                if (!a.row_meta) {
-                    const int slot = a.row_slot[em];
-                    pos = a.slot_kvpos[slot];
-                    blk = a.block_tables[(long)slot * a.max_blocks + pos / kKvBlockTokens];
-                }
-                const long off = kv_offset(blk, u - 1, d / kHeadDim, pos % kKvBlockTokens) + d % kHeadDim;
-                if (a.kv_half) reinterpret_cast<_Float16*>(a.kv_layer)[off] = (_Float16)t;
-                else reinterpret_cast<float*>(a.kv_layer)[off] = t;
-            }
-        }
-    }
-    if (a.prof && tid == 0) a.prof[(long)blockIdx.x * 8 + 5] = (long long)wall_clock64();
-}
-
-// Workgroup shapes.  16 waves, K-slice 64 per wave, is what the engine uses; tools/gemm_bench.hip defines AUR_GEMM_ALL_SHAPES and
-// also gets the A/B shapes (8 waves = K-slices of 128, wider tiles).  K = 4096 needs two chunk buffers: at most 32 rows per
-// workgroup.
-template <int KCH, bool LN, int EPI, int PREC, bool NT = false>
-static void launch_gemm_rows_mt(const GemmRowsArgs& a, int mt, int nw, hipStream_t st, int ntl = 1) {
-    const int n_tiles = a.N / (16 * ntl);
-    const int n_grp = (a.M + 16 * mt - 1) / (16 * mt);
-    const dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * n_grp));   // whole groups of 8 column tiles (one per XCD); surplus workgroups exit
-    AUR_REQUIRE(a.N % (16 * ntl) == 0, "gemm_rows: N is not a multiple of the workgroup's column tile");
-#define AUR_GR(MT_, NW_, NTL_)                                                                                     \
-    if (mt == MT_ && nw == NW_ && ntl == NTL_) {                                                                   \
-        hipLaunchKernelGGL((gemm_rows_kernel<MT_, KCH, LN, EPI, NW_, NTL_, PREC, NT>), grid, dim3(64 * NW_), 0, st, a); \
-        return;                                                                                                    \
-    }
-    AUR_GR(1, 16, 1)
-    if constexpr (!NT) {
-        if constexpr (KCH == 1 && LN) {
-            AUR_GR(1, 16, 2)
-            AUR_GR(1, 16, 3)
-            AUR_GR(2, 16, 2)
-        }
-#ifdef AUR_GEMM_ALL_SHAPES
-        AUR_GR(2, 16, 1)
-        if constexpr (KCH == 1) {
-            AUR_GR(4, 16, 1)
-            AUR_GR(1, 16, 4)
-            if constexpr (!LN) {
-                AUR_GR(1, 16, 2)
-                AUR_GR(1, 16, 3)
-                AUR_GR(2, 16, 2)
-            }
-            AUR_GR(1, 8, 1)
-            AUR_GR(2, 8, 1)
-            AUR_GR(1, 8, 2)
-        }
-#endif
-    }
-#undef AUR_GR
-    throw InvalidArgument("gemm_rows: no kernel for this (rows, waves, column tiles) workgroup shape");
-}
-
 // Shape policy.  The waves per workgroup fix the K grouping of the reduction, so they depend on the GEMM kind only (16
 // everywhere; the K-split form runs the same 16 slices in 4 workgroups), never on M: a row's result must not change with the
 // number of live rows.  Rows x columns per workgroup do not enter the arithmetic (the K order of an output element is the same for
@@ -861,55 +568,13 @@ GemmRowsShape gemm_rows_shape(int M, int N, int K, bool ln) {
     return s;
 }
 
-// K = 4096, K split over kGemmKsp workgroups of 4 waves per 16 x 16 output tile (M <= 16 rows)
-template <int PREC>
-static void launch_gemm_rows_ksp(const GemmRowsArgs& a, GemmRowsEpi epi, hipStream_t st) {
-    static_assert(kGemmKsp == 4, "16 K-slices = 4 workgroups of 4 waves");
-    AUR_REQUIRE(a.K == 4096 && a.N % 16 == 0 && a.ksp_buf && a.ksp_cnt, "gemm_rows K split: K == 4096 and the partial-tile scratch");
-    const int n_tiles = a.N / 16, n_grp = (a.M + 15) / 16;
-    const dim3 grid((unsigned)((n_tiles + 7) / 8 * 8 * n_grp), kGemmKsp);
-    if (epi == kEpiResidual) hipLaunchKernelGGL((gemm_rows_kernel<1, 4, false, kEpiResidual, 4, 1, PREC, true, kGemmKsp>), grid, dim3(256), 0, st, a);
-    else if (epi == kEpiBias) hipLaunchKernelGGL((gemm_rows_kernel<1, 4, false, kEpiBias, 4, 1, PREC, true, kGemmKsp>), grid, dim3(256), 0, st, a);
-    else throw InvalidArgument("gemm_rows K split: bias or residual epilogue");
-}
-
-template <int PREC, bool NT>
-static void launch_gemm_rows_prec(const GemmRowsArgs& b, bool ln, GemmRowsEpi epi, const GemmRowsShape& s, hipStream_t st) {
-    if (ln && epi == kEpiQkv) launch_gemm_rows_mt<1, true, kEpiQkv, PREC, NT>(b, s.mt, s.nw, st, s.ntl);
-    else if (ln && epi == kEpiBiasGelu) launch_gemm_rows_mt<1, true, kEpiBiasGelu, PREC, NT>(b, s.mt, s.nw, st, s.ntl);
-    else if (ln && epi == kEpiBias) launch_gemm_rows_mt<1, true, kEpiBias, PREC, NT>(b, s.mt, s.nw, st, s.ntl);
-    else if (!ln && epi == kEpiResidual && b.K == 1024) launch_gemm_rows_mt<1, false, kEpiResidual, PREC, NT>(b, s.mt, s.nw, st, s.ntl);
-    else if (!ln && epi == kEpiResidual && b.K == 4096) launch_gemm_rows_mt<4, false, kEpiResidual, PREC, NT>(b, s.mt, s.nw, st, s.ntl);
-    else if (!ln && epi == kEpiBias && b.K == 1024) launch_gemm_rows_mt<1, false, kEpiBias, PREC, NT>(b, s.mt, s.nw, st, s.ntl);
-    else if (!ln && epi == kEpiBias && b.K == 4096) launch_gemm_rows_mt<4, false, kEpiBias, PREC, NT>(b, s.mt, s.nw, st, s.ntl);
-    else throw InvalidArgument("launch_gemm_rows: unsupported (ln, epilogue, K) combination");
-}
-
-void launch_gemm_rows(const GemmRowsArgs& a, bool ln, GemmRowsEpi epi, hipStream_t st) {
-    AUR_REQUIRE(a.N % 16 == 0 && (a.K == 1024 || a.K == 4096) && a.M >= 1 && a.xmt >= 4 * ((a.M + 63) / 64), "gemm_rows: shape");
-    AUR_REQUIRE((epi != kEpiBiasGelu && epi != kEpiResidual) || a.omt >= (a.M + 15) / 16, "gemm_rows: packed output rows");
-    AUR_REQUIRE(!ln || (a.K == 1024 && a.stats_in && a.ln_c1 && a.bias), "gemm_rows: a LayerNorm-folded GEMM needs K == 1024, the row statistics, c1 and c2");
-    AUR_REQUIRE(!a.stats_out || (epi == kEpiResidual && a.N == 1024), "gemm_rows: statistics are emitted for 1024-wide residual rows");
-    GemmRowsShape s = gemm_rows_shape(a.M, a.N, a.K, ln);
-    trace_launch("gemm_rows_kernel");
-    AUR_REQUIRE(a.prec == 0 || a.prec == 1, "gemm_rows: prec is 0 (exact f32 MFMA) or 1 (bf16 x 3 split)");
-    if (s.ksp > 1 && !(a.ksp_buf && a.ksp_cnt)) s = GemmRowsShape{1, 16, 1, a.M <= 16, 1};   // no scratch given: the unsplit kernel (same bits)
-    if (s.ksp > 1) {
-        AUR_REQUIRE((long)((a.M + 15) / 16) * (a.N / 16) <= kGemmKspTiles, "gemm_rows K split: more output tiles than the scratch holds");
-        if (a.prec == 1) launch_gemm_rows_ksp<1>(a, epi, st);
-        else launch_gemm_rows_ksp<0>(a, epi, st);
-        HIP_CHECK(hipGetLastError());
-        return;
-    }
-    if (a.prec == 1) {
-        if (s.nt) launch_gemm_rows_prec<1, true>(a, ln, epi, s, st);
-        else launch_gemm_rows_prec<1, false>(a, ln, epi, s, st);
-    } else {
-        if (s.nt) launch_gemm_rows_prec<0, true>(a, ln, epi, s, st);
-        else launch_gemm_rows_prec<0, false>(a, ln, epi, s, st);
-    }
-    HIP_CHECK(hipGetLastError());
-}
+#define AUR_GR_NAME gemm_rows_kernel
+#define AUR_GR_LAUNCH launch_gemm_rows
+#define AUR_GR_NO_DATA 0
+#include "gemm_rows_kernel.inc"
+#undef AUR_GR_NAME
+#undef AUR_GR_LAUNCH
+#undef AUR_GR_NO_DATA
 
 // ------------------------------------------------------------------------------------------------
 // residual + LayerNorm rows (one wave per 1024-wide row; statistics via wavefront shuffles)
@@ -1017,13 +682,19 @@ void launch_qkv_epilogue(const float* P, int S, const float* bias, float* qbuf, 
 // Paged causal attention: one workgroup per (row, head).  16 lanes x float4 (fp32 pool) or 8 lanes x 8 halves (fp16 pool) span
 // the 64-wide head, so one wave instruction covers 4 / 8 consecutive cached tokens (1 KiB contiguous); 4 waves stride the
 // context.  Scores are reduced with wavefront shuffles; online softmax per lane group; groups merged through LDS.
-constexpr int kAttnMaxBlocks = 128;   // block-table entries of a row staged in LDS (the engine's table has 66)
+//
+// What stands between the launch and the first K/V request (round 5).  Until round 4: two dependent kernel-argument fetches, the
+// row's position (scalar load), its block table (vector load -> vmcnt(0) -> ds_write -> s_barrier), one more argument fetch, then
+// the first K/V addresses -- six scalar waits, a vector round trip and a barrier.  Now: the arguments are preloaded SGPRs (10
+// dwords, -amdgpu-kernarg-preload-count), and ONE scalar round trip fetches the row's position, its write block and the block ids
+// of the first 64 (128) tokens together, next to the q load.  The block ids of a token step are WAVE-UNIFORM -- a step of the
+// workgroup covers 16 (32) consecutive tokens starting at a multiple of 16 -- so they are scalar loads out of the row's dense table
+// (row_meta, written once per decode step by embed_decode_kernel) into SGPRs, requested one iteration ahead: no LDS copy of the
+// table, no barrier in front of the loop.  A lane past the end of the context reads the row's last token (position `pos`, block
+// row_meta[kRowMetaWblk]) as before.  Same K/V rows in the same order into the same arithmetic: bitwise equal to round 4.
 template <bool KVH>
-__global__ __launch_bounds__(256) void paged_attention_kernel(const float* __restrict__ qbuf, const void* __restrict__ kv_layer_v,
-                                                              const int* __restrict__ row_slot, const int* __restrict__ row_pos,
-                                                              const int* __restrict__ slot_kvpos,
-                                                              const int* __restrict__ block_tables, int max_blocks,
-                                                              float* __restrict__ out, int out_mtt, const int* __restrict__ row_meta) {
+__global__ __launch_bounds__(256) void paged_attention_kernel(const int* __restrict__ row_meta, const float* __restrict__ qbuf,
+                                                              const void* __restrict__ kv_layer_v, float* __restrict__ out, int out_mtt) {
     // (16 token steps in flight for M <= 16 rows -- one loop iteration per 256 tokens: at one row 8.2 vs 9.0 us at 244 tokens, but
     // 6.3 vs 4.9 at 64 and 12.5 vs 12.2 at 384, profiles/r04_gemm_bench_attention.log.  The launch is 3.5 us + 1.5 us per 64 tokens: one
     // CU per (row, head) pulls its K/V at 21-25 KB/us whatever the unroll.  Not kept.)
@@ -1032,27 +703,25 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
     constexpr int EPL = kHeadDim / LPT;      // elements per lane
     constexpr int TPW = 64 / LPT;            // tokens per wave instruction
     constexpr int NP = 4 * TPW;              // partial (m, l, o) groups per workgroup
+    constexpr int STEP = 4 * TPW * UN;       // tokens per workgroup iteration
+    constexpr int NBI = STEP / kKvBlockTokens;   // K/V blocks per workgroup iteration (4 / 8)
     using KT = typename std::conditional<KVH, _Float16, float>::type;
     __shared__ float part_o[NP][kHeadDim];
     __shared__ float part_m[NP], part_l[NP];
     const int m = blockIdx.x, head = blockIdx.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane / LPT, dl = lane % LPT;
-    int pos;
-    const int* bt;
-    if (row_meta) {   // dense per-row copy made once per decode step: one round trip instead of three dependent ones
-        pos = row_meta[(long)m * kRowMetaStride];
-        bt = row_meta + (long)m * kRowMetaStride + kRowMetaBt;
-    } else {
-        const int slot = row_slot[m];
-        pos = row_pos ? row_pos[m] : slot_kvpos[slot];
-        bt = block_tables + (long)slot * max_blocks;
-    }
-    // The row's block table goes to LDS once (issued together with `pos`, it does not depend on it): a token step then costs ONE
-    // dependent memory round trip (its K/V rows) instead of two (table entry, then rows), and the first K/V loads sit two trips
-    // behind the launch instead of three.  Same loads of the same rows in the same order as before: bitwise equal.
-    __shared__ int bt_s[kAttnMaxBlocks];
-    if ((int)threadIdx.x < max_blocks) bt_s[threadIdx.x] = bt[threadIdx.x];   // max_blocks <= kAttnMaxBlocks <= 256 (launcher)
+    const int* rm = row_meta + (long)m * kRowMetaStride;   // uniform: everything read through it is a scalar load
+    int ids[NBI];
+    // (contiguous, unclamped: the row's table is padded -- kRowMetaStride -- so that the ids of the iteration behind the last one are
+    // still inside the row; entries past the sequence's blocks are never used, the lanes they would serve are past `pos`)
+    auto load_ids = [&](int t0) {
+        const int* p = rm + kRowMetaBt + t0 / kKvBlockTokens;
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) ids[i] = p[i];
+    };
+    const int pos = rm[0], wblk = rm[kRowMetaWblk];
+    load_ids(0);
     float qv[EPL];
     {
         const float* qp = qbuf + (long)m * kHidden + head * kHeadDim + dl * EPL;
@@ -1063,7 +732,6 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
             for (int c = 0; c < 4; ++c) qv[4 * c4 + c] = q4[c];
         }
     }
-    __syncthreads();
     const int n_keys = pos + 1;
     const KT* kv_layer = reinterpret_cast<const KT*>(kv_layer_v);
 
@@ -1077,25 +745,38 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
         for (int u = 0; u < UN; ++u) {
             // (clamped to the context, not to the table: making the address independent of the row's position -- one dependent load
             // less in front of the first K/V loads -- made the masked lanes fetch real, distinct rows: 24.2 vs 22.6 us per launch)
-            const int t = min(t0 + 4 * TPW * u + wv * TPW + g, n_keys - 1);
-            const int blk = bt_s[t / kKvBlockTokens];
-            const long off = kv_offset(blk, 0, head, t % kKvBlockTokens) + dl * EPL;
+            const int traw = t0 + 4 * TPW * u + wv * TPW + g;
+            // block of this step inside the iteration: (4 TPW u + TPW wv) / 16 -- u for the fp32 pool, 2 u + (wv >> 1) for fp16
+            const int blk_u = KVH ? ((wv >> 1) ? ids[(2 * u + 1) % NBI] : ids[(2 * u) % NBI]) : ids[u % NBI];
+            const bool past = traw > pos;
+            const int blk = past ? wblk : blk_u;
+            const int tok = (past ? pos : traw) % kKvBlockTokens;
+            const long off = kv_offset(blk, 0, head, tok) + dl * EPL;
             kraw[u] = *reinterpret_cast<const RawT*>(kv_layer + off);
             vraw[u] = *reinterpret_cast<const RawT*>(kv_layer + off + (long)kHeads * kKvBlockTokens * kHeadDim);
         }
+        __builtin_amdgcn_sched_barrier(0);   // all 2 * UN requests leave before the first score (hipcc otherwise starts step 0's arithmetic, and its wait, in front of the last loads)
     };
     load_kv(0);
+    load_ids(STEP);   // one iteration ahead: the scalar round trip of iteration i + 1 runs under the K/V loads of iteration i
     float mi = -INFINITY, li = 0.f;
     float o[EPL];
 #pragma unroll
     for (int c = 0; c < EPL; ++c) o[c] = 0.f;
-    constexpr int STEP = 4 * TPW * UN;   // tokens per workgroup iteration
-    for (int t0 = 0; t0 < n_keys; t0 += STEP) {
-        if (t0 > 0) load_kv(t0);
+    int t0 = 0;
+    do {   // (n_keys >= 1: a for loop lets hipcc sink the first loads under the loop guard, i.e. behind the round trip for `pos`)
+        if (t0 > 0) {
+            load_kv(t0);
+            load_ids(t0 + STEP);
+        }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int t = t0 + 4 * TPW * u + wv * TPW + g;
             const bool valid = t < n_keys;
+            // (V is used under `valid` only, and hipcc SINKS a load into the one branch that uses it: until round 5 the V load of the
+            // first step of every iteration sat inside the branch, followed by s_waitcnt vmcnt(0) -- one dependent memory round trip
+            // and a drain of the seven other loads per 64 tokens.  Naming the register here keeps the load where it is issued.)
+            asm volatile("" ::"v"(vraw[u]));
             float kx[EPL], vx[EPL];
 #pragma unroll
             for (int c = 0; c < EPL; ++c) {
@@ -1117,7 +798,8 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const float* __res
                 mi = mn;
             }
         }
-    }
+        t0 += STEP;
+    } while (t0 < n_keys);
     const int pidx = wv * TPW + g;
 #pragma unroll
     for (int c = 0; c < EPL; ++c) part_o[pidx][dl * EPL + c] = o[c];
@@ -1294,17 +976,14 @@ void launch_prompt_attention(const float* qbuf, const void* kv_layer, const int2
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_paged_attention(const float* qbuf, const void* kv_layer, const int* row_slot, const int* row_pos,
-                            const int* slot_kvpos, const int* block_tables, int max_blocks, float* out, int M,
-                            hipStream_t st, int out_mtt, bool kv_half, const int* row_meta) {
+void launch_paged_attention(const float* qbuf, const void* kv_layer, const int* row_meta, int max_blocks, float* out, int M,
+                            hipStream_t st, int out_mtt, bool kv_half) {
     trace_launch("paged_attention_kernel");
-    AUR_REQUIRE(max_blocks >= 1 && max_blocks <= kAttnMaxBlocks, "paged attention: block table longer than the kernel's LDS copy");
-    if (kv_half)
-        hipLaunchKernelGGL(paged_attention_kernel<true>, dim3(M, kHeads), dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos,
-                           slot_kvpos, block_tables, max_blocks, out, out_mtt, row_meta);
-    else
-        hipLaunchKernelGGL(paged_attention_kernel<false>, dim3(M, kHeads), dim3(256), 0, st, qbuf, kv_layer, row_slot, row_pos,
-                           slot_kvpos, block_tables, max_blocks, out, out_mtt, row_meta);
+    // the kernel reads block ids one iteration (8 blocks with the fp16 pool) past the last block a sequence can own
+    AUR_REQUIRE(row_meta && max_blocks >= 1 && kRowMetaBt + (max_blocks + 7) / 8 * 8 + 8 <= kRowMetaStride,
+                "paged attention: the step's row_meta table (embed_decode_kernel), padded for the kernel's look-ahead");
+    if (kv_half) hipLaunchKernelGGL(paged_attention_kernel<true>, dim3(M, kHeads), dim3(256), 0, st, row_meta, qbuf, kv_layer, out, out_mtt);
+    else hipLaunchKernelGGL(paged_attention_kernel<false>, dim3(M, kHeads), dim3(256), 0, st, row_meta, qbuf, kv_layer, out, out_mtt);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1598,11 +1277,23 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
     const int tid = threadIdx.x;
     const int slot = a.sample_slot[j];
     const int V = a.V;
-    if (a.slot_finished[slot]) {   // ghost row (engine.hip, pipelined decode): leave every piece of slot state untouched
+    // every per-slot parameter in ONE burst of scalar loads (hipcc sinks each to its first use otherwise: a dependent round trip in
+    // front of the penalty loop, another in front of the temperature division, the top-k search, the top-p scan, the noise ...)
+    const int finished = a.slot_finished[slot];
+    const float pen = a.rep_penalty[slot];
+    const float T = a.temperature[slot];
+    const int topk = a.top_k[slot];
+    const float topp = a.top_p[slot];
+    const unsigned seed = a.seed[slot];
+    const int ngen0 = a.slot_ngen[slot];
+    const int max_tok = a.max_tokens[slot];
+    const int ign_stop = a.ignore_stop[slot];
+    asm volatile("; sampler: slot parameters resident" ::"s"(finished), "s"(pen), "s"(T), "s"(topk), "s"(topp), "s"(seed), "s"(ngen0), "s"(max_tok),
+                 "s"(ign_stop));
+    if (finished) {   // ghost row (engine.hip, pipelined decode): leave every piece of slot state untouched
         if (tid == 0) a.out_tok[j] = -1;
         return;
     }
-    const float pen = a.rep_penalty[slot];
     const unsigned char* seen = a.seen + (long)slot * kSeenStride;
 
     for (int v = tid; v < V; v += 256) {
@@ -1615,7 +1306,6 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
     }
     __syncthreads();
 
-    const float T = a.temperature[slot];
     int tok;
     if (T < 1e-5f) {
         float bv = -INFINITY;
@@ -1629,7 +1319,6 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
     } else {
         for (int v = tid; v < V; v += 256) z[v] = z[v] / T;
         __syncthreads();
-        const int topk = a.top_k[slot];
         // ---- top-k fast path (0 < k <= 64, the XTTS default is 50): the k-th largest value is found by a 32-step
         // bisection on the order-preserving integer image of the logits (one ballot/popcount per element, one barrier
         // per step; a 16-way search with 8 barriers measured slower, 29.7 vs 25.0 us: 15 x 5 ballots per step), the >= threshold survivors (k plus ties) are compacted and sorted by ONE wave, no workgroup
@@ -1645,6 +1334,9 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
                 const int v = (tid & 63) + 64 * u;
                 wvv[u] = (v < V) ? f2ord(z[v] + 0.0f) : 0u;   // (-0 -> +0: equal floats, equal images); 0 sorts below every float
             }
+            // (the search may stop at the first x with EXACTLY k values >= x: the survivor set {v : image(v) >= x} is then the top k, and
+            // everything below uses the threshold only as that mask -- the same survivors, keys and order as the full search, which
+            // goes on to the k-th value's own image; with ties at the k-th value no x has exactly k and all 32 steps run)
             unsigned lo = 0u;
             for (int bit = 31; bit >= 0; --bit) {
                 const unsigned x = lo | (1u << bit);
@@ -1652,6 +1344,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
 #pragma unroll
                 for (int u = 0; u < 17; ++u) c += __popcll(__ballot(wvv[u] >= x));
                 if (c >= topk) lo = x;
+                if (c == topk) break;
             }
             unsigned ov[5];
 #pragma unroll
@@ -1741,20 +1434,50 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
             if (z[v] < thr) z[v] = -INFINITY;
         __syncthreads();
         const float maxv = ord2f((unsigned)(keys[0] >> 32));
-        // top-p on the ascending-sorted softmax: mask cumsum <= 1-p, never the largest
-        const float topp = a.top_p[slot];
-        if (topp < 1.0f && tid == 0) {
-            float sum = 0.f;
-            for (int r = 0; r < n1; ++r) sum += expf(ord2f((unsigned)(keys[r] >> 32)) - maxv);
-            const float lim = 1.0f - topp;
-            double c = 0.0;
-            for (int r = n1 - 1; r >= 1; --r) {
-                const float pr = expf(ord2f((unsigned)(keys[r] >> 32)) - maxv) / sum;
-                c += (double)pr;
-                if ((float)c <= lim)
-                    z[(unsigned)(keys[r] & 0xffffffffull)] = -INFINITY;
-                else
-                    break;
+        // top-p on the ascending-sorted softmax: mask cumsum <= 1-p, never the largest.  The two sums are serial BY DEFINITION (their
+        // bits decide the cut: sum in rank order, cumulative sum in double from the smallest probability up), but their terms are
+        // not: for n1 <= 256 candidates (always on the top-k path) every thread computes its rank's exp and probability, and thread 0
+        // only adds -- until round 5 it evaluated 2 n1 expf and n1 divisions one after the other (~7 us of the kernel's 27).
+        // Same operands into the same additions in the same order: the same bits.
+        if (topp < 1.0f) {
+            if (n1 <= 256) {
+                const float ev = tid < n1 ? expf(ord2f((unsigned)(keys[min(tid, n1 - 1)] >> 32)) - maxv) : 0.f;
+                sv[tid] = ev;
+                __syncthreads();
+                if (tid == 0) {
+                    float sum = 0.f;
+                    for (int r = 0; r < n1; ++r) sum += sv[r];
+                    sh_f[1] = sum;
+                }
+                __syncthreads();
+                const float pr = ev / sh_f[1];
+                __syncthreads();
+                sv[tid] = pr;
+                __syncthreads();
+                if (tid == 0) {
+                    const float lim = 1.0f - topp;
+                    double c = 0.0;
+                    for (int r = n1 - 1; r >= 1; --r) {
+                        c += (double)sv[r];
+                        if ((float)c <= lim)
+                            z[(unsigned)(keys[r] & 0xffffffffull)] = -INFINITY;
+                        else
+                            break;
+                    }
+                }
+            } else if (tid == 0) {
+                float sum = 0.f;
+                for (int r = 0; r < n1; ++r) sum += expf(ord2f((unsigned)(keys[r] >> 32)) - maxv);
+                const float lim = 1.0f - topp;
+                double c = 0.0;
+                for (int r = n1 - 1; r >= 1; --r) {
+                    const float pr = expf(ord2f((unsigned)(keys[r] >> 32)) - maxv) / sum;
+                    c += (double)pr;
+                    if ((float)c <= lim)
+                        z[(unsigned)(keys[r] & 0xffffffffull)] = -INFINITY;
+                    else
+                        break;
+                }
             }
         }
         __syncthreads();
@@ -1762,8 +1485,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
         float part = 0.f;
         for (int v = tid; v < V; v += 256) part += expf(z[v] - maxv);
         const float sum2 = block_sum_tree(part, sv);
-        const unsigned seed = a.seed[slot];
-        const unsigned step = (unsigned)a.slot_ngen[slot];
+        const unsigned step = (unsigned)ngen0;
         float bv = -INFINITY;
         int bi = 0;   // NaN/-inf rows fall back to id 0 instead of indexing out of range
         for (int v = tid; v < V; v += 256) {
@@ -1779,16 +1501,30 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
 
     if (tid == 0) {
         a.seen[(long)slot * kSeenStride + tok] = 1;
-        const int ng = a.slot_ngen[slot] + 1;
+        const int ng = ngen0 + 1;
         a.slot_ngen[slot] = ng;
         a.slot_tok[slot] = tok;
         a.slot_pos[slot] = ng;   // k-th generated token enters at mel position k (vllm_mm_gpt.py:480)
         a.slot_kvpos[slot] = a.next_kvpos ? a.next_kvpos[j] : a.slot_kvpos[slot] + 1;
-        const bool stop = (tok == a.stop_token) && !a.ignore_stop[slot];
-        const bool fin = stop || ng >= a.max_tokens[slot];
+        const bool stop = (tok == a.stop_token) && !ign_stop;
+        const bool fin = stop || ng >= max_tok;
         if (fin) a.slot_finished[slot] = 1;
         a.out_tok[j] = tok | (fin ? kTokFinishedBit : 0);   // one read-back word per row: the token and "this was the last one"
     }
+}
+
+// test support: number of 32-bit words in which two buffers differ (bitwise), accumulated into *cnt
+__global__ __launch_bounds__(256) void count_mismatch_kernel(const unsigned* __restrict__ x, const unsigned* __restrict__ y, long n,
+                                                             unsigned long long* __restrict__ cnt) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool bad = i < n && x[i] != y[i];
+    const unsigned long long m = __ballot(bad);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(cnt, (unsigned long long)__popcll(m));
+}
+void launch_count_mismatch(const void* x, const void* y, long n_words, unsigned long long* cnt, hipStream_t st) {
+    hipLaunchKernelGGL(count_mismatch_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const unsigned*>(x),
+                       reinterpret_cast<const unsigned*>(y), n_words, cnt);
+    HIP_CHECK(hipGetLastError());
 }
 
 void launch_sampler(const SamplerArgs& a, hipStream_t st) {

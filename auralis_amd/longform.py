@@ -172,7 +172,10 @@ def stream_sharded(tts, requests: Sequence[TTSRequest], window: Optional[int] = 
         except BaseException as e:                                 # tell dst instead of leaving it in recv forever
             # ... unless the failure IS the channel (a send that raised: peer gone, communicator aborted): a second blocking send
             # on it would hang where the first one failed
-            if not isinstance(e, (dist.DistBackendError, dist.DistNetworkError, ConnectionError, BrokenPipeError)):
+            # (the torch.distributed error classes are looked up defensively: on a build without them an AttributeError here would
+            # mask `e` and skip the _ERROR message, which is the hang this handler exists to prevent)
+            channel_errors = tuple(getattr(dist, n) for n in ("DistBackendError", "DistNetworkError") if hasattr(dist, n)) + (ConnectionError, BrokenPipeError)
+            if not isinstance(e, channel_errors):
                 msg = f"rank {rank}: {type(e).__name__}: {e}".encode("utf-8", "replace")[:4096]
                 send_hdr(-1, _ERROR, len(msg))
                 dist.send(torch.frombuffer(bytearray(msg), dtype=torch.uint8).to(dev), dst=dst)

@@ -344,7 +344,7 @@ class Bench:
         xe = XTTSv2Engine(eng, XTTSTokenizer(None, vocab_size=self.xtts_sd["text_embedding.weight"].shape[0], synthetic=True),
                           max_concurrency=a.batch)
         tts = TTS(scheduler_max_concurrency=a.batch).with_engine(xe)
-        inflight = tts.scheduler.second_phase_concurrency   # the facade's gate (2 x slots): the engine queues what its slots cannot take
+        inflight = tts.scheduler.second_phase_concurrency   # the facade's gate = slots, as in the reference; the window's other chunks queue inside the engine
         window = window or default_window(tts)              # paragraphs in flight (>= 1 chunk each)
         try:
             eng.reset_stats()
@@ -367,8 +367,8 @@ class Bench:
             eng.load_weights({"mel_head.b": np.asarray(self.packed["mel_head.b"], np.float32)})
         occ = st["decode_rows"] / max(1, st["decode_steps"]) / a.batch
         return {"workload": f"BASELINE configs[4] at 1-GPU scale: {sum(len(p) for p in paras)} chars, {len(paras)} paragraphs en/fr/de "
-                            f"(language=auto), {n_chunks} chunks, natural stop (mel_head.bias[1025] = {STOP_BIAS_C5S}), {window} paragraphs / {inflight} chunk "
-                            f"generations in flight on {a.batch} slots (admit_min_batch {a.admit_min_batch or max(1, a.batch // 8)}), streamed in (paragraph, chunk) order "
+                            f"(language=auto), {n_chunks} chunks, natural stop (mel_head.bias[1025] = {STOP_BIAS_C5S}), {window} paragraphs in flight (every chunk of them submitted; facade gate {inflight}) "
+                            f"on {a.batch} slots (admit_min_batch {a.admit_min_batch or max(1, a.batch // 8)}), streamed in (paragraph, chunk) order "
                             f"through TTS / longform.stream_longform",
                 "chars": sum(len(p) for p in paras), "paragraphs": len(paras), "chunks": n_chunks, "in_order": bool(order_ok),
                 "wall_s": dt, "first_chunk_s": first, "samples": ns, "audio_s": ns / 24000.0, "samples_per_s": ns / dt, "rtf": dt / max(1e-9, ns / 24000.0),

@@ -244,6 +244,10 @@ int aur_dbg_gemm(aur_engine* e, const float* X, const float* W, float* out, int3
  * ln != 0 applies LayerNorm(gamma, beta, eps 1e-5) to the rows of X first (K must be 1024).  K in {1024, 4096}. */
 int aur_dbg_gemm_rows(aur_engine* e, const float* X, const float* W, const float* bias, const float* gamma,
                       const float* beta, float* out, int32_t M, int32_t N, int32_t K, int32_t epi, int32_t ln);
+/* Stress of the decode GEMM's K-split form (the K = 4096 -> 1024 projection at M <= 32 live sequences, same reference linear): `iters`
+ * back-to-back launches on fixed pseudo-random operands, each compared bitwise on the device with the unsplit kernel's result;
+ * *mismatches_out = differing 32-bit words over all launches (0 = the cross-workgroup hand-off held every time). */
+int aur_dbg_gemm_rows_ksplit_stress(aur_engine* e, int32_t M, int32_t iters, int64_t* mismatches_out);
 /* out[M][1024] = LayerNorm(h) rows */
 int aur_dbg_layernorm(aur_engine* e, const float* h, const float* gamma, const float* beta, float* out,
                       int32_t M);

@@ -125,6 +125,14 @@ def test_gemm_rows_is_batch_invariant_bitwise(eng):
             assert np.array_equal(full[:m], part), (K, N, m)
 
 
+@pytest.mark.parametrize("M", [1, 16, 32])
+def test_gemm_rows_ksplit_stress(eng, M):
+    """The K-split projection (four workgroups per output tile, partial tiles handed over through write-through stores, a device
+    ticket and sc0 sc1 loads; the decode path of every step at <= 32 live sequences): 3 000 back-to-back launches, each compared
+    bitwise on the device with the unsplit kernel.  A hand-off that is not visible in time would show as rare differing words."""
+    assert eng.dbg_gemm_rows_ksplit_stress(M, 3000) == 0
+
+
 def test_layernorm(eng):
     g = torch.Generator().manual_seed(0)
     h = torch.randn(37, 1024, generator=g) * 3 + 0.5

@@ -1,0 +1,65 @@
+"""The decode kernels' prologues, checked in the compiled gfx950 code (no GPU needed; hipcc cross-compiles in ~10 s).
+
+Round 4's review found that every decode launch spent its first microseconds on DEPENDENT scalar round trips: hipcc sinks each
+kernel-argument fetch to its first use, so `gemm_rows_kernel` had three to four `s_load -> s_waitcnt lgkmcnt(0)` pairs in front of
+its first weight-tile load and `paged_attention_kernel` six of them, a vector round trip and a barrier in front of its first K/V
+load ("What's weak" 2).  Round 5 orders the arguments for kernarg preloading and fetches the rest in one burst behind
+the first tile loads (gemm_rows_kernel.inc, gpt_kernels.hip); this test keeps it that way."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_skeleton  # noqa: E402
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+
+
+@pytest.fixture(scope="module")
+def asm():
+    return isa_skeleton.compile_to_asm(os.path.join(ROOT, "auralis_amd", "csrc", "gpt_kernels.hip"))
+
+
+def test_build_preloads_kernel_arguments():
+    from auralis_amd.build import FLAGS
+    assert "-amdgpu-kernarg-preload-count=16" in FLAGS
+
+
+def test_gemm_rows_requests_its_first_weight_tile_without_waiting_for_anything(asm):
+    ks = isa_skeleton.kernels(asm, "gemm_rows_kernel")
+    assert len(ks) >= 20, "every (shape, epilogue, arithmetic) instantiation of the decode GEMM"
+    for name, body in ks:
+        p = isa_skeleton.prologue(body)
+        assert p["found_data_load"], name
+        assert p["preload_dwords"] == 14, (name, p)   # Wt, X, M, N, xmt, omt, bias, ln_c1, out
+        # nothing between the entry and the first global_load_dwordx4: no kernel-argument round trip, no wait on the small
+        # epilogue-input loads issued first, no barrier
+        assert p["scalar_waits"] == 0 and p["vector_waits"] == 0 and p["barriers"] == 0, (name, p)
+        assert p["flat_loads"] == 0, (name, "a FLAT load turns every counted wait of the kernel into vmcnt(0)")
+
+
+@pytest.mark.parametrize("kvh,q_loads", [("ILb0E", 1), ("ILb1E", 2)])
+def test_decode_attention_is_one_scalar_round_trip_away_from_its_first_kv_load(asm, kvh, q_loads):
+    ks = isa_skeleton.kernels(asm, "paged_attention_kernel" + kvh)
+    assert len(ks) == 1
+    name, body = ks[0]
+    p = isa_skeleton.prologue(body, skip=q_loads)   # the q row is requested first; look at what precedes the first K/V load
+    assert p["found_data_load"] and p["preload_dwords"] >= 9, p
+    # one trip: the row's position, write block and first block ids, fetched together (scalar loads out of row_meta)
+    assert p["scalar_waits"] <= 1 and p["vector_waits"] == 0 and p["barriers"] == 0, (name, p)
+    assert p["flat_loads"] == 0
+    # all 2 * UN K/V requests of an iteration leave before the first wait on any of them (round 5: hipcc had sunk one V load into
+    # the branch that uses it, behind a vmcnt(0))
+    seq = isa_skeleton.tokens(body)
+    wide = [i for i, t in enumerate(seq) if t == "L4"]
+    first_kv = wide[q_loads]
+    run = 0
+    for t in seq[first_kv:]:
+        if t == "L4":
+            run += 1
+        elif t.startswith("W"):
+            break
+    assert run == 8, (name, run)

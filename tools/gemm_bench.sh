@@ -1,8 +1,17 @@
 #!/bin/bash
-# build + run the decode-GEMM micro-benchmark on the GPU box; output -> gpurun_out/gemm_bench_<tag>.log
+# build + run the decode-kernel micro-benchmark on the GPU box; output -> gpurun_out/gemm_bench_<tag>.log
+# usage: bash tools/gemm_bench.sh <tag> [M ...]
+#   GEMM_BENCH_AB=1 also builds (a) the same sources WITHOUT -amdgpu-kernarg-preload-count and (b) the round-4 kernels kept under
+#   tools/_r04/ (git-ignored copy of HEAD~'s sources, when present) and runs all three for every M
 exec < /dev/null
 TAG=${1:-a}; shift
 mkdir -p gpurun_out
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result tools/gemm_bench.hip -o /tmp/gemm_bench || exit 1
-for M in ${@:-64}; do timeout 120 /tmp/gemm_bench $M; done > gpurun_out/gemm_bench_$TAG.log 2>&1
+CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result"
+$CC -mllvm -amdgpu-kernarg-preload-count=16 tools/gemm_bench.hip -o /tmp/gemm_bench || exit 1
+BINS="/tmp/gemm_bench"
+if [ -n "$GEMM_BENCH_AB" ]; then
+  $CC tools/gemm_bench.hip -o /tmp/gemm_bench_nopreload && BINS="$BINS /tmp/gemm_bench_nopreload"
+  if [ -f tools/_r04/gemm_bench.hip ]; then (cd tools/_r04 && $CC gemm_bench.hip -o /tmp/gemm_bench_r04) && BINS="$BINS /tmp/gemm_bench_r04"; fi
+fi
+for M in ${@:-64}; do for B in $BINS; do echo "=== $B M=$M"; timeout 180 $B $M; done; done > gpurun_out/gemm_bench_$TAG.log 2>&1
 echo "gemm_bench rc=$?"; cat gpurun_out/gemm_bench_$TAG.log
