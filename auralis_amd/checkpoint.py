@@ -218,9 +218,10 @@ def make_synthetic_text_ids(dims: XTTSDims, n_text: int = 70, seed: int = 11):
 
 
 def save_checkpoint(root: str, gpt_sd: Dict[str, Tensor], xtts_sd: Dict[str, Tensor], dims: XTTSDims,
-                    synthetic_tokenizer: bool = False) -> None:
+                    synthetic_tokenizer: bool = False, gpt_max_audio_tokens: Optional[int] = None) -> None:
     """Write the two safetensors + configs.  synthetic_tokenizer=True marks the directory as a seeded synthetic checkpoint
-    whose text ids come from the stand-in vocabulary (api/text.py); a real checkpoint must carry tokenizer.json instead."""
+    whose text ids come from the stand-in vocabulary (api/text.py); a real checkpoint must carry tokenizer.json instead.
+    gpt_max_audio_tokens: the generation length XTTSConfig carries (max_tokens of every request, XTTSv2.py:735; default 605)."""
     from safetensors.torch import save_file
     os.makedirs(os.path.join(root, "gpt"), exist_ok=True)
     os.makedirs(os.path.join(root, "core_xttsv2"), exist_ok=True)
@@ -232,7 +233,8 @@ def save_checkpoint(root: str, gpt_sd: Dict[str, Tensor], xtts_sd: Dict[str, Ten
                    "num_attention_heads": dims.gpt.n_head, "n_inner": dims.gpt.n_inner,
                    "num_audio_tokens": dims.gpt.mel_vocab, "start_audio_token": dims.gpt.start_token,
                    "stop_audio_token": dims.gpt.stop_token, "max_audio_tokens": dims.gpt.max_audio_tokens,
-                   "activation_function": dims.gpt.activation}, f)
+                   "activation_function": dims.gpt.activation,
+                   **({"gpt_max_audio_tokens": int(gpt_max_audio_tokens)} if gpt_max_audio_tokens is not None else {})}, f)
     with open(os.path.join(root, "core_xttsv2", "config.json"), "w") as f:
         json.dump({"model_type": "xtts", "gpt_config": {"num_hidden_layers": n_layer},
                    **({"synthetic_tokenizer": True} if synthetic_tokenizer else {})}, f)

@@ -755,7 +755,9 @@ public:
         // aur_config.vocoder_min_batch: a vocoder pass of one utterance costs twice per utterance what a pass of eight does (and
         // slows the decode steps it runs beside); finished sequences wait for company, at most kVocHoldSteps steps
         const int minb = cfg_.vocoder_min_batch > 0 ? cfg_.vocoder_min_batch : std::max(1, cfg_.max_seqs / 16);
-        if (voc_queue_.empty() || voc_active_) voc_hold_steps_ = 0;
+        // (the hold runs from the step the oldest queued sequence finished, also while another batch is in flight: reset only when
+        // nothing waits, so a sequence queued behind an active batch is launched as soon as that batch is done once its hold is up)
+        if (voc_queue_.empty()) voc_hold_steps_ = 0;
         else ++voc_hold_steps_;
         if (!voc_active_ && !voc_queue_.empty() &&
             ((int)voc_queue_.size() >= minb || (running == 0 && n_wait == 0) || voc_hold_steps_ > kVocHoldSteps)) {

@@ -44,26 +44,49 @@ def broadcast_conditioning(engine, speaker_key: int, gpt_cond_latent: Optional[t
     return buf
 
 
-def broadcast_conditioning_native(engine, speaker_key: int, gpt_cond_latent: Optional[torch.Tensor],
-                                  speaker_embedding: Optional[torch.Tensor], src: int = 0) -> None:
-    """The same exchange with the collective INSIDE the library (aur_comm_init / aur_broadcast_conditioning: one ncclBroadcast on
-    the engine's own RCCL communicator).  torch.distributed is used once, to hand the 128-byte communicator id to every rank."""
+def comm_init_agreed(engine, device: Optional[torch.device] = None) -> str:
+    """Build the engine's own RCCL communicator on every rank (aur_comm_init; torch.distributed only carries the 128-byte id)
+    and AGREE on the outcome with one all_reduce: returns "" on every rank iff every rank's communicator is up, otherwise the
+    same non-empty reason on every rank.  Nothing enters a collective of the new communicator before this agreement, so a rank
+    whose aur_comm_init raised cannot leave the others waiting inside ncclBroadcast.  Collective; idempotent per engine."""
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
+    err = ""
     if not getattr(engine, "_comm_ready", False):
         uid = None
         if rank == 0:   # a failure to create the id must not leave the other ranks waiting in the broadcast below
             try:
                 uid = type(engine).comm_unique_id()
-            except Exception as ex:   # noqa: BLE001 - re-raised on every rank
+            except Exception as ex:   # noqa: BLE001 - reported on every rank
                 uid = ex
         ids = [uid]
         dist.broadcast_object_list(ids, src=0)
         if isinstance(ids[0], Exception):
-            raise RuntimeError(f"rank 0 could not create the RCCL communicator id: {ids[0]}")
-        engine.comm_init(ids[0], rank, world)
-        engine._comm_ready = True
-    if rank == src:
+            err = f"rank 0 could not create the RCCL communicator id: {ids[0]}"
+        else:
+            try:
+                engine.comm_init(ids[0], rank, world)
+                engine._comm_ready = True
+            except Exception as ex:   # noqa: BLE001 - agreed on below
+                err = f"rank {rank}: aur_comm_init: {type(ex).__name__}: {ex}"
+    bad = torch.tensor([1 if err else 0], dtype=torch.int32, device=device or torch.device("cpu"))
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+    if int(bad.item()) and not err:
+        err = "aur_comm_init failed on another rank"
+    return err
+
+
+def broadcast_conditioning_native(engine, speaker_key: int, gpt_cond_latent: Optional[torch.Tensor],
+                                  speaker_embedding: Optional[torch.Tensor], src: int = 0, device: Optional[torch.device] = None) -> None:
+    """The same exchange with the collective INSIDE the library (aur_comm_init / aur_broadcast_conditioning: one ncclBroadcast on
+    the engine's own RCCL communicator).  torch.distributed is used to hand the 128-byte communicator id to every rank and to
+    agree that every rank's communicator is up (comm_init_agreed) BEFORE any rank enters the broadcast; raises on every rank
+    otherwise."""
+    import torch.distributed as dist
+    err = comm_init_agreed(engine, device)
+    if err:
+        raise RuntimeError(err)
+    if dist.get_rank() == src:
         engine.set_conditioning(speaker_key, gpt_cond_latent.reshape(32, 1024).float().cpu().numpy(),
                                 speaker_embedding.reshape(512).float().cpu().numpy())
     engine.broadcast_conditioning(speaker_key, src)

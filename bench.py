@@ -62,7 +62,7 @@ def _r(x, n=4):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, n_tokens: int = 280, with_c1: bool = False):
+def cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, n_tokens: int = 280, with_c1: bool = False, activation: str = "gelu_new"):
     """CPU baseline (kind "port": the torch-CPU fp32 restatement of the reference path in oracle/) on this box's host cores.
 
     Sample = BASELINE configs[1] (C2) IN FULL: one 200-char utterance, 70 text ids, greedy, `n_tokens` = 280 mel tokens ->
@@ -71,7 +71,7 @@ def cpu_baseline(gpt_sd, xtts_sd, dims, cond, spk, text_ids, n_tokens: int = 280
     use makes the decode loop slower: round 1 measured 0.35 s/token at 64 threads against 36 ms/token at 8)."""
     from oracle import xtts_oracle as O
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    gpt = O.GPTOracle(gpt_sd, xtts_sd)
+    gpt = O.GPTOracle(gpt_sd, xtts_sd, activation=activation)
     w = O.vocoder_effective_weights(xtts_sd)
     c = gpt.build_cond(cond, text_ids)
     sweep = {}
@@ -125,7 +125,7 @@ def kernel_rooflines(args, st, dims, samples_in_pass):
     Decode GEMMs / attention: replay batches (one event pair per n_layer back-to-back launches of one kind, the step's real
     operands, outputs to scratch).  Vocoder convs: a pair per launch (0.2-2 ms each).  Prefill: the whole phase."""
     tj = _traffic()
-    pmc_key = "r04_decode" if "r04_decode" in tj else "r03_decode"
+    pmc_key = next((k for k in ("r05_decode", "r04_decode", "r03_decode") if k in tj), "r03_decode")
     pmc = tj.get(pmc_key, {})
     gemm_peak = FP32_MFMA_PEAK_TFLOPS if args.gemm == "f32" else BF16_MFMA_PEAK_TFLOPS / 6.0
 
@@ -198,7 +198,7 @@ def kernel_rooflines(args, st, dims, samples_in_pass):
             if n and m > 0:
                 cls[names[k]] = {"launches": n, "ms": m, "frac_mfma": st["conv_class_flops"][k] / (m * 1e-3) / 1e12 / mf_peak,
                                  "frac_hbm_as_stored": st["conv_class_bytes"][k] / (m * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-        conv_pmc = (tj.get("r04_conv") or tj.get("r03_conv") or {}).get(f"conv_{args.vocoder}")
+        conv_pmc = (tj.get("r05_conv") or tj.get("r04_conv") or tj.get("r03_conv") or {}).get(f"conv_{args.vocoder}")
         voc = {"kernel": "conv1d_dma_f16_kernel + resblock_round_f16_kernel + conv1d_mfma_f16_kernel (HiFi-GAN convs)"
                          if args.vocoder == "fp16" else "conv1d_mfma_kernel",
                "ms_per_batch": ms / max(1, st["vocoder_batches"]), "launches": st["conv_launches"],
@@ -249,19 +249,39 @@ class Bench:
         from auralis_amd.config import XTTSDims
         from auralis_amd.weights import pack_all
         self.dims = XTTSDims()
-        _log("building synthetic checkpoint")
-        self.gpt_sd = make_synthetic_gpt(self.dims.gpt, seed=1234, n_layer=args.layers)
-        self.xtts_sd = make_synthetic_xtts(self.dims, seed=1234, gpt_sd=self.gpt_sd)
+        gelu_erf = False
+        if args.checkpoint:   # real weights (the reference's on-disk format, XTTSv2.py:276-308); shapes and config are checked on load
+            from auralis_amd.checkpoint import load_checkpoint, read_checkpoint_config
+            _log(f"loading checkpoint {args.checkpoint}")
+            self.gpt_sd, self.xtts_sd = load_checkpoint(args.checkpoint)
+            ck = read_checkpoint_config(args.checkpoint, self.gpt_sd)
+            args.layers, gelu_erf = ck.n_layer, ck.gelu_erf
+        else:
+            _log("building synthetic checkpoint")
+            self.gpt_sd = make_synthetic_gpt(self.dims.gpt, seed=1234, n_layer=args.layers)
+            self.xtts_sd = make_synthetic_xtts(self.dims, seed=1234, gpt_sd=self.gpt_sd)
         # profile=False: the engine configuration the parity tests run (tests/test_gpu_baseline_size.py)
         self.eng = NativeEngine(n_layer=args.layers, max_seqs=args.batch, device=local_rank, profile=False,
                                 vocoder_fp16=(args.vocoder == "fp16"), return_latents=False,   # audio + tokens, as TTSOutput
                                 kv_fp16=(args.kv == "fp16"), gemm_f32_exact=(args.gemm == "f32"), admit_min_batch=args.admit_min_batch,
-                                vocoder_min_batch=args.vocoder_min_batch)
+                                vocoder_min_batch=args.vocoder_min_batch, gelu_erf=gelu_erf)
+        self.gelu_erf = gelu_erf
         self.packed = pack_all(self.gpt_sd, self.xtts_sd)
         self.eng.load_weights(self.packed)
         _log("weights resident")
         self.cond, self.spk = make_synthetic_conditioning(self.dims)
+        if args.speaker:      # .npz with gpt_cond_latent [1,32,1024] and speaker_embedding [1,512,1] (XTTSv2Engine.get_audio_conditioning's output)
+            z = np.load(args.speaker)
+            self.cond = torch.from_numpy(np.asarray(z["gpt_cond_latent"], np.float32).reshape(1, 32, 1024))
+            self.spk = torch.from_numpy(np.asarray(z["speaker_embedding"], np.float32).reshape(1, 512, 1))
         self.text_ids = make_synthetic_text_ids(self.dims, n_text=70, seed=11)
+        tok_file = os.path.join(args.checkpoint, "tokenizer.json") if args.checkpoint else ""
+        if tok_file and os.path.isfile(tok_file):   # the checkpoint's own tokenizer on a 200-character English sentence
+            from auralis_amd.api.text import XTTSTokenizer
+            txt = ("The old lighthouse keeper climbed the spiral stairs every evening, counted the ships on the horizon, wrote their names "
+                   "in a worn leather book, and wondered which of them would still be sailing when the winter storms arrived.")
+            self.text_ids = XTTSTokenizer(tok_file, vocab_size=self.xtts_sd["text_embedding.weight"].shape[0]).batch_encode_with_split(txt, "en")[0]
+            _log(f"text ids from the checkpoint's tokenizer: {len(self.text_ids)} ids for {len(txt)} characters")
         self.make_ids = lambda n, seed: make_synthetic_text_ids(self.dims, n_text=n, seed=seed)
         self.SPK = 1
 
@@ -324,6 +344,15 @@ class Bench:
         from auralis_amd.api.xtts_engine import XTTSv2Engine
         from auralis_amd.longform import build_requests, default_window, stream_longform
         a, eng = self.args, self.eng
+        slots = a.c5s_slots or a.batch
+        own = None
+        if slots != a.batch:   # the long-form knob is the facade's scheduler_max_concurrency (core/tts.py:20-51): its own engine, same weights
+            from auralis_amd._lib import NativeEngine
+            own = eng = NativeEngine(n_layer=a.layers, max_seqs=slots, device=self.local_rank, profile=False, vocoder_fp16=(a.vocoder == "fp16"),
+                                     return_latents=False, kv_fp16=(a.kv == "fp16"), gemm_f32_exact=(a.gemm == "f32"),
+                                     admit_min_batch=a.admit_min_batch, vocoder_min_batch=a.vocoder_min_batch, gelu_erf=self.gelu_erf)
+            eng.load_weights(self.packed)
+            eng.set_conditioning(self.SPK, self.cond.numpy(), self.spk.numpy())
         EN = ("It was a bright cold day in April, and the clocks were striking thirteen. Nobody in the street seemed to notice, "
               "and the wind kept pushing the dust along the old road as if nothing had happened at all. ")
         FR = ("Il était une fois, dans une petite ville que nous ne connaissons pas, un homme qui avait beaucoup d'idées et très peu "
@@ -342,8 +371,8 @@ class Bench:
         voice = {"gpt_cond_latent": self.cond.numpy(), "speaker_embedding": self.spk.numpy()}
         reqs = build_requests(paras, [voice], seed=3)   # request defaults: T 0.75 / top_p 0.85 / top_k 50 / rep_pen 5.0
         xe = XTTSv2Engine(eng, XTTSTokenizer(None, vocab_size=self.xtts_sd["text_embedding.weight"].shape[0], synthetic=True),
-                          max_concurrency=a.batch)
-        tts = TTS(scheduler_max_concurrency=a.batch).with_engine(xe)
+                          max_concurrency=slots)
+        tts = TTS(scheduler_max_concurrency=slots).with_engine(xe)
         inflight = tts.scheduler.second_phase_concurrency   # the facade's gate = slots, as in the reference; the window's other chunks queue inside the engine
         window = window or default_window(tts)              # paragraphs in flight (>= 1 chunk each)
         try:
@@ -364,13 +393,16 @@ class Bench:
             st = eng.stats()
         finally:
             tts.close(keep_engine=True)   # the bench still needs the native engine
-            eng.load_weights({"mel_head.b": np.asarray(self.packed["mel_head.b"], np.float32)})
-        occ = st["decode_rows"] / max(1, st["decode_steps"]) / a.batch
+            if own is not None:
+                own.close()
+            else:
+                eng.load_weights({"mel_head.b": np.asarray(self.packed["mel_head.b"], np.float32)})
+        occ = st["decode_rows"] / max(1, st["decode_steps"]) / slots
         return {"workload": f"BASELINE configs[4] at 1-GPU scale: {sum(len(p) for p in paras)} chars, {len(paras)} paragraphs en/fr/de "
                             f"(language=auto), {n_chunks} chunks, natural stop (mel_head.bias[1025] = {STOP_BIAS_C5S}), {window} paragraphs in flight (every chunk of them submitted; facade gate {inflight}) "
-                            f"on {a.batch} slots (admit_min_batch {a.admit_min_batch or max(1, a.batch // 8)}), streamed in (paragraph, chunk) order "
+                            f"on {slots} slots (admit_min_batch {a.admit_min_batch or max(1, slots // 8)}), streamed in (paragraph, chunk) order "
                             f"through TTS / longform.stream_longform",
-                "chars": sum(len(p) for p in paras), "paragraphs": len(paras), "chunks": n_chunks, "in_order": bool(order_ok),
+                "slots": slots, "chars": sum(len(p) for p in paras), "paragraphs": len(paras), "chunks": n_chunks, "in_order": bool(order_ok),
                 "wall_s": dt, "first_chunk_s": first, "samples": ns, "audio_s": ns / 24000.0, "samples_per_s": ns / dt, "rtf": dt / max(1e-9, ns / 24000.0),
                 "chars_per_s": sum(len(p) for p in paras) / dt, "slot_occupancy": occ,
                 "tokens_per_chunk": {"mean": float(np.mean(toks)), "min": int(np.min(toks)), "max": int(np.max(toks))} if toks else None,
@@ -459,8 +491,9 @@ def compact(line, full_path):
         out["c2"] = c2
     c5 = line.get("c5s")
     if c5 and "error" not in c5:
-        out["c5s"] = {"chars": c5["chars"], "chunks": c5["chunks"], "samples_per_s": _r(c5["samples_per_s"]), "rtf": _r(c5["rtf"]),
-                      "slot_occupancy": _r(c5["slot_occupancy"]), "first_chunk_s": _r(c5["first_chunk_s"]), "in_order": c5["in_order"]}
+        out["c5s"] = {"slots": c5.get("slots"), "chars": c5["chars"], "chunks": c5["chunks"], "samples_per_s": _r(c5["samples_per_s"]), "rtf": _r(c5["rtf"]),
+                      "slot_occupancy": _r(c5["slot_occupancy"]), "decode_ms_per_step": _r(c5.get("decode_ms_per_step")), "first_chunk_s": _r(c5["first_chunk_s"]),
+                      "in_order": c5["in_order"]}
     elif c5:
         out["c5s"] = c5
     c4 = line.get("c4")
@@ -493,12 +526,14 @@ def main():
     ap.add_argument("--gemm", choices=["bf16x3", "f32"], default="bf16x3",
                     help="GEMM arithmetic: bf16x3 = exact 3-way bf16 split of the fp32 operands, 6 bf16 MFMAs per product, fp32 "
                          "accumulate (default, what the parity tests run); f32 = v_mfma_f32_*_f32 (aur_config.gemm_f32_exact)")
-    ap.add_argument("--bcast", choices=["native", "torch"], default="torch",
-                    help="multi-GPU launches, conditioning broadcast BEFORE the measurements: torch (default) = torch.distributed.broadcast "
-                         "into a device buffer registered with aur_set_conditioning_device; native = the ncclBroadcast inside the library on "
-                         "the engine's own RCCL communicator (aur_comm_init / aur_broadcast_conditioning).  The native route has only run at "
-                         "world size 1 in the build environment, and a collective that hangs cannot be fallen back from: with the default it "
-                         "is exercised AFTER the measurements instead, under a watchdog, and reported as multi_gpu.native_route")
+    ap.add_argument("--bcast", choices=["auto", "native", "torch"], default="auto",
+                    help="multi-GPU launches, the conditioning broadcast BEFORE the measurements.  auto (default) = the ncclBroadcast inside the "
+                         "library on the engine's own RCCL communicator (aur_comm_init / aur_broadcast_conditioning) when aur_comm_init "
+                         "succeeded on EVERY rank (agreed with one all_reduce before any rank enters the collective), otherwise "
+                         "torch.distributed.broadcast into a device buffer registered with aur_set_conditioning_device, with the reason in "
+                         "multi_gpu.native_route_failed.  native = the same without the torch fallback for a failed init; torch = the torch "
+                         "route (the in-library one is then exercised after the measurements, multi_gpu.native_route).  The native "
+                         "broadcast runs under a watchdog (--native-check-timeout): a hang ends the run with a diagnostic instead of a silent stall")
     ap.add_argument("--native-check-timeout", type=float, default=90.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the c2 / c5s (and, N > 1, c4) measurements after the headline")
@@ -506,10 +541,20 @@ def main():
     ap.add_argument("--profile-every", type=int, default=8, help="profile pass: replay batches after every n-th decode step")
     ap.add_argument("--c5-chars", type=int, default=56250,
                     help="characters of the c5s long-form text; default = one GPU's eighth of BASELINE configs[4]'s ~450 k characters")
+    ap.add_argument("--c5s-slots", type=int, default=192,
+                    help="slots (TTS scheduler_max_concurrency, the reference's long-form knob, core/tts.py:20-51) of the c5s measurement; "
+                         "0 = --batch.  A value other than --batch builds a second engine for that workload (same weights, its own K/V "
+                         "pool).  Default 192: the decode GEMMs stream the weights once per step whatever the rows, so a long-form job is "
+                         "cheaper per token on more rows (profiles/r05_c5s_slots_sweep.jsonl: 64 slots 26.3 M samples/s, 128: 28.4, 192: 30.3)")
     ap.add_argument("--admit-min-batch", type=int, default=0,
                     help="aur_config.admit_min_batch (0 = the engine's default, slots / 8; 1 = admit one by one); matters for c5s only")
     ap.add_argument("--vocoder-min-batch", type=int, default=0,
                     help="aur_config.vocoder_min_batch: finished sequences wait for this many before a vocoder batch is launched (0/1 = at once)")
+    ap.add_argument("--checkpoint", default="",
+                    help="a checkpoint directory in the reference's on-disk format (XTTSv2.py:276-308) instead of the seeded synthetic "
+                         "weights: layer count, activation and tokenizer come from it.  The line's `data` then says so; generation stays "
+                         "in fixed-length mode (--tokens) so that runs are comparable")
+    ap.add_argument("--speaker", default="", help=".npz with gpt_cond_latent / speaker_embedding to use instead of the seeded synthetic voice")
     ap.add_argument("--pipeline", action="store_true",
                     help="queue all steps at once so the vocoder of batch k overlaps the GPT of batch k+1 (measured neutral)")
     ap.add_argument("--cpu-tokens", type=int, default=280, help="mel tokens of the CPU-baseline utterance (280 = C2 in full)")
@@ -544,24 +589,48 @@ def main():
     # speaker conditioning: computed on rank 0, RCCL-broadcast over xGMI, registered from the device buffer
     multi = {}
     route = args.bcast
-    if use_dist and route == "native":
-        # the collective inside the library: one ncclBroadcast of 133 120 B on the engine's own RCCL communicator.  This route has
-        # only ever run at world size 1 in the build environment, so a failure to set it up (raised on a rank) does not take the
-        # scaling run down: the ranks agree on it and fall back to torch.distributed's broadcast, and the line says so.
-        from auralis_amd.parallel import broadcast_conditioning_native
-        err = ""
-        try:
-            broadcast_conditioning_native(eng, SPK, B.cond if rank == 0 else None, B.spk if rank == 0 else None, src=0)
-            multi["rccl_ranks"], multi["rccl_rank_of_rank0"] = eng.comm_info()   # what the communicator itself reports
-        except Exception as ex:   # noqa: BLE001 - reported in the bench line
-            err = f"{type(ex).__name__}: {ex}"
-        bad = torch.tensor([1 if err else 0], device=torch.device("cuda", local_rank), dtype=torch.int32)
-        torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
+    dev = torch.device("cuda", local_rank)
+    if use_dist and route in ("auto", "native"):
+        # the collective inside the library: one ncclBroadcast of 133 120 B on the engine's own RCCL communicator.  First every rank
+        # builds its communicator and the ranks AGREE that all of them are up (parallel.comm_init_agreed); only then does anyone
+        # enter the broadcast.  The route has only ever run at world size 1 in the build environment, so the broadcast itself runs
+        # under a watchdog: a rank stuck in it cannot be recovered, the run then ends with a diagnostic on stderr.
+        import threading
+        from auralis_amd.parallel import broadcast_conditioning_native, comm_init_agreed
+        err = comm_init_agreed(eng, dev)
         multi["native_route_failed"] = False
-        if int(bad.item()):
+        if err:
+            if route == "native":
+                raise SystemExit(f"--bcast native: {err}")
+            multi["native_route_failed"] = err[:160]
+            _log(f"in-library RCCL route not available ({err}); falling back to torch.distributed.broadcast")
             route = "torch"
-            multi["native_route_failed"] = (err or "on another rank")[:160]
-            _log(f"in-library RCCL route failed ({multi['native_route_failed']}); falling back to torch.distributed.broadcast")
+        else:
+            res = {}
+
+            def native_bcast():
+                try:
+                    broadcast_conditioning_native(eng, SPK, B.cond if rank == 0 else None, B.spk if rank == 0 else None, src=0, device=dev)
+                    res["ok"] = True
+                except Exception as ex:   # noqa: BLE001 - agreed on below
+                    res["err"] = f"{type(ex).__name__}: {ex}"
+            th = threading.Thread(target=native_bcast, daemon=True)
+            th.start()
+            th.join(args.native_check_timeout)
+            if th.is_alive():
+                _log(f"rank {rank}: ncclBroadcast on the engine's communicator did not return within {args.native_check_timeout:.0f} s; "
+                     "re-run with --bcast torch")
+                sys.stderr.flush()
+                os._exit(3)
+            bad = torch.tensor([0 if res.get("ok") else 1], device=dev, dtype=torch.int32)
+            torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
+            if int(bad.item()):   # the collective returned an error somewhere: the voice is re-sent by the torch route on every rank
+                multi["native_route_failed"] = (res.get("err") or "aur_broadcast_conditioning failed on another rank")[:160]
+                _log(f"in-library broadcast failed ({multi['native_route_failed']}); falling back to torch.distributed.broadcast")
+                route = "torch"
+            else:
+                route = "native"
+                multi["rccl_ranks"], multi["rccl_rank_of_rank0"] = eng.comm_info()   # what the communicator itself reports
     if use_dist and route == "torch":
         from auralis_amd.parallel import broadcast_conditioning
         broadcast_conditioning(eng, SPK, B.cond if rank == 0 else None, B.spk if rank == 0 else None, src=0,
@@ -654,7 +723,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (GPT; GEMMs " + ("exact-f32 MFMA" if args.gemm == "f32" else "as exact bf16x3 splits, f32 acc") + ")"
                      + ("" if args.vocoder == "fp32" else " + f16-in/f32-acc vocoder") + (" + f16 K/V (NOT the parity mode)" if args.kv == "fp16" else ""),
-            "data": "synthetic", "rtf": dt / audio_s,
+            "data": "synthetic" if not args.checkpoint else "real checkpoint weights (" + os.path.basename(os.path.normpath(args.checkpoint)) + "), synthetic text / fixed-length generation",
+            "rtf": dt / audio_s,
             "config": {"workload": f"BASELINE configs[2]: {args.batch} concurrent 200-char utterances per GPU (70 text tokens -> {args.tokens} mel "
                                    f"tokens fixed-length -> {dims.voc.samples_for_latents(args.tokens)} samples each), T=0.75 top_p=0.85 top_k=50 "
                                    "rep_pen=5.0, shared speaker latent, continuous batching"
@@ -684,14 +754,14 @@ def main():
     # aur_broadcast_conditioning on the engine's own communicator and must arrive byte-identical to the first one.  Under a
     # watchdog: a hang ends in "timeout" in the line (and a hard exit after it has been printed), not in a lost run.
     hard_exit = False
-    if use_dist and route == "torch":
+    if use_dist and route == "torch" and args.bcast == "torch":
         import threading
         from auralis_amd.parallel import broadcast_conditioning_native
         res = {}
 
         def native():
             try:
-                broadcast_conditioning_native(eng, SPK + 1, B.cond if rank == 0 else None, B.spk if rank == 0 else None, src=0)
+                broadcast_conditioning_native(eng, SPK + 1, B.cond if rank == 0 else None, B.spk if rank == 0 else None, src=0, device=dev)
                 res["ranks"], res["rank0"] = eng.comm_info()
                 res["same_bytes"] = eng.conditioning_checksum(SPK + 1) == eng.conditioning_checksum(SPK)
                 res["status"] = "ok" if res["same_bytes"] and res["ranks"] == world else "mismatch"
@@ -710,7 +780,8 @@ def main():
     if rank == 0:
         line["c2"], line["c5s"], line["c4"] = c2, c5, c4
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(B.gpt_sd, B.xtts_sd, dims, B.cond, B.spk, B.text_ids, args.cpu_tokens, args.cpu_c1)
+            line["cpu_baseline"] = cpu_baseline(B.gpt_sd, B.xtts_sd, dims, B.cond, B.spk, B.text_ids, args.cpu_tokens, args.cpu_c1,
+                                                activation="gelu" if B.gelu_erf else "gelu_new")
         else:
             line["cpu_baseline"] = None
         full_path = args.out

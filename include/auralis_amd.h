@@ -38,8 +38,10 @@ typedef struct aur_config {
     int32_t max_seqs;         /* concurrent sequences (continuous-batching slots) */
     int32_t max_prefill_rows; /* cap on prompt rows prefetched in one step (0 = default 8192) */
     int32_t max_speakers;     /* speaker-conditioning table entries (0 = default 64) */
-    int32_t vocoder_min_batch;/* finished sequences wait until this many are ready for one vocoder pass -- at most 16 steps (~30 ms), and not
-                                 at all when nothing else runs or waits.  0 = default max_seqs / 16 (4 at 64 slots); 1 = vocode at once */
+    int32_t vocoder_min_batch;/* finished sequences wait until this many are ready for one vocoder pass -- at most 16 steps (~30 ms) counted
+                                 from the step the oldest waiting one finished, plus, when a vocoder pass is already in flight, the rest of
+                                 that pass (one pass at a time) -- and not at all when nothing else runs or waits.  0 = default
+                                 max_seqs / 16 (4 at 64 slots); 1 = vocode at once */
     int32_t profile;          /* 1 = profile mode from the start (see aur_set_profile; every 64th decode step) */
     int32_t vocoder_fp16;     /* 1 = HiFi-GAN convs on fp16-input / fp32-accumulate MFMA (needs the voc16.* tensors);
                                  0 = exact-f32 MFMA parity mode */
