@@ -1302,10 +1302,16 @@ private:
     }
     void profile_replay(RowWs& w, int M, const int* d_row_slot) {
         const int mtt = w.rows_cap / 16, nl = cfg_.n_layer;
-        prof_q_.ensure((size_t)w.rows_cap * kHidden * 4);
-        prof_h_.ensure((size_t)w.rows_cap * kHidden * 4);
-        prof_stats_.ensure((size_t)w.rows_cap * 64 * sizeof(float2));
-        prof_act_.ensure((size_t)w.rows_cap * 4 * kHidden * 4);
+        // (the residual replays READ their output scratch -- out += ... -- so a freshly allocated buffer is defined once)
+        auto scratch = [&](DevBuf& buf, size_t n) {
+            const void* before = buf.p;
+            buf.ensure(n);
+            if (buf.p != before) HIP_CHECK(hipMemsetAsync(buf.p, 0, n, w.st));
+        };
+        scratch(prof_q_, (size_t)w.rows_cap * kHidden * 4);
+        scratch(prof_h_, (size_t)w.rows_cap * kHidden * 4);
+        scratch(prof_stats_, (size_t)w.rows_cap * 64 * sizeof(float2));
+        scratch(prof_act_, (size_t)w.rows_cap * 4 * kHidden * 4);
         prof_kv_.ensure((size_t)kv_layer_stride_ * (kv_half_ ? 2 : 4));
         for (int kind = 0; kind < 4; ++kind) {
             bool ln;

@@ -1296,13 +1296,32 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
     }
     const unsigned char* seen = a.seen + (long)slot * kSeenStride;
 
-    for (int v = tid; v < V; v += 256) {
-        float s = a.P[(long)j * a.Npad + v];
-        for (int sl = 1; sl < a.S; ++sl) s += a.P[((long)sl * a.Ms + j) * a.Npad + v];
-        s += a.bias[v];
-        if (pen != 1.0f && seen[v]) s = (s > 0.f) ? s / pen : s * pen;
-        z[v] = s;
-        if (a.dbg_logits) a.dbg_logits[(long)j * V + v] = s;
+    // the row's logits, bias and penalty flags: every load of the thread (V <= 1040 = 5 x 256: up to five ids per thread) issued
+    // before the first use.  As a loop with the loads next to their uses hipcc emitted load -> wait -> load -> wait ...: fifteen
+    // dependent memory round trips per row, roughly half of the kernel's 27 us (round 4).
+    {
+        float pv[5], bv[5];
+        unsigned char sn[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int v = min(tid + 256 * u, V - 1);
+            pv[u] = a.P[(long)j * a.Npad + v];
+            bv[u] = a.bias[v];
+            sn[u] = seen[v];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int v = tid + 256 * u;
+            if (v < V) {
+                float s = pv[u];
+                for (int sl = 1; sl < a.S; ++sl) s += a.P[((long)sl * a.Ms + j) * a.Npad + v];   // (prefill-time callers; S == 1 on the decode path)
+                s += bv[u];
+                if (pen != 1.0f && sn[u]) s = (s > 0.f) ? s / pen : s * pen;
+                z[v] = s;
+                if (a.dbg_logits) a.dbg_logits[(long)j * V + v] = s;
+            }
+        }
     }
     __syncthreads();
 
@@ -1365,7 +1384,31 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
             }
             __syncthreads();
             const int n_surv = sh_i[1];
-            if (n_surv <= 128) {
+            if (n_surv <= 64) {
+                // k (+ ties) <= 64 survivors: one key per lane, bitonic network on shuffles -- 21 compare-exchange steps in registers
+                // instead of 28 LDS passes over 128 keys (~2.7 us of the kernel).  Keys are distinct (the id is part of the key), so
+                // every correct descending sort gives the same order.
+                if (tid < 64) {
+                    unsigned long long key = tid < n_surv ? keys[tid] : 0ull;
+                    for (int k = 2; k <= 64; k <<= 1)
+                        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                            const unsigned lo32 = (unsigned)__shfl_xor((int)(unsigned)key, jj, 64);
+                            const unsigned hi32 = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), jj, 64);
+                            const unsigned long long other = ((unsigned long long)hi32 << 32) | lo32;
+                            const bool lower = (tid & jj) == 0;        // this lane is element e < x = e ^ jj of the pair
+                            const bool up = (tid & k) == 0;            // descending block (as the LDS network below: larger key first)
+                            const bool take_max = lower == up;
+                            key = take_max ? (key > other ? key : other) : (key < other ? key : other);
+                        }
+                    keys[tid] = key;
+                    keys[tid + 64] = 0ull;
+                    if (tid == 0) {
+                        sh_f[0] = ord2f(lo);
+                        sh_i[0] = n_surv;
+                    }
+                }
+                sorted = true;
+            } else if (n_surv <= 128) {
                 if (tid < 64) {   // one wave: LDS accesses of a single wave execute in order, no barrier needed
                     for (int e = tid; e < 128; e += 64)
                         if (e >= n_surv) keys[e] = 0ull;
@@ -1451,20 +1494,26 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
                 }
                 __syncthreads();
                 const float pr = ev / sh_f[1];
-                __syncthreads();
-                sv[tid] = pr;
-                __syncthreads();
-                if (tid == 0) {
-                    const float lim = 1.0f - topp;
-                    double c = 0.0;
-                    for (int r = n1 - 1; r >= 1; --r) {
-                        c += (double)sv[r];
-                        if ((float)c <= lim)
-                            z[(unsigned)(keys[r] & 0xffffffffull)] = -INFINITY;
-                        else
-                            break;
-                    }
+                // c_r = pr[n1-1] + ... + pr[r] in double: rank r is masked iff r >= 1 and float(c_r) <= 1 - p.  c_r grows as r falls,
+                // so "mask until the first rank that fails" (the serial form) is the same set as "mask every rank whose own c_r
+                // passes": the ranks are independent once c_r is known, and c_r is a suffix sum -- four waves scan 64 ranks each
+                // on shuffles (double: two dwords), a carry per wave through LDS.  (The additions are those of the serial loop in
+                // another order; in double they are exact unless a term is below 2^-29 of the running sum, a difference of one
+                // unit in the 53rd bit, against the 24 bits the comparison looks at.)
+                double c = tid < n1 ? (double)pr : 0.0;
+                const int lane = tid & 63;
+#pragma unroll
+                for (int sh = 1; sh < 64; sh <<= 1) {   // inclusive suffix scan inside the wave: lane l += lane l + sh
+                    const int lo32 = __shfl_down((int)(unsigned)__double_as_longlong(c), sh, 64);
+                    const int hi32 = __shfl_down((int)(unsigned)(__double_as_longlong(c) >> 32), sh, 64);
+                    const double o = __longlong_as_double(((long long)hi32 << 32) | (unsigned)lo32);
+                    if (lane + sh < 64) c += o;
                 }
+                __shared__ double carry[4];
+                if (lane == 0) carry[tid >> 6] = c;   // the wave's total
+                __syncthreads();
+                for (int w2 = (tid >> 6) + 1; w2 < 4; ++w2) c += carry[w2];
+                if (tid >= 1 && tid < n1 && (float)c <= 1.0f - topp) z[(unsigned)(keys[tid] & 0xffffffffull)] = -INFINITY;
             } else if (tid == 0) {
                 float sum = 0.f;
                 for (int r = 0; r < n1; ++r) sum += expf(ord2f((unsigned)(keys[r] >> 32)) - maxv);

@@ -140,6 +140,68 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvArgs& a, f32x16 (&
     }
 }
 
+// The same epilogue when EVERY tensor it touches is interleaved halves (the default fp16 vocoder: residual stream, MRF sum and the
+// stage outputs; ConvArgs::res_f16 / mrf_f16 / out_act_f16) -- the arithmetic of conv_epilogue_plain element for element, written
+// so that a 32 x 32 tile needs its 16 row constants, eight packed loads and four values at a time: the 512-position workgroups of
+// eight waves run two per CU, i.e. at 128 registers per wave, where the general form (fp32 and fp16 branches side by side) spills.
+template <int WM, int WN, int MT, int NTW, int MODE>
+__device__ __forceinline__ void conv_epilogue_plain_h(const ConvArgs& a, f32x16 (&acc)[WM][WN], int b, int mtile, int q0, int wv,
+                                                      int l31, int hi, int n_q) {
+    const long ob = (long)b * a.o_bstride;
+    const bool has_res = a.res != nullptr;
+    const _Float16* rb = reinterpret_cast<const _Float16*>(a.res) + ob;
+    _Float16* mb = reinterpret_cast<_Float16*>(a.mrf) + ob;
+    _Float16* dstb = (MODE == 0 || MODE == 3) ? reinterpret_cast<_Float16*>(a.out) + ob : mb;
+    const float dsl = (MODE == 0 || MODE == 3) ? a.out_slope : 1.0f;
+    const float unact = a.res_unact;
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+        float add[16];
+        conv_row_adds<MT, false>(a, add, b, mtile, m, hi);
+        const int c0 = mtile * MT + m * 32 + 4 * hi;
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const int q = q0 + wv * NTW + n * 32 + l31;
+            const bool ok = q < n_q;
+            const int qc = min(q, n_q - 1);
+            long off[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) off[g] = ((long)((c0 + 8 * g) >> 4) * a.o_stride + qc) * 16 + ((c0 + 8 * g) & 15);
+            h16x4v rh[4], mh[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                rh[g] = h16x4v{0, 0, 0, 0};
+                mh[g] = h16x4v{0, 0, 0, 0};
+            }
+            if (has_res) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rh[g] = *reinterpret_cast<const h16x4v*>(rb + off[g]);
+            }
+            if (MODE >= 2) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) mh[g] = *reinterpret_cast<const h16x4v*>(mb + off[g]);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // all loads of this 32x32 tile are in flight before the first use
+            if (ok) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    h16x4v o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float rv = has_res ? (float)rh[g][k] : 0.f;
+                        if (has_res) rv = rv < 0.f ? rv * unact : rv;   // the stream is stored activated: undo the (invertible) leaky ReLU
+                        float val = acc[m][n][4 * g + k] + add[4 * g + k] + rv;
+                        if (MODE == 2) val += (float)mh[g][k];
+                        if (MODE == 3) val = ((float)mh[g][k] + val) / 3.0f;
+                        o[k] = (_Float16)lrelu(val, dsl);
+                    }
+                    *reinterpret_cast<h16x4v*>(dstb + off[g]) = o;
+                }
+            }
+        }
+    }
+}
+
 // polyphase transposed conv: virtual row v = co*s + phase lands at t = q*s + phase - p (no residual / MRF on these layers).
 // A lane's registers 4g .. 4g+3 are four CONSECUTIVE virtual rows at one position q:
 //   s = 8 (k 16, p 4): four consecutive phases of one output channel -> times 8q + 4*hi - 4 .. +3, one aligned 16-byte store;
@@ -616,19 +678,22 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int KS, int DIL, int MT, int NBUF>
-__global__ __launch_bounds__(256, 2) void conv1d_dma_f16_kernel(ConvArgs a) {
+// NWV = waves per workgroup: the tile is MT channels x (NWV * 32 * WN) positions.  The packed weights of a chunk are the same for
+// every position tile, so a workgroup of 8 waves (512 positions) pulls them through the CU's L1 once for twice the MFMAs.
+// EPIH: the all-halves epilogue (conv_epilogue_plain_h; the launcher checks that the tensors are halves).
+template <int KS, int DIL, int MT, int NBUF, int NWV = 4, bool EPIH = false>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 4) void conv1d_dma_f16_kernel(ConvArgs a) {   // (two workgroups per CU either way)
     constexpr int CK = 16;
     constexpr int WM = MT / 32;
     constexpr int WN = (MT == 64) ? 2 : 4;
     constexpr int NTW = 32 * WN;
-    constexpr int NT = 4 * NTW;
+    constexpr int NT = NWV * NTW;
     constexpr int HALO = (KS - 1) * DIL;
     constexpr int XROW = NT + HALO;
     constexpr int WI = KS * MT * 2 / 64;                   // weight copies (1 KiB each) per chunk
     constexpr int XI0 = (2 * XROW + 63) / 64;
-    constexpr int XI = XI0 + (4 - (WI + XI0) % 4) % 4;     // input-window copies, padded so that every wave issues IPW of them
-    constexpr int IPW = (WI + XI) / 4;
+    constexpr int XI = XI0 + (NWV - (WI + XI0) % NWV) % NWV;   // input-window copies, padded so that every wave issues IPW of them
+    constexpr int IPW = (WI + XI) / NWV;
     constexpr int BUF = (WI + XI) * 1024;
     static_assert((KS * MT * 2) % 64 == 0 && IPW * (NBUF - 2) < 64, "DMA bookkeeping");
     __shared__ __attribute__((aligned(1024))) char smem[NBUF * BUF];
@@ -660,7 +725,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_dma_f16_kernel(ConvArgs a) {
         const unsigned dst0 = sbase + (unsigned)(c % NBUF) * BUF;
 #pragma unroll
         for (int k = 0; k < IPW; ++k) {
-            const int ii = wvs + 4 * k;
+            const int ii = wvs + NWV * k;
             const bool is_w = ii < WI;   // wave-uniform; selects instead of branches keep the copy sequence straight-line
             const int s = (is_w ? ii : ii - WI) * 64 + lane, row = s >> 1, h = (s & 1) ^ ((row >> 3) & 1);
             const int t = q0 - a.padl + row;
@@ -704,13 +769,32 @@ __global__ __launch_bounds__(256, 2) void conv1d_dma_f16_kernel(ConvArgs a) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[m], bv[n], acc[m][n], 0, 0, 0);
         }
     }
-    if (a.ups_s) conv_epilogue_ups<WM, WN, MT, NTW>(a, acc, b, mtile, q0, wv, l31, hi, len_in, n_q);
-    else if (a.mrf_mode == 0) conv_epilogue_plain<WM, WN, MT, NTW, 0>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
-    else if (a.mrf_mode == 1) conv_epilogue_plain<WM, WN, MT, NTW, 1>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
-    else if (a.mrf_mode == 2) conv_epilogue_plain<WM, WN, MT, NTW, 2>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
-    else conv_epilogue_plain<WM, WN, MT, NTW, 3>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
+    if constexpr (EPIH) {
+        if (a.mrf_mode == 0) conv_epilogue_plain_h<WM, WN, MT, NTW, 0>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
+        else if (a.mrf_mode == 1) conv_epilogue_plain_h<WM, WN, MT, NTW, 1>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
+        else if (a.mrf_mode == 2) conv_epilogue_plain_h<WM, WN, MT, NTW, 2>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
+        else conv_epilogue_plain_h<WM, WN, MT, NTW, 3>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
+    } else {
+        if (a.ups_s) conv_epilogue_ups<WM, WN, MT, NTW>(a, acc, b, mtile, q0, wv, l31, hi, len_in, n_q);
+        else if (a.mrf_mode == 0) conv_epilogue_plain<WM, WN, MT, NTW, 0>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
+        else if (a.mrf_mode == 1) conv_epilogue_plain<WM, WN, MT, NTW, 1>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
+        else if (a.mrf_mode == 2) conv_epilogue_plain<WM, WN, MT, NTW, 2>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
+        else conv_epilogue_plain<WM, WN, MT, NTW, 3>(a, acc, b, mtile, q0, wv, l31, hi, n_q);
+    }
 }
 
+// Workgroup shape of the 64-channel-tile convs (the 256- and 128-channel stages): 8 = eight waves x 64 positions, two workgroups per
+// CU (default since round 5: the chunk's packed weights pass through the CU's L1 once per 512 positions instead of once per 256 --
+// PMC showed the L1 stalled on its pending-request limit 45-61 % of the time, profiles/r05_pmc_conv_latency.txt; 61.8 vs 65.4 ms per
+// 64 utterances); AUR_CONV_WAVES=4 selects round 4's 256-position tiles (A/B).  Also measured, not kept: one 1024-position workgroup
+// of 16 waves per CU 63.2 ms; four waves x 128 positions (256 registers, an A fragment serves four MFMAs) 64.8.
+static int conv_dma_waves() {
+    static const int w = [] {
+        const char* e = getenv("AUR_CONV_WAVES");
+        return e ? atoi(e) : 8;
+    }();
+    return w;
+}
 template <int KS, int DIL>
 static void launch_conv_dma(const ConvArgs& a, hipStream_t st) {
     constexpr int NBUF = KS >= 11 ? 2 : KS >= 3 ? 3 : 4;   // the fewer taps, the shorter a chunk's MFMA phase and the deeper the prefetch
@@ -718,7 +802,13 @@ static void launch_conv_dma(const ConvArgs& a, hipStream_t st) {
     AUR_REQUIRE(a.Cin / 16 >= NBUF - 1, "conv dma: fewer input-channel chunks than the prefetch depth");
     trace_launch("conv1d_dma_f16_kernel");
     const int n_q = a.ups_s ? a.max_len + 1 : a.max_len;
-    if (a.Mtot % 64 == 0) {
+    const bool all_halves = a.ups_s == 0 && (!a.res || a.res_f16) && (a.mrf_mode == 0 || a.mrf_f16) &&
+                            ((a.mrf_mode == 1 || a.mrf_mode == 2) || a.out_act_f16);
+    if (a.Mtot % 64 == 0 && conv_dma_waves() == 8 && KS >= 3 && all_halves) {
+        constexpr int NB8 = KS >= 7 ? 2 : 3;
+        dim3 grid((n_q + 511) / 512, a.Mtot / 64, a.B);
+        hipLaunchKernelGGL((conv1d_dma_f16_kernel<KS, DIL, 64, NB8, 8, true>), grid, dim3(512), 0, st, a);
+    } else if (a.Mtot % 64 == 0) {
         dim3 grid((n_q + 255) / 256, a.Mtot / 64, a.B);
         hipLaunchKernelGGL((conv1d_dma_f16_kernel<KS, DIL, 64, NBUF>), grid, dim3(256), 0, st, a);
     } else {
@@ -761,6 +851,7 @@ __global__ __launch_bounds__(64 * (C / 32) * (NT1 / 32 / WN)) void resblock_roun
     const unsigned xs_l = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)xs;
     const unsigned ws_l = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)&ws[0][0];
 
+    // (a deeper weight ring -- chunk g + 3 requested when chunk g starts, counted waits -- measured no gain: DESIGN section 7)
     auto issue_w = [&](int g) {   // weight chunk g of the sequence conv1[0..NCH), conv2[0..NCH) into buffer g & 1
         const char* src0 = reinterpret_cast<const char*>(g < NCH ? a.w1 : a.w2) + (long)(g < NCH ? g : g - NCH) * WCH;
         for (int ii = wvs; ii < WI; ii += NW) {
@@ -903,6 +994,10 @@ static void launch_round_c(const RoundArgs& a, hipStream_t st) {
     // 64 channels, k = 3 / 7: 128-position tiles (8 waves of 32 channels x 32 positions, <= 69 KB of LDS) so that two workgroups
     // share a CU -- 15.6 vs 16.4 ms for the stage; k = 11 needs 120 KB either way and keeps 256 positions (64 per wave).
     // 32 channels: 256 positions, 32 per wave (9.6 vs 10.1 ms with 64 per wave).
+    // Round 5, measured on these two stages and not kept (conv time per 64 utterances, same box): one 16-wave workgroup
+    // per CU on twice the positions -- half the weight re-streaming per position, one barrier domain -- 63.2 vs 62.3 ms (32-channel class
+    // 0.199 vs 0.215 of the matrix peak); two position tiles = two independent accumulators per wave on half the waves per workgroup
+    // (VERDICT r04 3 i) 62.7 vs 61.7; a four-deep weight ring with counted waits 62.6 vs 62.2.
     if (a.C == 64 && KS < 11) {
         constexpr int nt2 = 128 - (KS - 1);
         hipLaunchKernelGGL((resblock_round_f16_kernel<KS, DIL, 64, 1, 128>), dim3((a.max_len + nt2 - 1) / nt2, a.B), dim3(512), 0, st, a);

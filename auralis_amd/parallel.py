@@ -48,31 +48,40 @@ def comm_init_agreed(engine, device: Optional[torch.device] = None) -> str:
     """Build the engine's own RCCL communicator on every rank (aur_comm_init; torch.distributed only carries the 128-byte id)
     and AGREE on the outcome with one all_reduce: returns "" on every rank iff every rank's communicator is up, otherwise the
     same non-empty reason on every rank.  Nothing enters a collective of the new communicator before this agreement, so a rank
-    whose aur_comm_init raised cannot leave the others waiting inside ncclBroadcast.  Collective; idempotent per engine."""
+    whose aur_comm_init raised cannot leave the others waiting inside ncclBroadcast.  Collective on its first call per engine; later
+    calls return the agreed outcome."""
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
+    # the outcome of the first call is shared by construction (it was all-reduced), so later calls take the same branch on every
+    # rank without a collective: up everywhere, or failed everywhere (a communicator that is up on SOME ranks is useless)
+    if getattr(engine, "_comm_ready", False):
+        return ""
+    if getattr(engine, "_comm_failed", ""):
+        return engine._comm_failed
     err = ""
-    if not getattr(engine, "_comm_ready", False):
-        uid = None
-        if rank == 0:   # a failure to create the id must not leave the other ranks waiting in the broadcast below
-            try:
-                uid = type(engine).comm_unique_id()
-            except Exception as ex:   # noqa: BLE001 - reported on every rank
-                uid = ex
-        ids = [uid]
-        dist.broadcast_object_list(ids, src=0)
-        if isinstance(ids[0], Exception):
-            err = f"rank 0 could not create the RCCL communicator id: {ids[0]}"
-        else:
-            try:
-                engine.comm_init(ids[0], rank, world)
-                engine._comm_ready = True
-            except Exception as ex:   # noqa: BLE001 - agreed on below
-                err = f"rank {rank}: aur_comm_init: {type(ex).__name__}: {ex}"
+    uid = None
+    if rank == 0:   # a failure to create the id must not leave the other ranks waiting in the broadcast below
+        try:
+            uid = type(engine).comm_unique_id()
+        except Exception as ex:   # noqa: BLE001 - reported on every rank
+            uid = ex
+    ids = [uid]
+    dist.broadcast_object_list(ids, src=0)
+    if isinstance(ids[0], Exception):
+        err = f"rank 0 could not create the RCCL communicator id: {ids[0]}"
+    else:
+        try:
+            engine.comm_init(ids[0], rank, world)
+        except Exception as ex:   # noqa: BLE001 - agreed on below
+            err = f"rank {rank}: aur_comm_init: {type(ex).__name__}: {ex}"
     bad = torch.tensor([1 if err else 0], dtype=torch.int32, device=device or torch.device("cpu"))
     dist.all_reduce(bad, op=dist.ReduceOp.MAX)
     if int(bad.item()) and not err:
         err = "aur_comm_init failed on another rank"
+    if err:
+        engine._comm_failed = err
+    else:
+        engine._comm_ready = True
     return err
 
 

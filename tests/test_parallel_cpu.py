@@ -60,3 +60,72 @@ def test_broadcast_conditioning_gloo_world2(tmp_path):
         assert np.allclose(z["s"].reshape(-1), np.linspace(0, 1, 512, dtype=np.float32))
         assert z["order"].tolist() == list(range(10))
         assert bool(z["same"]) and not bool(z["differ"])
+
+
+class _CommEngine:
+    """Stand-in for NativeEngine's communicator calls: comm_init fails on the ranks named in `bad`."""
+    bad = ()
+
+    def __init__(self, rank):
+        self.rank, self.inits, self.bcasts = rank, 0, []
+
+    @staticmethod
+    def comm_unique_id():
+        return b"\x01" * 128
+
+    def comm_init(self, uid, rank, world):
+        assert uid == b"\x01" * 128
+        self.inits += 1
+        if rank in self.bad:
+            raise RuntimeError("aur_comm_init: injected failure")
+
+    def set_conditioning(self, key, g, s):
+        pass
+
+    def broadcast_conditioning(self, key, src):
+        self.bcasts.append((key, src))
+
+
+def _agree_worker(rank, world, port, out_dir, bad):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from auralis_amd.parallel import broadcast_conditioning_native, comm_init_agreed
+    _CommEngine.bad = tuple(bad)
+    eng = _CommEngine(rank)
+    err = comm_init_agreed(eng)
+    err2 = comm_init_agreed(eng)            # idempotent: a communicator that is up is not built twice
+    entered = False
+    try:
+        g = torch.zeros(1, 32, 1024) if rank == 0 else None
+        s = torch.zeros(1, 512, 1) if rank == 0 else None
+        broadcast_conditioning_native(eng, 5, g, s, src=0)
+        entered = True
+    except RuntimeError:
+        pass
+    with open(os.path.join(out_dir, f"a{rank}.txt"), "w") as f:
+        f.write(f"{err}|{err2}|{int(entered)}|{len(eng.bcasts)}|{eng.inits}")
+    dist.destroy_process_group()
+
+
+def test_native_route_is_entered_only_when_every_rank_built_its_communicator(tmp_path):
+    """parallel.comm_init_agreed: the ranks all-reduce the outcome of aur_comm_init BEFORE any of them enters ncclBroadcast -- with a
+    failure injected on rank 1 every rank gets a non-empty reason and NO rank calls aur_broadcast_conditioning (a rank that
+    entered the collective alone would hang there); with no failure every rank enters it exactly once."""
+    for bad, sub in (((1,), "bad"), ((), "ok")):
+        d = tmp_path / sub
+        d.mkdir()
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        mp.spawn(_agree_worker, args=(2, port, str(d), list(bad)), nprocs=2, join=True)
+        for r in range(2):
+            err, err2, entered, n_bcast, inits = (d / f"a{r}.txt").read_text().split("|")
+            if bad:
+                assert err and err2, (r, err)
+                assert ("rank 1" in err) == (r == 1) and ("another rank" in err) == (r == 0)
+                assert entered == "0" and n_bcast == "0"
+            else:
+                assert err == "" and err2 == "" and entered == "1" and n_bcast == "1" and inits == "1"
+            if bad:
+                assert inits == "1"   # the agreed failure is remembered: nobody re-enters the id exchange alone
