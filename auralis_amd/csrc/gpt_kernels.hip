@@ -1266,7 +1266,9 @@ __device__ __forceinline__ float block_sum_tree(float v, float* sv) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
+// (the arguments the kernel needs first -- the row's slot, its logits -- are leading scalars: preloaded SGPRs, item 7 of DESIGN section 3)
+__global__ __launch_bounds__(256) void sampler_kernel(const int* __restrict__ sample_slot_, const float* __restrict__ P_, const float* __restrict__ bias_,
+                                                      int Npad_, int V_, int S_, int Ms_, SamplerArgs a) {
     __shared__ float z[1040];
     __shared__ unsigned long long keys[2048];
     __shared__ float sv[256];
@@ -1275,8 +1277,8 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
     __shared__ int sh_i[2];
     const int j = blockIdx.x;
     const int tid = threadIdx.x;
-    const int slot = a.sample_slot[j];
-    const int V = a.V;
+    const int slot = sample_slot_[j];
+    const int V = V_;
     // every per-slot parameter in ONE burst of scalar loads (hipcc sinks each to its first use otherwise: a dependent round trip in
     // front of the penalty loop, another in front of the temperature division, the top-k search, the top-p scan, the noise ...)
     const int finished = a.slot_finished[slot];
@@ -1305,8 +1307,8 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
             const int v = min(tid + 256 * u, V - 1);
-            pv[u] = a.P[(long)j * a.Npad + v];
-            bv[u] = a.bias[v];
+            pv[u] = P_[(long)j * Npad_ + v];
+            bv[u] = bias_[v];
             sn[u] = seen[v];
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1315,7 +1317,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
             const int v = tid + 256 * u;
             if (v < V) {
                 float s = pv[u];
-                for (int sl = 1; sl < a.S; ++sl) s += a.P[((long)sl * a.Ms + j) * a.Npad + v];   // (prefill-time callers; S == 1 on the decode path)
+                for (int sl = 1; sl < S_; ++sl) s += P_[((long)sl * Ms_ + j) * Npad_ + v];   // (prefill-time callers; S == 1 on the decode path)
                 s += bv[u];
                 if (pen != 1.0f && sn[u]) s = (s > 0.f) ? s / pen : s * pen;
                 z[v] = s;
@@ -1483,7 +1485,26 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a) {
         // only adds -- until round 5 it evaluated 2 n1 expf and n1 divisions one after the other (~7 us of the kernel's 27).
         // Same operands into the same additions in the same order: the same bits.
         if (topp < 1.0f) {
-            if (n1 <= 256) {
+            if (n1 <= 64) {
+                // the usual case (k = 50 plus ties): one wave does all of it in registers, no LDS and no barrier -- the serial float
+                // sum runs over v_readlane values in rank order (ranks >= n1 hold +0: adding them changes no bit)
+                if (tid < 64) {
+                    const float ev = tid < n1 ? expf(ord2f((unsigned)(keys[min(tid, n1 - 1)] >> 32)) - maxv) : 0.f;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 64; ++r) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ev), r));
+                    const float pr = ev / sum;
+                    double c = tid < n1 ? (double)pr : 0.0;
+#pragma unroll
+                    for (int sh = 1; sh < 64; sh <<= 1) {   // inclusive suffix scan: lane l += lane l + sh
+                        const int lo32 = __shfl_down((int)(unsigned)__double_as_longlong(c), sh, 64);
+                        const int hi32 = __shfl_down((int)(unsigned)(__double_as_longlong(c) >> 32), sh, 64);
+                        const double o = __longlong_as_double(((long long)hi32 << 32) | (unsigned)lo32);
+                        if (tid + sh < 64) c += o;
+                    }
+                    if (tid >= 1 && tid < n1 && (float)c <= 1.0f - topp) z[(unsigned)(keys[tid] & 0xffffffffull)] = -INFINITY;
+                }
+            } else if (n1 <= 256) {
                 const float ev = tid < n1 ? expf(ord2f((unsigned)(keys[min(tid, n1 - 1)] >> 32)) - maxv) : 0.f;
                 sv[tid] = ev;
                 __syncthreads();
@@ -1579,7 +1600,7 @@ void launch_count_mismatch(const void* x, const void* y, long n_words, unsigned 
 void launch_sampler(const SamplerArgs& a, hipStream_t st) {
     AUR_REQUIRE(a.V <= 1040, "sampler: V <= 1040");
     trace_launch("sampler_kernel");
-    hipLaunchKernelGGL(sampler_kernel, dim3(a.Ms), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(sampler_kernel, dim3(a.Ms), dim3(256), 0, st, a.sample_slot, a.P, a.bias, a.Npad, a.V, a.S, a.Ms, a);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -997,7 +997,10 @@ static void launch_round_c(const RoundArgs& a, hipStream_t st) {
     // Round 5, measured on these two stages and not kept (conv time per 64 utterances, same box): one 16-wave workgroup
     // per CU on twice the positions -- half the weight re-streaming per position, one barrier domain -- 63.2 vs 62.3 ms (32-channel class
     // 0.199 vs 0.215 of the matrix peak); two position tiles = two independent accumulators per wave on half the waves per workgroup
-    // (VERDICT r04 3 i) 62.7 vs 61.7; a four-deep weight ring with counted waits 62.6 vs 62.2.
+    // (VERDICT r04 3 i) 62.7 vs 61.7; a four-deep weight ring with counted waits 62.6 vs 62.2; the weights as A fragments straight from
+    // global memory into registers, one chunk ahead, no weight buffers in LDS and two barriers per tile instead of one per chunk
+    // (every wave of a channel group re-reads the same lines through the L1) 64.3 vs 61.0 (64-channel class 0.236 vs 0.265, 32-channel
+    // 0.190 vs 0.216), bitwise equal.
     if (a.C == 64 && KS < 11) {
         constexpr int nt2 = 128 - (KS - 1);
         hipLaunchKernelGGL((resblock_round_f16_kernel<KS, DIL, 64, 1, 128>), dim3((a.max_len + nt2 - 1) / nt2, a.B), dim3(512), 0, st, a);

@@ -599,7 +599,26 @@ def main():
         # under a watchdog: a rank stuck in it cannot be recovered, the run then ends with a diagnostic on stderr.
         import threading
         from auralis_amd.parallel import broadcast_conditioning_native, comm_init_agreed
-        err = comm_init_agreed(eng, dev)
+
+        def watched(fn, what):   # run a step that contains a collective under the watchdog; a rank stuck inside it cannot be recovered
+            box = {}
+
+            def run():
+                try:
+                    box["v"] = fn()
+                except Exception as ex:   # noqa: BLE001 - handed back to the caller
+                    box["e"] = ex
+            th = threading.Thread(target=run, daemon=True)
+            th.start()
+            th.join(args.native_check_timeout)
+            if th.is_alive():
+                _log(f"rank {rank}: {what} did not return within {args.native_check_timeout:.0f} s; re-run with --bcast torch")
+                sys.stderr.flush()
+                os._exit(3)
+            if "e" in box:
+                raise box["e"]
+            return box.get("v")
+        err = watched(lambda: comm_init_agreed(eng, dev), "aur_comm_init (ncclCommInitRank on the engine's communicator)")
         multi["native_route_failed"] = False
         if err:
             if route == "native":
@@ -609,21 +628,12 @@ def main():
             route = "torch"
         else:
             res = {}
-
-            def native_bcast():
-                try:
-                    broadcast_conditioning_native(eng, SPK, B.cond if rank == 0 else None, B.spk if rank == 0 else None, src=0, device=dev)
-                    res["ok"] = True
-                except Exception as ex:   # noqa: BLE001 - agreed on below
-                    res["err"] = f"{type(ex).__name__}: {ex}"
-            th = threading.Thread(target=native_bcast, daemon=True)
-            th.start()
-            th.join(args.native_check_timeout)
-            if th.is_alive():
-                _log(f"rank {rank}: ncclBroadcast on the engine's communicator did not return within {args.native_check_timeout:.0f} s; "
-                     "re-run with --bcast torch")
-                sys.stderr.flush()
-                os._exit(3)
+            try:
+                watched(lambda: broadcast_conditioning_native(eng, SPK, B.cond if rank == 0 else None, B.spk if rank == 0 else None, src=0,
+                                                              device=dev), "ncclBroadcast on the engine's communicator")
+                res["ok"] = True
+            except Exception as ex:   # noqa: BLE001 - agreed on below
+                res["err"] = f"{type(ex).__name__}: {ex}"
             bad = torch.tensor([0 if res.get("ok") else 1], device=dev, dtype=torch.int32)
             torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX)
             if int(bad.item()):   # the collective returned an error somewhere: the voice is re-sent by the torch route on every rank
