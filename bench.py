@@ -605,6 +605,7 @@ def main():
 
             def run():
                 try:
+                    torch.cuda.set_device(local_rank)   # the current device is per thread: object collectives stage through it
                     box["v"] = fn()
                 except Exception as ex:   # noqa: BLE001 - handed back to the caller
                     box["e"] = ex
@@ -773,6 +774,7 @@ def main():
 
         def native():
             try:
+                torch.cuda.set_device(local_rank)   # per thread
                 broadcast_conditioning_native(eng, SPK + 1, B.cond if rank == 0 else None, B.spk if rank == 0 else None, src=0, device=dev)
                 res["ranks"], res["rank0"] = eng.comm_info()
                 res["same_bytes"] = eng.conditioning_checksum(SPK + 1) == eng.conditioning_checksum(SPK)
