@@ -66,7 +66,7 @@ def comm_init_agreed(engine, device: Optional[torch.device] = None) -> str:
         except Exception as ex:   # noqa: BLE001 - reported on every rank
             uid = ex
     ids = [uid]
-    dist.broadcast_object_list(ids, src=0)
+    dist.broadcast_object_list(ids, src=0, **({"device": device} if device is not None and device.type != "cpu" else {}))
     if isinstance(ids[0], Exception):
         err = f"rank 0 could not create the RCCL communicator id: {ids[0]}"
     else:
