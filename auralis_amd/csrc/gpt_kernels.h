@@ -82,9 +82,9 @@ struct GemmRowsArgs {
     unsigned* ksp_cnt;   // [tiles], zero before the first launch (the last arriver resets its counter)
 };
 // The kernel-side remainder of GemmRowsArgs: what the kernel needs only after its first tile loads are in flight (the leading
-// scalar kernel arguments -- Wt, X, M, N, xmt, omt, bias, ln_c1, out -- are preloaded into SGPRs, gemm_rows_kernel.inc).
+// scalar kernel arguments -- Wt, X, bias, ln_c1, out, stats_in and M, N, xmt, omt packed into two dwords -- are preloaded into SGPRs,
+// gemm_rows_kernel.inc).
 struct GemmRowsTail {
-    const float2* stats_in;
     float2* stats_out;
     const int* row_meta;
     void* kv_layer;

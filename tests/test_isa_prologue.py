@@ -34,7 +34,7 @@ def test_gemm_rows_requests_its_first_weight_tile_without_waiting_for_anything(a
     for name, body in ks:
         p = isa_skeleton.prologue(body)
         assert p["found_data_load"], name
-        assert p["preload_dwords"] == 14, (name, p)   # Wt, X, M, N, xmt, omt, bias, ln_c1, out
+        assert p["preload_dwords"] == 14, (name, p)   # Wt, X, bias, ln_c1, out, stats_in, M | N/16, xmt | omt
         # nothing between the entry and the first global_load_dwordx4: no kernel-argument round trip, no wait on the small
         # epilogue-input loads issued first, no barrier
         assert p["scalar_waits"] == 0 and p["vector_waits"] == 0 and p["barriers"] == 0, (name, p)

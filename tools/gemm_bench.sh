@@ -11,7 +11,11 @@ $CC -mllvm -amdgpu-kernarg-preload-count=16 tools/gemm_bench.hip -o /tmp/gemm_be
 BINS="/tmp/gemm_bench"
 if [ -n "$GEMM_BENCH_AB" ]; then
   $CC tools/gemm_bench.hip -o /tmp/gemm_bench_nopreload && BINS="$BINS /tmp/gemm_bench_nopreload"
-  if [ -f tools/_r04/gemm_bench.hip ]; then (cd tools/_r04 && $CC gemm_bench.hip -o /tmp/gemm_bench_r04) && BINS="$BINS /tmp/gemm_bench_r04"; fi
+  if [ -f tools/_r04/gemm_bench.hip ]; then
+    (cd tools/_r04 && $CC gemm_bench.hip -o /tmp/gemm_bench_r04) && BINS="$BINS /tmp/gemm_bench_r04"
+    # the same round-4 kernels with tile loads and MFMAs compiled out (tools/_r04 carries an R04_NODATA guard around them)
+    grep -q R04_NODATA tools/_r04/gpt_kernels.hip && (cd tools/_r04 && $CC -DR04_NODATA gemm_bench.hip -o /tmp/gemm_bench_r04_nodata) && BINS="$BINS /tmp/gemm_bench_r04_nodata"
+  fi
 fi
 for M in ${@:-64}; do for B in $BINS; do echo "=== $B M=$M"; timeout 180 $B $M; done; done > gpurun_out/gemm_bench_$TAG.log 2>&1
 echo "gemm_bench rc=$?"; cat gpurun_out/gemm_bench_$TAG.log
