@@ -5,9 +5,9 @@ exec < /dev/null
 TAG=${1:-r05sqc}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --list-avail 2>/dev/null | grep -o "SQC_[A-Z_]*" | sort -u | tr '\n' ' ' | cut -c1-1500; echo
 i=0
-for pass in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE"; do
+for pass in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE" \
+            "SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES"; do
   i=$((i+1)); OUT=$R/gpurun_out/pmc_$TAG/sqc$i; mkdir -p $OUT
   timeout 200 rocprofv3 --pmc $pass --kernel-include-regex "${PMC_KERNELS:-paged_attention_kernel|gemm_rows_kernel}" --output-format csv -d $OUT -o pmc -- \
       python $R/bench.py --steps 1 --warmup 0 --tokens 40 --no-cpu-baseline --no-side --no-profile-pass --out /tmp/pmc_bench_full.json > $OUT/stdout.log 2>&1
