@@ -183,6 +183,7 @@ public:
         const int S = cfg_.max_seqs;
         n_blocks_ = (long)S * kMaxBlocks + 2L * cfg_.max_speakers;   // + 2 shared prefix blocks per speaker
         kv_layer_stride_ = n_blocks_ * kKvBlockElems;
+        AUR_REQUIRE(n_blocks_ <= kMaxKvBlocksPerLayer, "K/V pool: at most 32767 blocks (4 GiB of fp32 K/V) per layer -- lower max_seqs");
         kv_half_ = cfg_.kv_fp16 != 0;
         gemm_prec_ = cfg_.gemm_f32_exact ? 0 : 1;
         kv_.ensure((size_t)cfg_.n_layer * kv_layer_stride_ * (kv_half_ ? 2 : 4));

@@ -8,6 +8,7 @@ constexpr int kHidden = 1024;
 constexpr int kHeads = 16;
 constexpr int kHeadDim = 64;
 constexpr int kKvBlockTokens = 16;                                    // paged-KV block size (vLLM default)
+constexpr long kMaxKvBlocksPerLayer = 32767;                            // paged_attention_kernel addresses a layer's pool with 32-bit byte offsets (128 KiB per fp32 block)
 constexpr long kKvBlockElems = 2L * kHeads * kKvBlockTokens * kHeadDim;  // one layer, K and V
 
 // Optional bias + GELU epilogue of the prefill FC GEMM: act[m][n] = gelu(total + bias[n]) is written instead of the slab.

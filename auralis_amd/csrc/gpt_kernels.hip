@@ -733,42 +733,54 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const int* __restr
         }
     }
     const int n_keys = pos + 1;
-    const KT* kv_layer = reinterpret_cast<const KT*>(kv_layer_v);
 
     // UN steps unrolled: all 2*UN K/V loads of a lane are issued before the first softmax update (addresses are clamped instead
     // of predicated so that the loads can be hoisted).
     // (the fp16 pool's values stay packed, 4 registers per 8 halves, until they are used: as floats they cost 104 VGPRs)
     using RawT = typename std::conditional<KVH, h16x8g, f32x4>::type;
     RawT kraw[UN], vraw[UN];
+    // Addresses as 32-bit BYTE offsets from the layer's K base and V base (two SGPR pairs): the fields of
+    // [block][K|V][head][token][64] do not overlap, so an offset is (block << kBlkSh) | lane part, and the lane part -- head, the
+    // token slot inside its block, the lane's 16 bytes of the row -- is the same for every step and every iteration, because a step
+    // starts at a multiple of 16 tokens (4 * TPW * u + t0) and a wave covers TPW consecutive ones.  Per step that leaves one scalar
+    // shift, an OR, a compare and a select, against the 22 VALU instructions (64-bit multiplies-by-shift, a signed modulo) hipcc
+    // made of kv_offset(): 115 -> 40 instructions in front of the eighth request of a launch whose instruction cache is cold, and a
+    // shorter loop.  A layer's pool therefore has to stay below 4 GiB (kMaxKvBlocksPerLayer; the engine checks it when it sizes the pool).
+    constexpr int kBlkSh = KVH ? 16 : 17;                                   // log2(bytes of one block: K and V, 16 heads x 16 tokens x 64)
+    constexpr unsigned kVOff = 1u << (kBlkSh - 1);                          // bytes from a block's K half to its V half
+    static_assert(sizeof(KT) * 2 * kHeads * kKvBlockTokens * kHeadDim == (1u << kBlkSh) && kKvBlockTokens == 16, "paged K/V layout");
+    const char* const kbase = reinterpret_cast<const char*>(kv_layer_v);
+    const char* const vbase = kbase + kVOff;
+    const unsigned row_bytes = kHeadDim * sizeof(KT);                       // one token of one head
+    const unsigned lane_off = (unsigned)head * (kKvBlockTokens * row_bytes) + (unsigned)dl * (EPL * (unsigned)sizeof(KT));
+    // token slot of this lane inside its block, for every step: (wv * TPW + g) mod 16 (fp16 pool: TPW = 8, waves 2 and 3 start at slot 0 / 8 of the next block)
+    const unsigned own_off = lane_off + (unsigned)((wv * TPW + g) & (kKvBlockTokens - 1)) * row_bytes;
     auto load_kv = [&](int t0) {
+        // (a lane past the end of the context reads the row's last token: clamped to the context, not to the table -- making the
+        // address independent of the row's position made the masked lanes fetch real, distinct rows: 24.2 vs 22.6 us per launch)
+        const unsigned last_off = ((unsigned)wblk << kBlkSh) + lane_off + (unsigned)(pos & (kKvBlockTokens - 1)) * row_bytes;
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            // (clamped to the context, not to the table: making the address independent of the row's position -- one dependent load
-            // less in front of the first K/V loads -- made the masked lanes fetch real, distinct rows: 24.2 vs 22.6 us per launch)
             const int traw = t0 + 4 * TPW * u + wv * TPW + g;
             // block of this step inside the iteration: (4 TPW u + TPW wv) / 16 -- u for the fp32 pool, 2 u + (wv >> 1) for fp16
             const int blk_u = KVH ? ((wv >> 1) ? ids[(2 * u + 1) % NBI] : ids[(2 * u) % NBI]) : ids[u % NBI];
-            const bool past = traw > pos;
-            const int blk = past ? wblk : blk_u;
-            const int tok = (past ? pos : traw) % kKvBlockTokens;
-            const long off = kv_offset(blk, 0, head, tok) + dl * EPL;
-            kraw[u] = *reinterpret_cast<const RawT*>(kv_layer + off);
-            vraw[u] = *reinterpret_cast<const RawT*>(kv_layer + off + (long)kHeads * kKvBlockTokens * kHeadDim);
+            const unsigned off = traw > pos ? last_off : (((unsigned)blk_u << kBlkSh) | own_off);
+            kraw[u] = *reinterpret_cast<const RawT*>(kbase + off);
+            vraw[u] = *reinterpret_cast<const RawT*>(vbase + off);
         }
         __builtin_amdgcn_sched_barrier(0);   // all 2 * UN requests leave before the first score (hipcc otherwise starts step 0's arithmetic, and its wait, in front of the last loads)
     };
-    load_kv(0);
-    load_ids(STEP);   // one iteration ahead: the scalar round trip of iteration i + 1 runs under the K/V loads of iteration i
     float mi = -INFINITY, li = 0.f;
     float o[EPL];
 #pragma unroll
     for (int c = 0; c < EPL; ++c) o[c] = 0.f;
     int t0 = 0;
-    do {   // (n_keys >= 1: a for loop lets hipcc sink the first loads under the loop guard, i.e. behind the round trip for `pos`)
-        if (t0 > 0) {
-            load_kv(t0);
-            load_ids(t0 + STEP);
-        }
+    // (n_keys >= 1, hence do-while: there is no guard for hipcc to sink the first loads under.  ONE copy of the body: with the first
+    // iteration's loads issued in front of the loop -- `if (t0 > 0) load` inside -- hipcc peeled the whole iteration, and a launch
+    // fetched both copies through its cold instruction cache: 6.7 KB of code, now 3.5)
+    do {
+        load_kv(t0);
+        load_ids(t0 + STEP);   // one iteration ahead: the scalar round trip of iteration i + 1 runs under the K/V loads of iteration i
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int t = t0 + 4 * TPW * u + wv * TPW + g;
@@ -785,8 +797,21 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const int* __restr
             }
             float sc = (qv[0] * kx[0] + qv[1] * kx[1]) + (qv[2] * kx[2] + qv[3] * kx[3]);
             if constexpr (EPL == 8) sc += (qv[4] * kx[4] + qv[5] * kx[5]) + (qv[6] * kx[6] + qv[7] * kx[7]);
+            if constexpr (LPT == 16) {
+                // the butterfly sc += sc[lane ^ 8], ^ 4, ^ 2, ^ 1 over the token's 16 lanes (= one DPP row) as four v_add_f32_dpp
+                // instead of four ds_bpermute round trips through the LDS crossbar: lane ^ 8 is a row rotation by 8; after it the
+                // values are invariant under ^ 8, so the rotation by 4 delivers sc[lane ^ 4] (or its equal sc[lane ^ 4 ^ 8]);
+                // ^ 2 and ^ 1 are quad permutations.  Same operand pairs in the same order: bitwise the shuffle version.
+#define AUR_DPP_ADD(ctrl) sc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sc), (ctrl), 0xF, 0xF, false))
+                AUR_DPP_ADD(0x128);   // row_ror:8
+                AUR_DPP_ADD(0x124);   // row_ror:4
+                AUR_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+                AUR_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+#undef AUR_DPP_ADD
+            } else {
 #pragma unroll
-            for (int sh = LPT / 2; sh > 0; sh >>= 1) sc += __shfl_xor(sc, sh, 64);
+                for (int sh = LPT / 2; sh > 0; sh >>= 1) sc += __shfl_xor(sc, sh, 64);
+            }
             sc *= 0.125f;   // 1/sqrt(64)
             if (valid) {
                 const float mn = fmaxf(mi, sc);
@@ -813,7 +838,9 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const int* __restr
 #pragma unroll
         for (int p = 0; p < NP; ++p) mx = fmaxf(mx, part_m[p]);
         float L = 0.f, O = 0.f;
-#pragma unroll
+        // (rolled: NP copies of expf are 1.6 KB of straight-line code that one wave per workgroup would pull through the cold
+        // instruction cache at the very end of the launch; the order of the sum is the unrolled one)
+#pragma unroll 1
         for (int p = 0; p < NP; ++p) {
             const float w = expf(part_m[p] - mx);
             L += part_l[p] * w;

@@ -49,7 +49,9 @@ def test_decode_attention_is_one_scalar_round_trip_away_from_its_first_kv_load(a
     p = isa_skeleton.prologue(body, skip=q_loads)   # the q row is requested first; look at what precedes the first K/V load
     assert p["found_data_load"] and p["preload_dwords"] >= 9, p
     # one trip: the row's position, write block and first block ids, fetched together (scalar loads out of row_meta)
-    assert p["scalar_waits"] <= 1 and p["vector_waits"] == 0 and p["barriers"] == 0, (name, p)
+    # (the loop header carries a second s_waitcnt for the ids requested one iteration ahead: nothing is outstanding when the first
+    # iteration reaches it)
+    assert p["scalar_round_trips"] <= 1 and p["vector_waits"] == 0 and p["barriers"] == 0, (name, p)
     assert p["flat_loads"] == 0
     # all 2 * UN K/V requests of an iteration leave before the first wait on any of them (round 5: hipcc had sunk one V load into
     # the branch that uses it, behind a vmcnt(0))

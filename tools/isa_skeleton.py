@@ -22,7 +22,7 @@ Runs are counted (M24 = 24 MFMAs in a row).  What to look for:
   * an `L` inside a `|...|` block that follows a `[Wn]` of the same iteration: hipcc sinks a load into the only branch that uses
     its result (round 5: the V load of the decode attention, one dependent round trip per 64 tokens).
 
-`prologue(body)` returns what tests/test_isa_prologue.py asserts on: the scalar waits, vector waits, barriers and flat loads between
+`prologue(body)` returns what tests/test_isa_prologue.py asserts on: the scalar round trips (waits with a scalar load outstanding), scalar waits, vector waits, barriers and flat loads between
 the kernel's real entry (behind the preload prologue) and its first wide data load."""
 import os
 import re
@@ -102,8 +102,20 @@ def prologue(body: str, skip: int = 0) -> dict:
     wide = [i for i in range(start, len(seq)) if seq[i] == "L4"]
     first = wide[skip] if len(wide) > skip else len(seq)
     pre = seq[start:first]
+    # a scalar wait costs a round trip only when a scalar load is outstanding beyond what it lets pass (a wait at a loop header that
+    # the first iteration reaches with nothing in flight is free)
+    pending = trips = 0
+    for x in pre:
+        if x == "k":
+            pending += 1
+        elif x.startswith("K"):
+            n = int(x[1:])
+            if pending > n:
+                trips += 1
+                pending = n
     return {
         "preload_dwords": int(preload[0]) if preload else 0,
+        "scalar_round_trips": trips,
         "scalar_waits": sum(1 for x in pre if x.startswith("K")),
         "scalar_loads": sum(1 for x in pre if x == "k"),
         "vector_waits": sum(1 for x in pre if x.startswith("W")),
