@@ -833,16 +833,29 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const int* __restr
         part_l[pidx] = li;
     }
     __syncthreads();
-    if (threadIdx.x < kHeadDim) {
-        float mx = -INFINITY;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) mx = fmaxf(mx, part_m[p]);
+    if (threadIdx.x < kHeadDim) {   // wave 0
+        // The NP group weights exp(m_p - max) ONCE, in parallel: lane p computes weight p (one expf in the code instead of NP copies
+        // -- 1.6 KB of straight-line code one wave would pull through the cold instruction cache at the very end of the launch -- or
+        // NP serial trips through a rolled loop), the wave exchanges them through LDS (same wave: LDS operations execute in order,
+        // no barrier), and every lane then sums its output column in the order p = 0 .. NP - 1 as before: same values, same order.
+        static_assert(NP == 16 || NP == 32, "merge: one lane per partial group");
+        const float pm = part_m[lane & (NP - 1)];
+        float mx = pm;
+#define AUR_DPP_MAX(ctrl) mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), (ctrl), 0xF, 0xF, false)))
+        AUR_DPP_MAX(0x128);   // row_ror:8, 4, 2, 1: the maximum of every 16-lane row in all of its lanes
+        AUR_DPP_MAX(0x124);
+        AUR_DPP_MAX(0x122);
+        AUR_DPP_MAX(0x121);
+#undef AUR_DPP_MAX
+        if constexpr (NP == 32) mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        if (lane < NP) part_m[lane] = expf(pm - mx);   // (every lane of the wave has read its part_m element above)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         float L = 0.f, O = 0.f;
-        // (rolled: NP copies of expf are 1.6 KB of straight-line code that one wave per workgroup would pull through the cold
-        // instruction cache at the very end of the launch; the order of the sum is the unrolled one)
-#pragma unroll 1
+#pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const float w = expf(part_m[p] - mx);
+            const float w = part_m[p];
             L += part_l[p] * w;
             O += part_o[p][threadIdx.x] * w;
         }

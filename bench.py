@@ -301,11 +301,29 @@ class Bench:
         total = 0
         groups = [list(keys)] if a.pipeline else [[k] for k in keys]
         for grp in groups:
+            t_grp = time.perf_counter()
             for k in grp:
                 for b in range(batch):
                     eng.submit(self.text_ids, self.SPK, temperature=0.75 if sampled else 0.0, top_p=0.85, top_k=50, repetition_penalty=5.0,
                                max_tokens=a.tokens, seed=(self.rank * 100003 + (k + 7) * 1009 + b), ignore_stop=True)
-            outs = eng.run_until_done(max_steps=len(grp) * (a.tokens + 16) + 64, copy=False)
+            if os.environ.get("AUR_BENCH_STEP_TRACE"):   # host time of every aur_step of the batch: where the wall time outside the GPU phases goes
+                outs, marks, t_sub = [], [], time.perf_counter()
+                while True:
+                    t0 = time.perf_counter()
+                    live, fin = eng.step()
+                    t1 = time.perf_counter()
+                    got = eng.poll(cap=64, copy=False) if fin or live == 0 else []
+                    outs.extend(got)
+                    marks.append((t1 - t0, time.perf_counter() - t1, live, len(got)))
+                    if live == 0:
+                        break
+                tot = time.perf_counter() - t_sub
+                mid = sorted(m[0] for m in marks[2:-4])
+                _log(f"step trace: submits {(t_sub - t_grp) * 1e3:.2f} ms; {len(marks)} aur_step calls in {tot * 1e3:.2f} ms; first two {marks[0][0] * 1e3:.2f} / {marks[1][0] * 1e3:.2f} ms, "
+                     f"median of the middle {mid[len(mid) // 2] * 1e3:.3f} ms (sum {sum(mid) * 1e3:.1f}), last four "
+                     + " / ".join(f"{m[0] * 1e3:.2f}+poll {m[1] * 1e3:.2f} (live {m[2]}, got {m[3]})" for m in marks[-4:]))
+            else:
+                outs = eng.run_until_done(max_steps=len(grp) * (a.tokens + 16) + 64, copy=False)
             assert len(outs) == batch * len(grp)
             total += sum(len(o["wav"]) for o in outs)
             for o in outs:

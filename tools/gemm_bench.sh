@@ -17,5 +17,15 @@ if [ -n "$GEMM_BENCH_AB" ]; then
     grep -q R04_NODATA tools/_r04/gpt_kernels.hip && (cd tools/_r04 && $CC -DR04_NODATA gemm_bench.hip -o /tmp/gemm_bench_r04_nodata) && BINS="$BINS /tmp/gemm_bench_r04_nodata"
   fi
 fi
-for M in ${@:-64}; do for B in $BINS; do echo "=== $B M=$M"; timeout 180 $B $M; done; done > gpurun_out/gemm_bench_$TAG.log 2>&1
+#   GEMM_BENCH_VARIANT="-DAUR_GR_LN_EARLY=0" also builds the current sources with these extra flags (/tmp/gemm_bench_variant)
+#   GEMM_BENCH_PREV=1 also builds tools/_prev/ (git-ignored mirror of an earlier commit's csrc/ + tools/gemm_bench.hip: same-box A/B
+#   of a change that has no compile-time switch)
+#   GEMM_BENCH_QUICK=1: chains only;  GEMM_BENCH_REPS=n: the whole set of binaries n times, interleaved
+if [ -n "$GEMM_BENCH_VARIANT" ]; then
+  $CC -mllvm -amdgpu-kernarg-preload-count=16 $GEMM_BENCH_VARIANT tools/gemm_bench.hip -o /tmp/gemm_bench_variant && BINS="$BINS /tmp/gemm_bench_variant"
+fi
+if [ -n "$GEMM_BENCH_PREV" ] && [ -f tools/_prev/tools/gemm_bench.hip ]; then
+  (cd tools/_prev && $CC -mllvm -amdgpu-kernarg-preload-count=16 tools/gemm_bench.hip -o /tmp/gemm_bench_prev) && BINS="$BINS /tmp/gemm_bench_prev"
+fi
+for R in $(seq 1 ${GEMM_BENCH_REPS:-1}); do for M in ${@:-64}; do for B in $BINS; do echo "=== $B M=$M rep $R"; timeout 180 $B $M $GEMM_BENCH_QUICK; done; done; done > gpurun_out/gemm_bench_$TAG.log 2>&1
 echo "gemm_bench rc=$?"; cat gpurun_out/gemm_bench_$TAG.log
