@@ -225,6 +225,7 @@ public:
         if (const char* e = getenv("AUR_CONV_DMA")) conv_dma_ = atoi(e) != 0;   // 0: register-staged ResBlock convs (A/B only)
         if (const char* e = getenv("AUR_GEMM_PRESPLIT")) gemm_presplit_ = atoi(e) != 0; // 0: prompt-row GEMMs split their weights per tile instead of reading the planes packed at load time (A/B only)
         if (const char* e = getenv("AUR_DECODE_PIPELINE")) pipeline_ = atoi(e) != 0;
+        if (const char* e = getenv("AUR_WAV_DIRECT")) wav_direct_ = atoi(e) != 0;   // 0: conv_post writes device memory, one D2H copy per sequence behind it (A/B only)
         if (const char* e = getenv("AUR_SAMPLER_FULL_SORT")) sampler_full_sort_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_TEST_FAIL_STEP")) fail_at_step_ = atoi(e);
         if (const char* e = getenv("AUR_TEST_FAIL_VOC")) fail_at_voc_ = atoi(e);
@@ -1995,7 +1996,7 @@ private:
             cond[b] = voc_batch_[b]->spk_row;
             voc_max_samples_ = std::max(voc_max_samples_, frames_for(voc_nl_[b]) * 256);
         }
-        tmp_wav_.ensure((size_t)B * voc_max_samples_ * 4);
+        if (!wav_direct_) tmp_wav_.ensure((size_t)B * voc_max_samples_ * 4);
         {
             std::lock_guard<std::mutex> lk(mu_);
             voc_block_ = nullptr;
@@ -2012,14 +2013,19 @@ private:
             throw HipError("injected failure (AUR_TEST_FAIL_VOC)");
         voc_block_->buf.ensure((size_t)B * voc_max_samples_ * 4 + (cfg_.return_latents ? (size_t)B * kMaxLatRows * kHidden * 4 : 0));
         HIP_CHECK(hipStreamWaitEvent(st_voc_, ev_lat_, 0));   // latents parked by the main stream
-        run_vocoder(B, voc_nl_, latpool_.as<float>(), (long)kMaxLatRows * kHidden, &rows, cond, tmp_wav_.as<float>(),
-                    voc_max_samples_);
+        // The waveform goes straight into the pinned result block: conv_post (Cin -> 1, + tanh: 0.4 ms of HBM-bound work per 64
+        // utterances) stores its samples over PCIe -- coalesced 1 KiB per workgroup -- instead of into device memory with one D2H copy
+        // per sequence behind it (80 MB in 64 copies: 3.2 ms of the 64-utterance step with nothing to overlap, the batch's last
+        // decode step being over).  hipHostMalloc memory is device-visible and coherent; the event below orders the host's reads.
         float* hw = voc_block_->buf.as<float>();
         float* hl = hw + (size_t)B * voc_max_samples_;
+        run_vocoder(B, voc_nl_, latpool_.as<float>(), (long)kMaxLatRows * kHidden, &rows, cond, wav_direct_ ? hw : tmp_wav_.as<float>(),
+                    voc_max_samples_);
         for (int b = 0; b < B; ++b) {
             const int ns = frames_for(voc_nl_[b]) * 256;
-            HIP_CHECK(hipMemcpyAsync(hw + (size_t)b * voc_max_samples_, tmp_wav_.as<float>() + (long)b * voc_max_samples_,
-                                     (size_t)ns * 4, hipMemcpyDeviceToHost, st_voc_));
+            if (!wav_direct_)
+                HIP_CHECK(hipMemcpyAsync(hw + (size_t)b * voc_max_samples_, tmp_wav_.as<float>() + (long)b * voc_max_samples_,
+                                         (size_t)ns * 4, hipMemcpyDeviceToHost, st_voc_));
             if (cfg_.return_latents)
                 HIP_CHECK(hipMemcpyAsync(hl + (size_t)b * kMaxLatRows * kHidden,
                                          latpool_.as<float>() + (long)rows[b] * kMaxLatRows * kHidden,
@@ -2168,6 +2174,7 @@ private:
     int admit_hold_steps_ = 0;
     static constexpr int kVocHoldSteps = 16;     // longest wait of a finished sequence for a fuller vocoder batch, in aur_steps (~30 ms)
     int voc_hold_steps_ = 0;
+    bool wav_direct_ = true;   // AUR_WAV_DIRECT
     std::vector<Seq*> slot_owner_;
     std::vector<Seq*> just_finished_;
     int64_t finished_total_ = 0;
