@@ -795,8 +795,11 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const int* __restr
                 kx[c] = (float)kraw[u][c];
                 vx[c] = (float)vraw[u][c];
             }
-            float sc = (qv[0] * kx[0] + qv[1] * kx[1]) + (qv[2] * kx[2] + qv[3] * kx[3]);
-            if constexpr (EPL == 8) sc += (qv[4] * kx[4] + qv[5] * kx[5]) + (qv[6] * kx[6] + qv[7] * kx[7]);
+            // (explicit fused multiply-adds, here and in the update below: which products of `a * b + c * d` hipcc contracts depends
+            // on the code around them -- a branch-free form of this loop compiled to packed multiplies and separate adds -- and the
+            // rounding of a score must not depend on the build.  This is the form every build so far compiled to.)
+            float sc = fmaf(qv[0], kx[0], qv[1] * kx[1]) + fmaf(qv[2], kx[2], qv[3] * kx[3]);
+            if constexpr (EPL == 8) sc += fmaf(qv[4], kx[4], qv[5] * kx[5]) + fmaf(qv[6], kx[6], qv[7] * kx[7]);
             if constexpr (LPT == 16) {
                 // the butterfly sc += sc[lane ^ 8], ^ 4, ^ 2, ^ 1 over the token's 16 lanes (= one DPP row) as four v_add_f32_dpp
                 // instead of four ds_bpermute round trips through the LDS crossbar: lane ^ 8 is a row rotation by 8; after it the
@@ -817,9 +820,9 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const int* __restr
                 const float mn = fmaxf(mi, sc);
                 const float alpha = expf(mi - mn);   // mi = -inf on first use -> 0
                 const float p = expf(sc - mn);
-                li = li * alpha + p;
+                li = fmaf(li, alpha, p);
 #pragma unroll
-                for (int c = 0; c < EPL; ++c) o[c] = o[c] * alpha + p * vx[c];
+                for (int c = 0; c < EPL; ++c) o[c] = fmaf(o[c], alpha, p * vx[c]);
                 mi = mn;
             }
         }
