@@ -65,3 +65,17 @@ def test_decode_attention_is_one_scalar_round_trip_away_from_its_first_kv_load(a
         elif t.startswith("W"):
             break
     assert run == 8, (name, run)
+
+
+def test_decode_attention_is_one_copy_of_its_loop(asm):
+    """Round 5: every launch pulls its code through a COLD instruction cache.  hipcc had peeled the first iteration of the token loop
+    and unrolled sixteen copies of expf in the final merge: 6.7 KB.  One copy of the loop and one expf in the merge are 3.1 KB (fp32
+    pool); the bound leaves room for scheduling differences, not for a second copy."""
+    import re
+    for kvh, cap in (("ILb0E", 3600), ("ILb1E", 4700)):
+        (name, body), = isa_skeleton.kernels(asm, "paged_attention_kernel" + kvh)
+        size = int(re.search(r"codeLenInByte = (\d+)", body).group(1)) if "codeLenInByte" in body else None
+        if size is None:   # (the marker sits behind .end_amdhsa_kernel in some layouts: fall back to counting the loop's MFMA-free body)
+            size = int(re.search(re.escape(name) + r":.*?codeLenInByte = (\d+)", asm, re.S).group(1))
+        assert size <= cap, (name, size)
+        assert len(re.findall(r"v_exp_f32", body)) <= 2 * 4 + 1, (name, "copies of expf: two per token step, four steps, one in the merge")
