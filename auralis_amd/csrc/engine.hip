@@ -184,10 +184,10 @@ public:
         n_blocks_ = (long)S * kMaxBlocks + 2L * cfg_.max_speakers;   // + 2 shared prefix blocks per speaker
         kv_layer_stride_ = n_blocks_ * kKvBlockElems;
         kv_half_ = cfg_.kv_fp16 != 0;
-        // paged_attention_kernel addresses a layer's pool with 32-bit byte offsets: 494 slots with the fp32 pool, 990 with fp16
+        // paged_attention_kernel addresses a layer's pool with 32-bit byte offsets: 494 slots with the fp32 pool, 991 with fp16
         // (at 30 layers that is 120 GiB of K/V; HBM holds ~1000 slots' worth next to the weights)
         AUR_REQUIRE(n_blocks_ <= (kv_half_ ? 2 * kMaxKvBlocksPerLayer + 1 : kMaxKvBlocksPerLayer),
-                    "K/V pool: a layer's pool must stay below 4 GiB (max_seqs <= 494 with the fp32 pool, <= 990 with kv_fp16)");
+                    "K/V pool: a layer's pool must stay below 4 GiB (max_seqs <= 494 with the fp32 pool, <= 991 with kv_fp16)");
         gemm_prec_ = cfg_.gemm_f32_exact ? 0 : 1;
         kv_.ensure((size_t)cfg_.n_layer * kv_layer_stride_ * (kv_half_ ? 2 : 4));
         for (int b = (int)n_blocks_ - 1; b >= 0; --b) free_blocks_.push_back(b);

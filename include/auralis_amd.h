@@ -35,7 +35,7 @@ typedef struct aur_engine aur_engine;
  * (XTTSv2.py:198-232: max_model_len 1047, max_num_seqs = concurrency, block size 16). */
 typedef struct aur_config {
     int32_t n_layer;          /* GPT blocks (30 for XTTSv2; tests may use fewer) */
-    int32_t max_seqs;         /* concurrent sequences (continuous-batching slots); <= 494 (fp32 K/V pool) / 990 (kv_fp16): a layer's
+    int32_t max_seqs;         /* concurrent sequences (continuous-batching slots); <= 494 (fp32 K/V pool) / 991 (kv_fp16): a layer's
                                  pool is addressed with 32-bit byte offsets */
     int32_t max_prefill_rows; /* cap on prompt rows prefetched in one step (0 = default 8192) */
     int32_t max_speakers;     /* speaker-conditioning table entries (0 = default 64) */

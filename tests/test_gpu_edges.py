@@ -435,9 +435,9 @@ def test_admission_hold_is_bounded(dims):
 
 def test_kv_pool_above_the_32_bit_offset_range_is_refused_at_creation():
     """paged_attention_kernel addresses a layer's K/V pool with 32-bit byte offsets: a pool of 4 GiB or more per
-    layer -- 495 slots with the fp32 pool, 991 with fp16 -- must be refused when the engine is created, not read past 4 GiB later."""
+    layer -- 495 slots with the fp32 pool, 992 with fp16 -- must be refused when the engine is created, not read past 4 GiB later."""
     from auralis_amd._lib import NativeEngine
     with pytest.raises(AurError, match="4 GiB"):
         NativeEngine(n_layer=1, max_seqs=495)
     with pytest.raises(AurError, match="4 GiB"):
-        NativeEngine(n_layer=1, max_seqs=991, kv_fp16=True)
+        NativeEngine(n_layer=1, max_seqs=992, kv_fp16=True)
