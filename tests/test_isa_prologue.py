@@ -79,3 +79,15 @@ def test_decode_attention_is_one_copy_of_its_loop(asm):
             size = int(re.search(re.escape(name) + r":.*?codeLenInByte = (\d+)", asm, re.S).group(1))
         assert size <= cap, (name, size)
         assert len(re.findall(r"v_exp_f32", body)) <= 2 * 4 + 1, (name, "copies of expf: two per token step, four steps, one in the merge")
+
+
+def test_no_gpt_kernel_spills_or_uses_flat_loads(asm):
+    """Every kernel of the GPT translation unit keeps its state in registers (no scratch: private segment 0) and addresses global
+    memory with global_ / buffer_ instructions -- one flat_load makes every later counted wait of its kernel a vmcnt(0) (round 5)."""
+    import re
+    ks = isa_skeleton.kernels(asm, "")
+    assert len(ks) >= 60
+    for name, body in ks:
+        priv = re.findall(r"\.amdhsa_private_segment_fixed_size (\d+)", body)
+        assert priv and int(priv[0]) == 0, (name, "scratch bytes per lane", priv)
+        assert "flat_load" not in body and "scratch_" not in body, name
