@@ -698,7 +698,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(const int* __restr
     // (16 token steps in flight for M <= 16 rows -- one loop iteration per 256 tokens: at one row 8.2 vs 9.0 us at 244 tokens, but
     // 6.3 vs 4.9 at 64 and 12.5 vs 12.2 at 384, profiles/r04_gemm_bench_attention.log.  The launch is 3.5 us + 1.5 us per 64 tokens: one
     // CU per (row, head) pulls its K/V at 21-25 KB/us whatever the unroll.  Not kept.)
-    constexpr int UN = 4;                    // token steps in flight per workgroup iteration (8 measured slower at 64 rows: registers)
+    constexpr int UN = 4;                    // token steps in flight per workgroup iteration (8: slower in round 3 -- registers -- and, re-measured on the round-5 loop at 91 VGPRs, 23.4-24.0 vs 23.4-23.6 us at 244 tokens, 4.45 vs 3.4 at one)
     constexpr int LPT = KVH ? 8 : 16;        // lanes per token
     constexpr int EPL = kHeadDim / LPT;      // elements per lane
     constexpr int TPW = 64 / LPT;            // tokens per wave instruction
