@@ -56,9 +56,30 @@ inline void post_launch(const char* name, hipStream_t st) {
     if (debug_sync()) hip_check(hipStreamSynchronize(st), name, __FILE__, __LINE__);
 }
 
+// The butterfly v += v[lane ^ 32], ^ 16, ^ 8, ^ 4, ^ 2, ^ 1 (every lane ends with the sum, the operand pairs and their order are
+// those of six __shfl_xor steps: the same bits) without the six dependent ds_bpermute round trips through the LDS crossbar:
+//   ^ 32, ^ 16  gfx950's lane swaps: v_permlane32_swap / v_permlane16_swap of a register with itself leave {lower, lower} /
+//               {upper, upper} halves (resp. even / odd 16-lane rows) in the two results; their sum is v[l] + v[l ^ 32] in every lane;
+//   ^ 8         DPP row rotation by 8;
+//   ^ 4         DPP row rotation by 4: the value is invariant under ^ 8 by then, so lane l - 4 holds what lane l ^ 4 holds;
+//   ^ 2, ^ 1    DPP quad permutations.
+// Callers run it with all 64 lanes active (a wave per row).
+#define AUR_WAVE_BUTTERFLY(OP)                                                                                                    \
+    {                                                                                                                             \
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);                    \
+        v = OP(__uint_as_float(r[0]), __uint_as_float(r[1]));                                                                      \
+    }                                                                                                                             \
+    {                                                                                                                             \
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);                    \
+        v = OP(__uint_as_float(r[0]), __uint_as_float(r[1]));                                                                      \
+    }                                                                                                                             \
+    v = OP(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false)));   /* row_ror:8 */       \
+    v = OP(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false)));   /* row_ror:4 */       \
+    v = OP(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));    /* quad_perm [2,3,0,1] */ \
+    v = OP(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));    /* quad_perm [1,0,3,2] */
+__device__ __forceinline__ float aur_addf(float a, float b) { return a + b; }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    AUR_WAVE_BUTTERFLY(aur_addf)
     return v;
 }
 // 64-lane sum on the DPP network (6 VALU adds + one readlane) instead of 6 dependent ds_bpermute round trips (~100 cycles
@@ -77,10 +98,10 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    AUR_WAVE_BUTTERFLY(fmaxf)
     return v;
 }
+#undef AUR_WAVE_BUTTERFLY
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 

@@ -1083,9 +1083,11 @@ __global__ __launch_bounds__(256) void embed_decode_kernel(const int* __restrict
                     *reinterpret_cast<const f32x4*>(wpe + (long)slot_pos[slot] * kHidden + n);
     *reinterpret_cast<f32x4*>(h + (h_mtt > 0 ? pk_off(m, n, h_mtt) : (long)m * kHidden + n)) = v;
     if (stats) {   // LayerNorm partials per 16-column tile (4 adjacent lanes), same definition as the kEpiResidual epilogue
+        // (lane ^ 2, lane ^ 1 as DPP quad permutations: the shuffles' operand pairs without their ds_bpermute round trips)
+#define AUR_QUAD_ADD(x, ctrl) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), (ctrl), 0xF, 0xF, false))
         float sm = (v[0] + v[1]) + (v[2] + v[3]);
-        sm += __shfl_xor(sm, 2, 64);
-        sm += __shfl_xor(sm, 1, 64);
+        AUR_QUAD_ADD(sm, 0x4E);   // quad_perm [2,3,0,1]
+        AUR_QUAD_ADD(sm, 0xB1);   // quad_perm [1,0,3,2]
         const float mu = sm * (1.0f / 16.0f);
         float m2 = 0.f;
 #pragma unroll
@@ -1093,8 +1095,9 @@ __global__ __launch_bounds__(256) void embed_decode_kernel(const int* __restrict
             const float d = v[c] - mu;
             m2 = fmaf(d, d, m2);
         }
-        m2 += __shfl_xor(m2, 2, 64);
-        m2 += __shfl_xor(m2, 1, 64);
+        AUR_QUAD_ADD(m2, 0x4E);
+        AUR_QUAD_ADD(m2, 0xB1);
+#undef AUR_QUAD_ADD
         if ((threadIdx.x & 3) == 0) stats[(long)m * 64 + (threadIdx.x >> 2)] = make_float2(mu, m2);
     }
 }
