@@ -79,7 +79,7 @@ EXPORTS = [
     "aur_set_conditioning", "aur_set_conditioning_device", "aur_has_conditioning", "aur_compute_conditioning", "aur_comm_unique_id", "aur_comm_init", "aur_broadcast_conditioning",
     "aur_comm_info", "aur_conditioning_checksum",
     "aur_submit", "aur_step", "aur_poll_finished",
-    "aur_release", "aur_vocode", "aur_sync", "aur_get_stats", "aur_reset_stats", "aur_set_profile", "aur_dbg_gemm", "aur_dbg_gemm_rows", "aur_dbg_gemm_rows_ksplit_stress",
+    "aur_release", "aur_vocode", "aur_sync", "aur_get_stats", "aur_reset_stats", "aur_set_profile", "aur_dbg_gemm", "aur_dbg_gemm_rows", "aur_dbg_gemm_rows_ksplit_stress", "aur_dbg_lane_xor_selftest",
     "aur_dbg_layernorm", "aur_dbg_conv1d", "aur_dbg_conv1d_f16", "aur_dbg_prefill", "aur_dbg_sample",
 ]
 
@@ -130,6 +130,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "aur_dbg_gemm": [eng, fp, fp, fp, C.c_int32, C.c_int32, C.c_int32],
         "aur_dbg_gemm_rows": [eng, fp, fp, fp, fp, fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32],
         "aur_dbg_gemm_rows_ksplit_stress": [eng, C.c_int32, C.c_int32, C.POINTER(C.c_int64)],
+        "aur_dbg_lane_xor_selftest": [eng, C.c_int32, C.POINTER(C.c_int64)],
         "aur_dbg_layernorm": [eng, fp, fp, fp, fp, C.c_int32],
         "aur_dbg_conv1d": [eng, fp, fp, fp, fp, fp, ip, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                            C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32],
@@ -386,6 +387,12 @@ class NativeEngine:
         """`iters` back-to-back K-split projection launches at M rows vs the unsplit kernel, bitwise on the device: differing words."""
         bad = C.c_int64(-1)
         self._check(self.lib.aur_dbg_gemm_rows_ksplit_stress(self.h, int(M), int(iters), C.byref(bad)))
+        return int(bad.value)
+
+    def dbg_lane_xor_selftest(self, blocks: int = 64) -> int:
+        """lane_xor<J> / wave_sum / wave_max (DPP + lane swaps) vs the shuffles they replace, on the GPU: results that differ bitwise."""
+        bad = C.c_int64(-1)
+        self._check(self.lib.aur_dbg_lane_xor_selftest(self.h, int(blocks), C.byref(bad)))
         return int(bad.value)
 
     def dbg_layernorm(self, h, gamma, beta) -> np.ndarray:

@@ -103,6 +103,36 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 #undef AUR_WAVE_BUTTERFLY
 
+// x of lane (lane ^ J), J a power of two below 64: what __shfl_xor(x, J, 64) returns, without its ds_bpermute round trip through the
+// LDS crossbar (~100 cycles, and a counted wait behind it).  J = 1, 2: DPP quad permutations; 4: two row shifts, each written to the
+// banks (groups of four lanes) it serves; 8: row rotation; 16, 32: gfx950's v_permlane16_swap / v_permlane32_swap of the register with
+// itself (results {R0,R0,R2,R2} / {R1,R1,R3,R3} by 16-lane rows, resp. {lower,lower} / {upper,upper} by halves) and a select on the
+// lane's own bit.  All 64 lanes active.  aur_dbg_lane_xor_selftest (engine.hip) checks every J against __shfl_xor on the GPU.
+template <int J>
+__device__ __forceinline__ int lane_xor(int x) {
+    static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "lane_xor: a power of two below 64");
+    if constexpr (J == 1) {
+        return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    } else if constexpr (J == 2) {
+        return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    } else if constexpr (J == 4) {
+        const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);   // row_shl:4 -> banks 0, 2: lane l reads l + 4
+        return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);          // row_shr:4 -> banks 1, 3: lane l reads l - 4
+    } else if constexpr (J == 8) {
+        return __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false);  // row_ror:8
+    } else if constexpr (J == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+        return (int)((__lane_id() & 16) ? r[0] : r[1]);
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+        return (int)((__lane_id() & 32) ? r[0] : r[1]);
+    }
+}
+template <int J>
+__device__ __forceinline__ float lane_xor(float x) {
+    return __int_as_float(lane_xor<J>(__float_as_int(x)));
+}
+
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 // tanh-form GELU ("gelu_new"), same expression order as the oracle.

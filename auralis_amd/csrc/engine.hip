@@ -939,6 +939,18 @@ public:
     // vmcnt, device-scope ticket, sc0 sc1 read-back by the last arriver, counter reset for the next launch): `iters` back-to-back
     // launches of the K = 4096 -> 1024 residual GEMM at M rows, no host synchronisation in between, each compared word for word on
     // the device with the UNSPLIT kernel's result on the same operands.  A visibility bug shows up as a non-zero count.
+    long long dbg_lane_xor_selftest(int blocks) {
+        use();
+        AUR_REQUIRE(blocks >= 1 && blocks <= 4096, "lane_xor selftest: 1..4096 workgroups");
+        DevBuf dcnt;
+        dcnt.ensure(8);
+        HIP_CHECK(hipMemsetAsync(dcnt.p, 0, 8, st_));
+        launch_lane_xor_selftest(0x9E3779B9u, blocks, dcnt.as<unsigned long long>(), st_);
+        unsigned long long bad = 0;
+        HIP_CHECK(hipMemcpyAsync(&bad, dcnt.p, 8, hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipStreamSynchronize(st_));
+        return (long long)bad;
+    }
     long long dbg_gemm_rows_ksplit_stress(int M, int iters) {
         use();
         const int K = 4 * kHidden, N = kHidden;
@@ -2358,6 +2370,11 @@ int aur_dbg_gemm_rows_ksplit_stress(aur_engine* e, int32_t M, int32_t iters, int
     CHECK_PTR(e);
     CHECK_PTR(mismatches_out);
     return guarded([&] { *mismatches_out = e->impl.dbg_gemm_rows_ksplit_stress(M, iters); });
+}
+int aur_dbg_lane_xor_selftest(aur_engine* e, int32_t blocks, int64_t* mismatches_out) {
+    CHECK_PTR(e);
+    CHECK_PTR(mismatches_out);
+    return guarded([&] { *mismatches_out = e->impl.dbg_lane_xor_selftest(blocks); });
 }
 int aur_dbg_layernorm(aur_engine* e, const float* h, const float* gamma, const float* beta, float* out, int32_t M) {
     CHECK_PTR(e);

@@ -182,6 +182,7 @@ void launch_double_norm_rows(const float* src, float* dst, int n, const float* g
 
 // test support: *cnt += number of 32-bit words in which x and y differ
 void launch_count_mismatch(const void* x, const void* y, long n_words, unsigned long long* cnt, hipStream_t st);
+void launch_lane_xor_selftest(unsigned seed, int blocks, unsigned long long* cnt, hipStream_t st);   // test support: lane_xor / wave_sum / wave_max vs the shuffles they replace
 
 constexpr int kTokFinishedBit = 1 << 30;
 struct SamplerArgs {

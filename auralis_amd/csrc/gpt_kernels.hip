@@ -1264,15 +1264,18 @@ __device__ __forceinline__ float ord2f(unsigned o) {
 // winner, so the waves reduce with shuffles and meet once in LDS instead of eight barrier-separated LDS levels)
 __device__ __forceinline__ int block_argmax(float val, int idx, float* sv, int* si) {
     const int tid = threadIdx.x;
-#pragma unroll
-    for (int sh = 32; sh > 0; sh >>= 1) {
-        const float ov = __shfl_xor(val, sh, 64);
-        const int oi = __shfl_xor(idx, sh, 64);
-        if (ov > val || (ov == val && oi < idx)) {
-            val = ov;
-            idx = oi;
-        }
+    // (the butterfly over lane ^ 32, .., ^ 1 on lane_xor: DPP / lane swaps instead of twelve ds_bpermute round trips)
+#define AUR_ARGMAX_STEP(J)                                   \
+    {                                                        \
+        const float ov = lane_xor<J>(val);                   \
+        const int oi = lane_xor<J>(idx);                     \
+        if (ov > val || (ov == val && oi < idx)) {           \
+            val = ov;                                        \
+            idx = oi;                                        \
+        }                                                    \
     }
+    AUR_ARGMAX_STEP(32) AUR_ARGMAX_STEP(16) AUR_ARGMAX_STEP(8) AUR_ARGMAX_STEP(4) AUR_ARGMAX_STEP(2) AUR_ARGMAX_STEP(1)
+#undef AUR_ARGMAX_STEP
     if ((tid & 63) == 0) {
         sv[tid >> 6] = val;
         si[tid >> 6] = idx;
@@ -1302,8 +1305,9 @@ __device__ __forceinline__ float block_sum_tree(float v, float* sv) {
     float x = 0.f;
     if (tid < 64) {
         x = sv[tid] + sv[tid + 64];
-#pragma unroll
-        for (int sh = 32; sh > 0; sh >>= 1) x += __shfl_down(x, sh, 64);   // lane t: x[t] + x[t + sh]; lane 0 ends with the tree's root
+        // lane t: x[t] + x[t + sh], sh = 32 .. 1; lane 0 ends with the tree's root.  On the lanes that feed lane 0 (t < sh at every level)
+        // t + sh == t ^ sh, so wave_sum's butterfly (lane swaps + DPP, common.h) forms the same sums in the same order there.
+        x = wave_sum(x);
         if (tid == 0) sv[0] = x;
     }
     __syncthreads();
@@ -1438,16 +1442,24 @@ __global__ __launch_bounds__(256) void sampler_kernel(const int* __restrict__ sa
                 // every correct descending sort gives the same order.
                 if (tid < 64) {
                     unsigned long long key = tid < n_surv ? keys[tid] : 0ull;
-                    for (int k = 2; k <= 64; k <<= 1)
-                        for (int jj = k >> 1; jj > 0; jj >>= 1) {
-                            const unsigned lo32 = (unsigned)__shfl_xor((int)(unsigned)key, jj, 64);
-                            const unsigned hi32 = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), jj, 64);
-                            const unsigned long long other = ((unsigned long long)hi32 << 32) | lo32;
-                            const bool lower = (tid & jj) == 0;        // this lane is element e < x = e ^ jj of the pair
-                            const bool up = (tid & k) == 0;            // descending block (as the LDS network below: larger key first)
-                            const bool take_max = lower == up;
-                            key = take_max ? (key > other ? key : other) : (key < other ? key : other);
-                        }
+                    // (partner keys through lane_xor -- DPP / lane swaps -- instead of 42 ds_bpermute round trips)
+#define AUR_SORT_STEP(K, JJ)                                                                                                   \
+    {                                                                                                                          \
+        const unsigned lo32 = (unsigned)lane_xor<JJ>((int)(unsigned)key);                                                      \
+        const unsigned hi32 = (unsigned)lane_xor<JJ>((int)(unsigned)(key >> 32));                                              \
+        const unsigned long long other = ((unsigned long long)hi32 << 32) | lo32;                                              \
+        const bool lower = (tid & JJ) == 0; /* this lane is element e < x = e ^ jj of the pair */                             \
+        const bool up = (tid & K) == 0;     /* descending block (as the LDS network below: larger key first) */                \
+        const bool take_max = lower == up;                                                                                     \
+        key = take_max ? (key > other ? key : other) : (key < other ? key : other);                                            \
+    }
+                    AUR_SORT_STEP(2, 1)
+                    AUR_SORT_STEP(4, 2) AUR_SORT_STEP(4, 1)
+                    AUR_SORT_STEP(8, 4) AUR_SORT_STEP(8, 2) AUR_SORT_STEP(8, 1)
+                    AUR_SORT_STEP(16, 8) AUR_SORT_STEP(16, 4) AUR_SORT_STEP(16, 2) AUR_SORT_STEP(16, 1)
+                    AUR_SORT_STEP(32, 16) AUR_SORT_STEP(32, 8) AUR_SORT_STEP(32, 4) AUR_SORT_STEP(32, 2) AUR_SORT_STEP(32, 1)
+                    AUR_SORT_STEP(64, 32) AUR_SORT_STEP(64, 16) AUR_SORT_STEP(64, 8) AUR_SORT_STEP(64, 4) AUR_SORT_STEP(64, 2) AUR_SORT_STEP(64, 1)
+#undef AUR_SORT_STEP
                     keys[tid] = key;
                     keys[tid + 64] = 0ull;
                     if (tid == 0) {
@@ -1640,6 +1652,37 @@ __global__ __launch_bounds__(256) void count_mismatch_kernel(const unsigned* __r
 void launch_count_mismatch(const void* x, const void* y, long n_words, unsigned long long* cnt, hipStream_t st) {
     hipLaunchKernelGGL(count_mismatch_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const unsigned*>(x),
                        reinterpret_cast<const unsigned*>(y), n_words, cnt);
+    HIP_CHECK(hipGetLastError());
+}
+
+// test support: lane_xor<J> / wave_sum / wave_max (common.h: DPP + gfx950 lane swaps) against the shuffles they replace, on four
+// waves of pseudo-random words; *cnt += number of (lane, J) results that differ bitwise
+__global__ __launch_bounds__(256) void lane_xor_selftest_kernel(unsigned seed, unsigned long long* __restrict__ cnt) {
+    unsigned x = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + seed;
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+    const int xi = (int)x;
+    int bad = 0;
+    bad += lane_xor<1>(xi) != __shfl_xor(xi, 1, 64);
+    bad += lane_xor<2>(xi) != __shfl_xor(xi, 2, 64);
+    bad += lane_xor<4>(xi) != __shfl_xor(xi, 4, 64);
+    bad += lane_xor<8>(xi) != __shfl_xor(xi, 8, 64);
+    bad += lane_xor<16>(xi) != __shfl_xor(xi, 16, 64);
+    bad += lane_xor<32>(xi) != __shfl_xor(xi, 32, 64);
+    const float f = (float)(x >> 8) * (1.0f / 16777216.0f) - 0.5f;   // sums whose bits depend on the order of the additions
+    float rs = f, rm = f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        rs += __shfl_xor(rs, o, 64);
+        rm = fmaxf(rm, __shfl_xor(rm, o, 64));
+    }
+    bad += __float_as_uint(wave_sum(f)) != __float_as_uint(rs);
+    bad += __float_as_uint(wave_max(f)) != __float_as_uint(rm);
+    const unsigned long long any = __ballot(bad != 0);
+    if (bad) atomicAdd(cnt, (unsigned long long)bad);
+    (void)any;
+}
+void launch_lane_xor_selftest(unsigned seed, int blocks, unsigned long long* cnt, hipStream_t st) {
+    hipLaunchKernelGGL(lane_xor_selftest_kernel, dim3(blocks), dim3(256), 0, st, seed, cnt);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -251,6 +251,10 @@ int aur_dbg_gemm_rows(aur_engine* e, const float* X, const float* W, const float
  * back-to-back launches on fixed pseudo-random operands, each compared bitwise on the device with the unsplit kernel's result;
  * *mismatches_out = differing 32-bit words over all launches (0 = the cross-workgroup hand-off held every time). */
 int aur_dbg_gemm_rows_ksplit_stress(aur_engine* e, int32_t M, int32_t iters, int64_t* mismatches_out);
+/* The kernels' cross-lane helpers (lane_xor<J>, wave_sum, wave_max: DPP and gfx950 lane swaps, csrc/common.h) against the wavefront
+ * shuffles they replace, on `blocks` workgroups of pseudo-random words; *mismatches_out = results that differ bitwise (0 expected).
+ * Test support: the reference has no counterpart (its reductions are torch's). */
+int aur_dbg_lane_xor_selftest(aur_engine* e, int32_t blocks, int64_t* mismatches_out);
 /* out[M][1024] = LayerNorm(h) rows */
 int aur_dbg_layernorm(aur_engine* e, const float* h, const float* gamma, const float* beta, float* out,
                       int32_t M);

@@ -133,6 +133,13 @@ def test_gemm_rows_ksplit_stress(eng, M):
     assert eng.dbg_gemm_rows_ksplit_stress(M, 3000) == 0
 
 
+def test_cross_lane_helpers_equal_the_shuffles_they_replace(eng):
+    """lane_xor<1..32>, wave_sum and wave_max (csrc/common.h: DPP permutations and gfx950's v_permlane16/32_swap) against __shfl_xor
+    and the six-step shuffle butterflies, bitwise, on 1 024 waves of pseudo-random words: LayerNorm statistics, the sampler's argmax,
+    its 64-key sort and its softmax denominator all run on them, and every bit-exact test downstream assumes they permute exactly."""
+    assert eng.dbg_lane_xor_selftest(256) == 0
+
+
 def test_layernorm(eng):
     g = torch.Generator().manual_seed(0)
     h = torch.randn(37, 1024, generator=g) * 3 + 0.5
