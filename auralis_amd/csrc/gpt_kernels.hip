@@ -1058,29 +1058,47 @@ void launch_embed_prompt(const int4* desc, const float* spk_cond, const float* t
     HIP_CHECK(hipGetLastError());
 }
 
-__global__ __launch_bounds__(256) void embed_decode_kernel(const int* __restrict__ row_slot,
-                                                           const int* __restrict__ slot_tok,
-                                                           const int* __restrict__ slot_pos,
-                                                           const float* __restrict__ wte,
-                                                           const float* __restrict__ wpe, float* __restrict__ h, int h_mtt,
-                                                           float2* __restrict__ stats, int* __restrict__ row_meta,
-                                                           const int* __restrict__ slot_kvpos,
-                                                           const int* __restrict__ block_tables, int max_blocks) {
+// What the launch waits for (round 5): the row's slot, then the slot's token / position / K/V position TOGETHER, then the two embedding
+// rows and the row's block table together -- three dependent memory trips, the minimum for row -> slot -> token -> embedding.  hipcc had
+// made seven of them: every kernel argument behind the preloaded ones and every per-slot word was fetched where it was first used.
+// The leading arguments (everything the first two trips need) arrive in SGPRs; the rest is one scalar burst next to the first trip.
+struct EmbedDecodeTail {
+    const float* wpe;
+    float* h;
+    float2* stats;
+    int* row_meta;
+};
+__global__ __launch_bounds__(256) void embed_decode_kernel(const int* __restrict__ row_slot, const int* __restrict__ slot_tok,
+                                                           const int* __restrict__ slot_pos, const int* __restrict__ slot_kvpos,
+                                                           const int* __restrict__ block_tables, int max_blocks, int h_mtt,
+                                                           const float* __restrict__ wte, EmbedDecodeTail tl) {
     const int m = blockIdx.x;
     const int slot = row_slot[m];
+    const float* const wpe = tl.wpe;
+    float* const h = tl.h;
+    float2* const stats = tl.stats;
+    int* const row_meta = tl.row_meta;
+    asm volatile("; EmbedDecodeTail resident" ::"s"(wpe), "s"(h), "s"(stats), "s"(row_meta));
+    const int tok = slot_tok[slot], pe = slot_pos[slot];
+    const int kvpos = row_meta ? slot_kvpos[slot] : 0;
+    asm volatile("; per-slot words resident" ::"s"(tok), "s"(pe), "s"(kvpos));
     const int n = 4 * threadIdx.x;
+    const int* const bt = block_tables + (long)slot * max_blocks;
+    const int wblk = row_meta ? bt[kvpos / kKvBlockTokens] : 0;   // (uniform: a scalar load, requested with the rows below)
+    const f32x4 e0 = *reinterpret_cast<const f32x4*>(wte + (long)tok * kHidden + n);
+    const f32x4 e1 = *reinterpret_cast<const f32x4*>(wpe + (long)pe * kHidden + n);
+    const int btv = row_meta ? bt[min((int)threadIdx.x, max_blocks - 1)] : 0;
+    asm volatile("; write block resident" ::"s"(wblk), "v"(btv));
     if (row_meta) {   // the step's K/V addressing of this row, dense (kRowMetaStride ints)
         int* rm = row_meta + (long)m * kRowMetaStride;
+        if ((int)threadIdx.x < max_blocks) rm[kRowMetaBt + threadIdx.x] = btv;
         if (threadIdx.x == 0) {
-            const int pos = slot_kvpos[slot];
-            rm[0] = pos;
+            rm[0] = kvpos;
             rm[1] = slot;
-            rm[kRowMetaWblk] = block_tables[(long)slot * max_blocks + pos / kKvBlockTokens];
+            rm[kRowMetaWblk] = wblk;
         }
-        if ((int)threadIdx.x < max_blocks) rm[kRowMetaBt + threadIdx.x] = block_tables[(long)slot * max_blocks + threadIdx.x];
     }
-    const f32x4 v = *reinterpret_cast<const f32x4*>(wte + (long)slot_tok[slot] * kHidden + n) +
-                    *reinterpret_cast<const f32x4*>(wpe + (long)slot_pos[slot] * kHidden + n);
+    const f32x4 v = e0 + e1;
     *reinterpret_cast<f32x4*>(h + (h_mtt > 0 ? pk_off(m, n, h_mtt) : (long)m * kHidden + n)) = v;
     if (stats) {   // LayerNorm partials per 16-column tile (4 adjacent lanes), same definition as the kEpiResidual epilogue
         // (lane ^ 2, lane ^ 1 as DPP quad permutations: the shuffles' operand pairs without their ds_bpermute round trips)
@@ -1107,8 +1125,8 @@ void launch_embed_decode(const int* row_slot, const int* slot_tok, const int* sl
                          const int* slot_kvpos, const int* block_tables, int max_blocks) {
     AUR_REQUIRE(!row_meta || (slot_kvpos && block_tables && max_blocks + kRowMetaBt <= kRowMetaStride), "embed_decode: row meta");
     trace_launch("embed_decode_kernel");
-    hipLaunchKernelGGL(embed_decode_kernel, dim3(M), dim3(256), 0, st, row_slot, slot_tok, slot_pos, wte, wpe, h, h_mtt, stats,
-                       row_meta, slot_kvpos, block_tables, max_blocks);
+    hipLaunchKernelGGL(embed_decode_kernel, dim3(M), dim3(256), 0, st, row_slot, slot_tok, slot_pos, slot_kvpos, block_tables, max_blocks, h_mtt,
+                       wte, EmbedDecodeTail{wpe, h, stats, row_meta});
     HIP_CHECK(hipGetLastError());
 }
 
