@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
+import weakref
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -63,7 +65,9 @@ class aur_stats(C.Structure):
                 ("attn_bytes", C.c_double), ("decode_steps", C.c_int64), ("decode_ms", C.c_double), ("prefill_ms", C.c_double),
                 ("decode_weight_bytes", C.c_double), ("decode_kv_bytes", C.c_double),
                 ("conv_class_launches", C.c_int64 * 5), ("conv_class_ms", C.c_double * 5), ("conv_class_bytes", C.c_double * 5),
-                ("conv_class_flops", C.c_double * 5), ("prefill_batches", C.c_int64)]
+                ("conv_class_flops", C.c_double * 5), ("prefill_batches", C.c_int64),
+                ("result_blocks", C.c_int64), ("result_blocks_free", C.c_int64), ("result_block_bytes", C.c_int64),
+                ("speakers", C.c_int64), ("sequences_tracked", C.c_int64)]
 
     def as_dict(self) -> Dict[str, float]:
         out = {}
@@ -165,8 +169,42 @@ def _ip(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
 
 
+class ResultLease:
+    """One finished sequence's hold on its pinned result block (aur_result.wav / .latents stay valid until aur_release).
+    `release()` is idempotent; dropping the last reference releases too, so an array built on the lease (poll(copy=False))
+    returns the block when the array -- and every view of it -- is gone.  The reference hands out plain numpy copies
+    (XTTSv2.py:804-811); the lease is what lets this path hand out the engine's own buffer instead."""
+    __slots__ = ("_eng", "seq_id", "nbytes", "__weakref__")
+
+    def __init__(self, eng: "NativeEngine", seq_id: int, nbytes: int):
+        self._eng, self.seq_id, self.nbytes = eng, seq_id, nbytes
+
+    def release(self):
+        eng, self._eng = self._eng, None
+        if eng is not None:
+            eng._lease_dropped(self)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:   # interpreter shutdown
+            pass
+
+
+class _PinnedView:
+    """__array_interface__ over `n` elements at `addr`; numpy keeps this object (and through it the lease) as the array's base."""
+    __slots__ = ("__array_interface__", "lease")
+
+    def __init__(self, addr: int, shape, typestr: str, lease: ResultLease):
+        self.__array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (addr, False), "version": 3}
+        self.lease = lease
+
+
 class NativeEngine:
     """Thin object wrapper over the C ABI; one instance per GPU."""
+    # poll(copy=False) hands out views of pinned host memory; past this many leased bytes (waveforms somebody keeps) new
+    # results are copied instead, so that kept outputs cost pageable memory like the reference's, not pinned blocks
+    LEASE_BUDGET_BYTES = 2 << 30
 
     def __init__(self, n_layer: int = 30, max_seqs: int = 64, device: int = 0, max_prefill_rows: int = 0,
                  max_speakers: int = 0, vocoder_min_batch: int = 0, profile: bool = False, vocoder_fp16: bool = False,
@@ -180,15 +218,40 @@ class NativeEngine:
         self.h = h
         self.max_seqs = max_seqs
         self.n_layer = n_layer
+        self._lease_lock = threading.Lock()
+        self._leases: Dict[int, "weakref.ref"] = {}   # seq_id -> lease handed out by poll(copy=False)
+        self._leased_bytes = 0
+        self._closing = False
 
     def _check(self, rc: int):
         if rc != 0:
             raise AurError(rc, self.lib.aur_last_error().decode("utf-8", "replace"))
 
     def close(self):
-        if getattr(self, "h", None):
-            self.lib.aur_engine_destroy(self.h)
-            self.h = None
+        """Destroy the engine.  While arrays handed out by poll(copy=False) are alive their memory belongs to the engine, so the
+        destruction waits for the last of them (it then happens on the thread that drops it)."""
+        if not getattr(self, "h", None):
+            return
+        with self._lease_lock:
+            self._closing = True
+            if self._leases:
+                return
+            h, self.h = self.h, None
+        self.lib.aur_engine_destroy(h)
+
+    def _lease_dropped(self, lease: "ResultLease"):
+        with self._lease_lock:
+            if self._leases.pop(lease.seq_id, None) is None:
+                return
+            self._leased_bytes -= lease.nbytes
+            h = self.h
+            last = self._closing and not self._leases
+            if last:
+                self.h = None
+        if h:
+            self.lib.aur_release(h, lease.seq_id)
+            if last:
+                self.lib.aur_engine_destroy(h)
 
     def __del__(self):
         try:
@@ -282,34 +345,56 @@ class NativeEngine:
         return live.value, fin.value
 
     def poll(self, cap: int = 64, want_latents: bool = True, copy: bool = True) -> List[dict]:
-        """Finished sequences.  copy=True: owned numpy arrays, the engine's result block is released at once.  copy=False: the
-        arrays are VIEWS of the engine's pinned result block (aur_result.wav / .tokens / .latents, valid until release(seq_id));
-        the caller releases each sequence when it is done with the view."""
+        """Finished sequences.  copy=True: owned numpy arrays, the engine's result block is released at once.  copy=False: `wav`
+        (and `latents`) are VIEWS of the engine's pinned result block (aur_result.wav / .latents); the item's `lease`
+        (ResultLease) gives the block back -- explicitly (lease.release() / release(seq_id)) or when the last array over it is
+        dropped.  Token ids are always copied (a few hundred int32)."""
         res = (aur_result * cap)()
         n = C.c_size_t()
         self._check(self.lib.aur_poll_finished(self.h, res, cap, C.byref(n)))
-        own = (lambda a: a.copy()) if copy else (lambda a: a)
         out = []
         for i in range(n.value):
             r = res[i]
+            nbytes = 4 * (r.n_samples + (r.n_latent_rows * 1024 if want_latents else 0))
+            lease = None
+            if not copy and nbytes:
+                with self._lease_lock:
+                    if self._leased_bytes + nbytes <= self.LEASE_BUDGET_BYTES:
+                        lease = ResultLease(self, r.seq_id, nbytes)
+                        self._leases[r.seq_id] = weakref.ref(lease)
+                        self._leased_bytes += nbytes
+
+            def arr(ptr, shape):
+                if lease is None:
+                    return np.ctypeslib.as_array(ptr, shape=shape).copy()
+                return np.asarray(_PinnedView(C.addressof(ptr.contents), shape, "<f4", lease))
             item = {
                 "seq_id": r.seq_id,
-                "tokens": (own(np.ctypeslib.as_array(r.tokens, shape=(r.n_tokens,))) if r.n_tokens
+                "tokens": (np.ctypeslib.as_array(r.tokens, shape=(r.n_tokens,)).copy() if r.n_tokens
                            else np.zeros(0, dtype=np.int32)),
-                "wav": (own(np.ctypeslib.as_array(r.wav, shape=(r.n_samples,))) if r.n_samples
+                "wav": (arr(r.wav, (r.n_samples,)) if r.n_samples
                         else np.zeros(0, dtype=np.float32)),   # failed sequences carry no audio (error != 0)
                 "error": r.error,
             }
             if want_latents and r.n_latent_rows:
-                item["latents"] = own(np.ctypeslib.as_array(r.latents, shape=(r.n_latent_rows, 1024)))
-            if copy:
+                item["latents"] = arr(r.latents, (r.n_latent_rows, 1024))
+            if lease is None:
                 self._check(self.lib.aur_release(self.h, r.seq_id))
+            else:
+                item["lease"] = lease
             out.append(item)
         return out
 
     def release(self, seq_id: int):
-        """Give a sequence's result block back (after poll(copy=False))."""
-        self._check(self.lib.aur_release(self.h, seq_id))
+        """Give a sequence's result block back now (after poll(copy=False)); the arrays over it must not be used afterwards.
+        A sequence whose lease is already gone is not an error."""
+        with self._lease_lock:
+            ref = self._leases.get(seq_id)
+        lease = ref() if ref is not None else None
+        if lease is not None:
+            lease.release()
+        elif ref is not None:     # the lease object is being finalised: its __del__ releases
+            return
 
     def run_until_done(self, max_steps: int = 100000, copy: bool = True) -> List[dict]:
         """Drive aur_step until nothing is live; returns finished results in completion order (copy: see poll)."""

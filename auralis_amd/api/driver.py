@@ -4,23 +4,44 @@ The reference needs three mechanisms here: vLLM's background engine loop, a Hidd
 second-pass hidden states from the vLLM worker thread to asyncio with a 3 s timeout
 (components/vllm/hidden_state_collector.py:89-167) and a 10 ms polling loop that re-orders chunk outputs
 (two_phase_scheduler.py:308-388).  Natively one driver thread per engine calls aur_step() while anything is live and
-resolves one asyncio future per sequence with loop.call_soon_threadsafe — no polling, no second pass."""
+resolves one asyncio future per sequence with loop.call_soon_threadsafe — no polling loop, no second pass.
+
+What the driver thread does per iteration is aur_step and nothing else: aur_poll_finished is called only when the step's
+finished counter moved (or nothing is live any more), and results are taken as VIEWS of the engine's pinned result blocks
+(`poll(copy=False)`): no waveform is copied on the thread that issues the next decode step.  The view carries a lease
+(auralis_amd._lib.ResultLease) that gives the block back (aur_release) when the last array referring to it is dropped, i.e.
+with the TTSOutput the plugin builds from it.
+
+A failed aur_step fails the sequences that were in flight (the engine reports them through aur_poll_finished with
+aur_result.error set and stays usable, engine.hip: Engine::step / fail_in_flight); their futures get the exception, queued
+sequences and later submissions go on.  Only `max_consecutive_failures` failed steps in a row (a lost device) stop the driver
+for good: then every pending future fails and submit() raises."""
 from __future__ import annotations
 
 import asyncio
 import threading
+import time
 from typing import Any, Dict, Optional, Tuple
 
 
 class EngineDriver:
-    def __init__(self, engine: Any):
-        """`engine` needs submit(**kw)->id, step()->(live, finished), poll()->list[dict] (NativeEngine or a test double)."""
+    def __init__(self, engine: Any, max_consecutive_failures: int = 3, burst_gap_s: float = 1e-3, burst_max_s: float = 25e-3):
+        """`engine` needs submit(**kw)->id, step()->(live, finished_total), poll(copy=False)->list[dict] (NativeEngine or a
+        test double).  `burst_gap_s` / `burst_max_s`: an IDLE engine does not start on the first submission of a burst -- N
+        concurrent generate_speech calls reach it a fraction of a millisecond apart, the event loop tokenises them one after
+        the other, and a prefill pass costs the same ~4.5 ms of launches for one prompt as for 64 -- but once no submission has
+        arrived for burst_gap_s (at most burst_max_s after the first).  A lone request pays burst_gap_s once; a running engine
+        never waits (its admission groups arrivals itself, aur_config.admit_min_batch)."""
         self.engine = engine
+        self.max_consecutive_failures = max(1, int(max_consecutive_failures))
+        self.burst_gap_s, self.burst_max_s = float(burst_gap_s), float(burst_max_s)
+        self._last_submit = 0.0
         self._pending: Dict[int, Tuple[asyncio.AbstractEventLoop, asyncio.Future]] = {}
         self._lock = threading.Lock()
         self._wake = threading.Event()
         self._stop = False
         self._error: Optional[BaseException] = None
+        self.failed_steps = 0          # aur_step calls that raised (the driver went on after them unless they came in a row)
         self._thread = threading.Thread(target=self._run, name="auralis-amd-driver", daemon=True)
         self._thread.start()
 
@@ -41,22 +62,31 @@ class EngineDriver:
                 reregister()
                 sid = self.engine.submit(**seq)
             self._pending[sid] = (loop, fut)
+            self._last_submit = time.perf_counter()
         self._wake.set()
         return fut
 
-    def _resolve(self, item: dict):
+    def _resolve(self, item: dict, step_error: Optional[BaseException] = None):
         with self._lock:
             ent = self._pending.pop(item["seq_id"], None)
         if ent is None:
+            lease = item.get("lease")
+            if lease is not None:      # nobody waits for it (cancelled / unknown id): give the block back at once
+                lease.release()
             return
         loop, fut = ent
 
         def done():
-            if not fut.done():
-                if item.get("error"):
-                    fut.set_exception(RuntimeError(f"sequence failed with code {item['error']}"))
-                else:
-                    fut.set_result(item)
+            if fut.done():             # cancelled consumer: the result is dropped, the lease goes with it
+                return
+            if item.get("error"):
+                exc = RuntimeError(f"sequence {item['seq_id']} failed with code {item['error']}"
+                                   + (f": {step_error}" if step_error is not None else ""))
+                if step_error is not None:
+                    exc.__cause__ = step_error
+                fut.set_exception(exc)
+            else:
+                fut.set_result(item)
         loop.call_soon_threadsafe(done)
 
     def _fail_all(self, exc: BaseException):
@@ -65,21 +95,54 @@ class EngineDriver:
         for loop, fut in pend.values():
             loop.call_soon_threadsafe(lambda f=fut: (not f.done()) and f.set_exception(exc))
 
+    def _drain(self, step_error: Optional[BaseException] = None):
+        while True:                    # a vocoder batch (or a failed step) can finish more than one poll's worth at once
+            got = self.engine.poll(cap=64, copy=False)
+            for item in got:
+                self._resolve(item, step_error)
+            if len(got) < 64:
+                return
+
     def _run(self):
+        try:
+            self._loop()
+        except BaseException as e:  # noqa: BLE001 - a driver that dies silently would leave every future pending for ever
+            self._error = e
+            self._fail_all(e)
+
+    def _loop(self):
         while not self._stop:
             self._wake.wait(timeout=0.5)
             self._wake.clear()
-            try:
-                while not self._stop:
-                    live, _ = self.engine.step()
-                    for item in self.engine.poll():
-                        self._resolve(item)
-                    if live == 0:
-                        break
-            except BaseException as e:  # first error wins, as in the reference scheduler (two_phase_scheduler.py:279-291)
-                self._error = e
-                self._fail_all(e)
-                return
+            t_end = time.perf_counter() + self.burst_max_s
+            while not self._stop:     # the burst that woke an idle engine is still arriving
+                now = time.perf_counter()
+                if now >= t_end or now - self._last_submit >= self.burst_gap_s:
+                    break
+                time.sleep(self.burst_gap_s * 0.25)
+            last_fin = None
+            in_a_row = 0
+            while not self._stop:
+                try:
+                    live, fin = self.engine.step()
+                    in_a_row = 0
+                except Exception as e:  # noqa: BLE001 - handed to the futures of the sequences it hit
+                    self.failed_steps += 1
+                    in_a_row += 1
+                    if in_a_row >= self.max_consecutive_failures:
+                        raise           # nothing but failures: the device is gone (the reference stops at its FIRST error,
+                                        # two_phase_scheduler.py:279-291)
+                    self._drain(e)      # the sequences that were in flight, failed by the engine
+                    with self._lock:
+                        if not self._pending:
+                            break
+                    last_fin = None
+                    continue
+                if fin != last_fin or live == 0:
+                    self._drain()
+                    last_fin = fin
+                if live == 0:
+                    break
 
     def shutdown(self):
         self._stop = True

@@ -34,6 +34,9 @@ class TTSOutput:
         """Concatenate chunk outputs in order; sample rate of the first (output.py:95-111)."""
         if not outputs:
             raise ValueError("combine_outputs needs at least one output")
+        if len(outputs) == 1:   # a one-chunk request (every text up to the character limit): the chunk's own array, not a 1.25 MB copy of it
+            o = outputs[0]
+            return TTSOutput(array=o.array, sample_rate=o.sample_rate, token_length=o.token_length or None, start_time=o.start_time)
         return TTSOutput(array=np.concatenate([o.array for o in outputs]), sample_rate=outputs[0].sample_rate,
                          token_length=sum(o.token_length or 0 for o in outputs) or None,
                          start_time=outputs[0].start_time)

@@ -25,6 +25,21 @@ from .requests import TTSRequest
 from .text import XTTSTokenizer
 
 
+try:                       # 133 KB per request: xxh3 takes ~10 us, blake2b ~190 us of the event-loop thread
+    from xxhash import xxh3_64 as _Hash64
+except ImportError:        # same role, slower
+    def _Hash64():
+        return hashlib.blake2b(digest_size=8)
+
+
+def _content_key(g: np.ndarray, s: np.ndarray) -> int:
+    """64-bit key of a voice's conditioning CONTENT (fed through the buffer protocol: no copy).  Keys are local to a process."""
+    h = _Hash64()
+    h.update(np.ascontiguousarray(g).data)
+    h.update(np.ascontiguousarray(s).data)
+    return int.from_bytes(h.digest(), "little")
+
+
 class ChunkHandle:
     """Opaque per-chunk "token generator" handed to the facade (the reference passes a vLLM async generator)."""
 
@@ -49,6 +64,9 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
         self.driver = EngineDriver(native_engine)
         self._speakers = {}
         self._seed_counter = 0
+        # bench / test knob (aur_seq_desc.ignore_stop): every chunk runs to gpt_max_audio_tokens whatever it samples, so that
+        # runs do identical work (SURVEY 8d "fixed-length mode"); never set by from_pretrained
+        self.fixed_length = False
 
     # ------------------------------------------------------------------ construction
     @classmethod
@@ -57,7 +75,8 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
         """Load a checkpoint directory in the reference's on-disk format (checkpoint.py docstring).  kwargs the
         reference forwards to vLLM (tensor_parallel_size, pipeline_parallel_size, gpt_model, torch_dtype, device_map;
         XTTSv2.py:235-243) are accepted; tp/pp other than 1 are rejected (the path shards by utterance).
-        `admit_min_batch` / `vocoder_min_batch` are the batcher's two grouping knobs (include/auralis_amd.h, aur_config)."""
+        `admit_min_batch` / `vocoder_min_batch` are the batcher's two grouping knobs, `max_speakers` the size of the engine's voice
+        table (include/auralis_amd.h, aur_config)."""
         from .._lib import NativeEngine
         from ..checkpoint import load_checkpoint, read_checkpoint_config
         from ..weights import pack_all
@@ -71,7 +90,8 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
         # path, the reference's own GPU path autocasts to fp16); vocoder="fp32": exact-f32 MFMA parity mode
         native = NativeEngine(n_layer=ck.n_layer, max_seqs=max(1, max_concurrency), device=device,
                               vocoder_fp16=(vocoder == "fp16"), return_latents=False, gelu_erf=ck.gelu_erf,
-                              admit_min_batch=int(kwargs.get("admit_min_batch", 0)), vocoder_min_batch=int(kwargs.get("vocoder_min_batch", 0)))
+                              admit_min_batch=int(kwargs.get("admit_min_batch", 0)), vocoder_min_batch=int(kwargs.get("vocoder_min_batch", 0)),
+                              max_speakers=int(kwargs.get("max_speakers", 0)))
         native.load_weights(pack_all(gpt_sd, xtts_sd))
         if any(k.startswith("conditioning_encoder.") for k in xtts_sd):
             from ..weights import pack_conditioning
@@ -177,7 +197,7 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
         """Content-addressed speaker key.  The engine's speaker table is bounded (aur_config.max_speakers) and evicts the least
         recently used idle voice, so presence is asked of the engine itself (aur_has_conditioning, which also refreshes the
         voice's LRU stamp) instead of being mirrored in an ever-growing Python dict; an evicted voice is simply re-registered."""
-        key = int.from_bytes(hashlib.blake2b(g.tobytes() + s.tobytes(), digest_size=8).digest(), "little")
+        key = _content_key(g, s)
         has = getattr(self.native, "has_conditioning", None)
         if has is not None:
             if not has(key):
@@ -211,7 +231,8 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
                                      text_ids=text_ids, speaker_key=key, temperature=request.temperature,
                                      top_p=request.top_p, top_k=request.top_k,
                                      repetition_penalty=request.repetition_penalty,
-                                     max_tokens=self.gpt_max_audio_tokens, seed=seed)
+                                     max_tokens=self.gpt_max_audio_tokens, seed=seed,
+                                     **({"ignore_stop": True} if self.fixed_length else {}))
             rid = f"{request.request_id}_{idx}"
             handles.append(ChunkHandle(fut, rid, len(text_ids)))
             ids.append(rid)
@@ -222,6 +243,8 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
                                        request: Optional[TTSRequest] = None) -> AsyncGenerator[TTSOutput, None]:
         assert speaker_embeddings is not None, "Speaker embeddings must be provided for speech generation with XTTSv2."
         item = await generator.future
+        # item["wav"] is the engine's own pinned result block (EngineDriver polls with copy=False): the TTSOutput's array is a view
+        # of it and gives the block back when it is dropped (ResultLease); nothing is copied between the GPU's store and the caller
         yield TTSOutput(array=item["wav"], sample_rate=24000,
                         start_time=request.start_time if request is not None else None,
                         token_length=int(len(item["tokens"])))

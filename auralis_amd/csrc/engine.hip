@@ -128,6 +128,19 @@ __global__ __launch_bounds__(256) void init_slots_kernel(const SlotInit* __restr
     }
 }
 
+// Test support (aur_dbg_gemm_rows_ksplit_stress): background HBM / L2 traffic on a second stream.  Every workgroup streams a
+// 64 KiB-aligned share of `src` (>= 32 KiB per CU per launch, the guide's "uneven load" rule for cross-workgroup hand-off tests)
+// and leaves one partial sum per workgroup so that the loads cannot be dropped.
+__global__ __launch_bounds__(256) void stress_load_kernel(const float4* __restrict__ src, float* __restrict__ sink, long n_vec) {
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (long)gridDim.x * 256) {
+        const float4 v = src[i];
+        acc += v.x + v.y + v.z + v.w;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sink + blockIdx.x, acc);
+}
+
 // Row workspace of one GPT forward chain (prefill uses chain 0; decode can run two chains on two streams).
 struct RowWs {
     hipStream_t st = nullptr;
@@ -186,8 +199,13 @@ public:
         kv_half_ = cfg_.kv_fp16 != 0;
         // paged_attention_kernel addresses a layer's pool with 32-bit byte offsets: 494 slots with the fp32 pool, 991 with fp16
         // (at 30 layers that is 120 GiB of K/V; HBM holds ~1000 slots' worth next to the weights)
-        AUR_REQUIRE(n_blocks_ <= (kv_half_ ? 2 * kMaxKvBlocksPerLayer + 1 : kMaxKvBlocksPerLayer),
-                    "K/V pool: a layer's pool must stay below 4 GiB (max_seqs <= 494 with the fp32 pool, <= 991 with kv_fp16)");
+        {
+            const long cap = kv_half_ ? 2 * kMaxKvBlocksPerLayer + 1 : kMaxKvBlocksPerLayer;
+            if (n_blocks_ > cap)
+                throw InvalidArgument("requirement failed: K/V pool: a layer's pool must stay below 4 GiB; with max_speakers = " +
+                                      std::to_string(cfg_.max_speakers) + (kv_half_ ? " and kv_fp16" : " and the fp32 pool") + " max_seqs <= " +
+                                      std::to_string((cap - 2L * cfg_.max_speakers) / kMaxBlocks) + " (asked for " + std::to_string(S) + ")");
+        }
         gemm_prec_ = cfg_.gemm_f32_exact ? 0 : 1;
         kv_.ensure((size_t)cfg_.n_layer * kv_layer_stride_ * (kv_half_ ? 2 : 4));
         for (int b = (int)n_blocks_ - 1; b >= 0; --b) free_blocks_.push_back(b);
@@ -826,6 +844,15 @@ public:
         aur_stats s = stats_;
         s.kv_blocks_total = n_blocks_;
         s.kv_blocks_free = (int64_t)free_blocks_.size();
+        s.result_blocks = (int64_t)result_blocks_.size();
+        s.result_blocks_free = 0;
+        s.result_block_bytes = 0;
+        for (auto& b : result_blocks_) {
+            if (b->refs == 0) s.result_blocks_free++;
+            s.result_block_bytes += (int64_t)b->buf.bytes;
+        }
+        s.speakers = (int64_t)spk_rows_.size();
+        s.sequences_tracked = (int64_t)seqs_.size();
         return s;
     }
     void reset_stats() {
@@ -937,8 +964,9 @@ public:
     }
     // Stress of the K-split projection's cross-workgroup protocol (gemm_rows_kernel.inc, KSP: write-through partial tiles, drained
     // vmcnt, device-scope ticket, sc0 sc1 read-back by the last arriver, counter reset for the next launch): `iters` back-to-back
-    // launches of the K = 4096 -> 1024 residual GEMM at M rows, no host synchronisation in between, each compared word for word on
-    // the device with the UNSPLIT kernel's result on the same operands.  A visibility bug shows up as a non-zero count.
+    // launches of the K = 4096 -> 1024 residual GEMM at M rows, no host synchronisation in between, on two alternating operand
+    // sets and beside a second stream that streams 256 MiB per launch, each compared word for word on the device with the UNSPLIT
+    // kernel's result on the matching operands.  A visibility bug shows up as a non-zero count (dbg_gemm_rows_ksplit_stress).
     long long dbg_lane_xor_selftest(int blocks) {
         use();
         AUR_REQUIRE(blocks >= 1 && blocks <= 4096, "lane_xor selftest: 1..4096 workgroups");
@@ -956,17 +984,21 @@ public:
         const int K = 4 * kHidden, N = kHidden;
         AUR_REQUIRE(M >= 1 && M <= 32 && iters >= 1, "ksplit stress: the split is used for M <= 32 rows");
         AUR_REQUIRE(gemm_rows_shape(M, N, K, false).ksp > 1, "ksplit stress: the policy does not split at this M");
+        // TWO operand sets, alternated launch by launch: consecutive launches publish DIFFERENT partial tiles into ksp_buf, so a
+        // last arriver that read a stale partial (the previous launch's, left in a cache the sc0 sc1 read-back failed to bypass, or
+        // a ticket that ran ahead of its data) produces the wrong words -- on identical operands it would have produced the right ones.
         const int mtt = 4;
-        std::vector<float> hx((size_t)mtt * 16 * K), hw((size_t)K * N), hb(N), hh((size_t)mtt * 16 * N);
+        const size_t nx = (size_t)mtt * 16 * K, nh = (size_t)mtt * 16 * N;
+        std::vector<float> hx(2 * nx), hw((size_t)K * N), hb(N), hh(2 * nh);
         unsigned sd = 12345u + (unsigned)M;
         auto rnd = [&] { sd = sd * 1664525u + 1013904223u; return (float)(sd >> 8) * (1.0f / 8388608.0f) - 1.0f; };
         for (auto& v : hx) v = rnd();
         for (auto& v : hw) v = 0.05f * rnd();
         for (auto& v : hb) v = 0.1f * rnd();
         for (auto& v : hh) v = rnd();
-        DevBuf dx, dw, dwt, db, dh0, dh, dref, dcnt;
+        DevBuf dx, dw, dwt, db, dh0, dh, dref, dcnt, dload, dsink;
         dx.ensure(hx.size() * 4); dw.ensure(hw.size() * 4); dwt.ensure(hw.size() * 4); db.ensure(hb.size() * 4);
-        dh0.ensure(hh.size() * 4); dh.ensure(hh.size() * 4); dref.ensure(hh.size() * 4); dcnt.ensure(8);
+        dh0.ensure(hh.size() * 4); dh.ensure(nh * 4); dref.ensure(hh.size() * 4); dcnt.ensure(8);
         HIP_CHECK(hipMemcpy(dx.p, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(dw.p, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(db.p, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
@@ -974,21 +1006,43 @@ public:
         HIP_CHECK(hipMemsetAsync(dcnt.p, 0, 8, st_));
         launch_pack_wt16(dw.as<float>(), N, dwt.as<float>(), K, N, st_);
         GemmRowsArgs a{};
-        a.X = dx.as<float>(); a.xmt = mtt; a.omt = mtt; a.Wt = dwt.as<float>(); a.M = M; a.N = N; a.K = K; a.bias = db.as<float>(); a.prec = gemm_prec_;
-        a.out = dref.as<float>();   // reference: no scratch -> the unsplit kernel
+        a.xmt = mtt; a.omt = mtt; a.Wt = dwt.as<float>(); a.M = M; a.N = N; a.K = K; a.bias = db.as<float>(); a.prec = gemm_prec_;
+        // references: no scratch -> the UNSPLIT kernel, one per operand set
         HIP_CHECK(hipMemcpyAsync(dref.p, dh0.p, hh.size() * 4, hipMemcpyDeviceToDevice, st_));
-        launch_gemm_rows(a, false, kEpiResidual, st_);
-        a.out = dh.as<float>(); a.ksp_buf = ksp_buf_.as<float>(); a.ksp_cnt = ksp_cnt_.as<unsigned>();
-        for (int i = 0; i < iters; ++i) {
-            HIP_CHECK(hipMemcpyAsync(dh.p, dh0.p, hh.size() * 4, hipMemcpyDeviceToDevice, st_));
+        for (int s = 0; s < 2; ++s) {
+            a.X = dx.as<float>() + s * nx; a.out = dref.as<float>() + s * nh;
             launch_gemm_rows(a, false, kEpiResidual, st_);
-            if (i % 3 == 2) launch_gemm_rows(a, false, kEpiResidual, st_), HIP_CHECK(hipMemcpyAsync(dh.p, dh0.p, hh.size() * 4, hipMemcpyDeviceToDevice, st_)),
-                launch_gemm_rows(a, false, kEpiResidual, st_);   // (two split launches with nothing between them: the counter reset is on the path)
-            launch_count_mismatch(dh.p, dref.p, (long)hh.size(), dcnt.as<unsigned long long>(), st_);
         }
+        // background load on the low-priority stream for the whole test: 256 MiB streamed per launch by 1024 workgroups (256 KiB
+        // each), a launch enqueued for every second split launch (~50 us of traffic against ~25 us per iteration), so that the
+        // split kernel's workgroups start unevenly and its partials, tickets and read-backs share L2 and the fabric with other traffic
+        const size_t load_bytes = (size_t)256 << 20;
+        dload.ensure(load_bytes);
+        dsink.ensure(1024 * 4);
+        HIP_CHECK(hipMemsetAsync(dload.p, 0, load_bytes, st_voc_));
+        HIP_CHECK(hipMemsetAsync(dsink.p, 0, 1024 * 4, st_voc_));
+        HIP_CHECK(hipStreamSynchronize(st_));
+        a.ksp_buf = ksp_buf_.as<float>(); a.ksp_cnt = ksp_cnt_.as<unsigned>();
+        auto split_launch = [&](int s) {
+            HIP_CHECK(hipMemcpyAsync(dh.p, dh0.as<float>() + s * nh, nh * 4, hipMemcpyDeviceToDevice, st_));
+            a.X = dx.as<float>() + s * nx; a.out = dh.as<float>();
+            launch_gemm_rows(a, false, kEpiResidual, st_);
+        };
+        for (int i = 0; i < iters; ++i) {
+            const int s = i & 1;
+            if ((i & 1) == 0)
+                hipLaunchKernelGGL(stress_load_kernel, dim3(1024), dim3(256), 0, st_voc_, dload.as<float4>(), dsink.as<float>(), (long)(load_bytes / 16));
+            if (i % 3 == 2) {   // two split launches on DIFFERENT data with nothing between them but the residual copy: the counter reset
+                split_launch(s ^ 1);   // and the scratch reuse are on the path; only the second one is checked
+            }
+            split_launch(s);
+            launch_count_mismatch(dh.p, dref.as<float>() + s * nh, (long)nh, dcnt.as<unsigned long long>(), st_);
+        }
+        HIP_CHECK(hipGetLastError());
         unsigned long long bad = 0;
         HIP_CHECK(hipMemcpyAsync(&bad, dcnt.p, 8, hipMemcpyDeviceToHost, st_));
         HIP_CHECK(hipStreamSynchronize(st_));
+        HIP_CHECK(hipStreamSynchronize(st_voc_));
         return (long long)bad;
     }
     void dbg_layernorm(const float* h, const float* gamma, const float* beta, float* out, int M) {
@@ -1228,6 +1282,9 @@ private:
         w.ybuf.ensure((size_t)cap * kHidden * 4);
         w.stats.ensure((size_t)cap * 64 * sizeof(float2));
         w.row_meta.ensure((size_t)cap * kRowMetaStride * sizeof(int));
+        // embed_decode writes entries [0, kRowMetaBt + max_blocks) of the live rows only; the look-ahead entries behind them and the rows
+        // >= M of the last tile are READ (their values discarded by selects): defined zeros, not whatever the allocation held
+        HIP_CHECK(hipMemsetAsync(w.row_meta.p, 0, (size_t)cap * kRowMetaStride * sizeof(int), w.st));
         w.h.ensure((size_t)cap * kHidden * 4);
         w.xn.ensure((size_t)cap * kHidden * 4);
         w.qbuf.ensure((size_t)cap * kHidden * 4);
@@ -1909,12 +1966,16 @@ private:
             v_C_.ensure(Bz * 8192 * T * 4);
         }
         HIP_CHECK(hipEventRecord(ev_va_, st_voc_));
-        launch_interp2(d_lat, lat_bstride, d_latrow, d_nlat, d_len, v_z_.as<float>(), (long)T, (long)(1024 * T), 1024, B, maxT, st_voc_);
+        // fp16 vocoder: z leaves the interpolation as interleaved halves (what conv_pre's staging rounded it to anyway) and conv_pre
+        // runs on the LDS-DMA kernel like every other wide conv (round 5: the register-staged kernel, with 32 spilled VGPRs)
+        const bool z_f16 = xt_f16_ && conv_dma_;
+        launch_interp2(d_lat, lat_bstride, d_latrow, d_nlat, d_len, v_z_.as<float>(), (long)T, (long)(1024 * T), 1024, B, maxT, st_voc_, z_f16);
         const float* condt = voc_cond_.as<float>();
         ConvArgs a{};
         a.base_len = d_len; a.B = B; a.cond_row = d_cond; a.cond_stride = kCondStride;
         // conv_pre (+ cond_layer)
-        a.x = v_z_.as<float>(); a.wp = v_pre_.wp; a.wp16 = v_pre_.wp16; a.bias = v_pre_.bias; a.cond = condt; a.res = nullptr; a.mrf = nullptr;
+        a.x = v_z_.as<float>(); a.x_f16 = z_f16 ? 1 : 0; a.zeros = z_f16 ? v_zero_.p : nullptr;
+        a.wp = v_pre_.wp; a.wp16 = v_pre_.wp16; a.bias = v_pre_.bias; a.cond = condt; a.res = nullptr; a.mrf = nullptr;
         a.out = v_s0_.as<float>(); a.len_mul = 1; a.Cin = 1024; a.Mtot = 512; a.Cout = 512;
         a.x_stride = (long)T; a.o_stride = (long)T; a.x_bstride = (long)(1024 * T); a.o_bstride = (long)(512 * T);
         a.padl = 3; a.slope = 1.0f; a.ups_s = 0; a.ups_p = 0; a.mrf_mode = 0; a.max_len = maxT;

@@ -1433,8 +1433,11 @@ __global__ __launch_bounds__(256) void sampler_kernel(const int* __restrict__ sa
 #pragma unroll
                 for (int u = 0; u < 17; ++u) c += __popcll(__ballot(wvv[u] >= x));
                 if (c >= topk) lo = x;
-                if (c == topk) break;
+                // (not below the image of the smallest finite float: with fewer than k finite logits the search must run on to the k-th
+                // value's own image, -inf, or the survivor set would differ from the full sort's "k plus ties")
+                if (c == topk && x >= 0x00800000u) break;
             }
+            if (lo < 0x007FFFFFu) lo = 0x007FFFFFu;   // image of -inf: below it lie only NaN patterns, and `z < NaN` would mask nothing
             unsigned ov[5];
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
@@ -1557,9 +1560,9 @@ __global__ __launch_bounds__(256) void sampler_kernel(const int* __restrict__ sa
         const float maxv = ord2f((unsigned)(keys[0] >> 32));
         // top-p on the ascending-sorted softmax: mask cumsum <= 1-p, never the largest.  The two sums are serial BY DEFINITION (their
         // bits decide the cut: sum in rank order, cumulative sum in double from the smallest probability up), but their terms are
-        // not: for n1 <= 256 candidates (always on the top-k path) every thread computes its rank's exp and probability, and thread 0
-        // only adds -- until round 5 it evaluated 2 n1 expf and n1 divisions one after the other (~7 us of the kernel's 27).
-        // Same operands into the same additions in the same order: the same bits.
+        // not: for n1 <= 256 candidates (always on the top-k path) every thread computes its rank's exp and probability, and only the
+        // additions are serial -- until round 5 one thread evaluated 2 n1 expf and n1 divisions one after the other (~7 us of the
+        // kernel's 27).  Same operands into the same additions in the same order: the same bits.
         if (topp < 1.0f) {
             if (n1 <= 64) {
                 // the usual case (k = 50 plus ties): one wave does all of it in registers, no LDS and no barrier -- the serial float
@@ -1570,15 +1573,16 @@ __global__ __launch_bounds__(256) void sampler_kernel(const int* __restrict__ sa
 #pragma unroll
                     for (int r = 0; r < 64; ++r) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ev), r));
                     const float pr = ev / sum;
-                    double c = tid < n1 ? (double)pr : 0.0;
-#pragma unroll
-                    for (int sh = 1; sh < 64; sh <<= 1) {   // inclusive suffix scan: lane l += lane l + sh
-                        const int lo32 = __shfl_down((int)(unsigned)__double_as_longlong(c), sh, 64);
-                        const int hi32 = __shfl_down((int)(unsigned)(__double_as_longlong(c) >> 32), sh, 64);
-                        const double o = __longlong_as_double(((long long)hi32 << 32) | (unsigned)lo32);
-                        if (tid + sh < 64) c += o;
+                    // c_r = pr[n1-1] + ... + pr[r], accumulated in double in exactly that order -- the reference's cumsum over the
+                    // ascending-sorted probabilities (torch accumulates a float cumsum in double on the CPU) -- so the cut is the serial
+                    // form's bit for bit, by construction: 63 dependent adds on readlane values (~0.5 us), every lane keeps its rank's sum
+                    double c = 0.0, mine = 0.0;
+#pragma unroll 7
+                    for (int r = 63; r >= 1; --r) {
+                        c += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pr), r));
+                        if (tid == r) mine = c;
                     }
-                    if (tid >= 1 && tid < n1 && (float)c <= 1.0f - topp) z[(unsigned)(keys[tid] & 0xffffffffull)] = -INFINITY;
+                    if (tid >= 1 && tid < n1 && (float)mine <= 1.0f - topp) z[(unsigned)(keys[tid] & 0xffffffffull)] = -INFINITY;
                 }
             } else if (n1 <= 256) {
                 const float ev = tid < n1 ? expf(ord2f((unsigned)(keys[min(tid, n1 - 1)] >> 32)) - maxv) : 0.f;
@@ -1591,26 +1595,22 @@ __global__ __launch_bounds__(256) void sampler_kernel(const int* __restrict__ sa
                 }
                 __syncthreads();
                 const float pr = ev / sh_f[1];
-                // c_r = pr[n1-1] + ... + pr[r] in double: rank r is masked iff r >= 1 and float(c_r) <= 1 - p.  c_r grows as r falls,
-                // so "mask until the first rank that fails" (the serial form) is the same set as "mask every rank whose own c_r
-                // passes": the ranks are independent once c_r is known, and c_r is a suffix sum -- four waves scan 64 ranks each
-                // on shuffles (double: two dwords), a carry per wave through LDS.  (The additions are those of the serial loop in
-                // another order; in double they are exact unless a term is below 2^-29 of the running sum, a difference of one
-                // unit in the 53rd bit, against the 24 bits the comparison looks at.)
-                double c = tid < n1 ? (double)pr : 0.0;
-                const int lane = tid & 63;
-#pragma unroll
-                for (int sh = 1; sh < 64; sh <<= 1) {   // inclusive suffix scan inside the wave: lane l += lane l + sh
-                    const int lo32 = __shfl_down((int)(unsigned)__double_as_longlong(c), sh, 64);
-                    const int hi32 = __shfl_down((int)(unsigned)(__double_as_longlong(c) >> 32), sh, 64);
-                    const double o = __longlong_as_double(((long long)hi32 << 32) | (unsigned)lo32);
-                    if (lane + sh < 64) c += o;
-                }
-                __shared__ double carry[4];
-                if (lane == 0) carry[tid >> 6] = c;   // the wave's total
                 __syncthreads();
-                for (int w2 = (tid >> 6) + 1; w2 < 4; ++w2) c += carry[w2];
-                if (tid >= 1 && tid < n1 && (float)c <= 1.0f - topp) z[(unsigned)(keys[tid] & 0xffffffffull)] = -INFINITY;
+                sv[tid] = pr;
+                __syncthreads();
+                // (65..256 candidates only when dozens of logits tie at the k-th value: the serial form itself, on the probabilities the
+                // threads computed)
+                if (tid == 0) {
+                    const float lim = 1.0f - topp;
+                    double c = 0.0;
+                    for (int r = n1 - 1; r >= 1; --r) {
+                        c += (double)sv[r];
+                        if ((float)c <= lim)
+                            z[(unsigned)(keys[r] & 0xffffffffull)] = -INFINITY;
+                        else
+                            break;
+                    }
+                }
             } else if (tid == 0) {
                 float sum = 0.f;
                 for (int r = 0; r < n1; ++r) sum += expf(ord2f((unsigned)(keys[r] >> 32)) - maxv);

@@ -89,8 +89,10 @@ void launch_resblock_round_f16(const RoundArgs& a, int KS, int DIL, hipStream_t 
 void launch_conv1d_f16(const ConvArgs& a, int KS, int DIL, hipStream_t st);
 
 // z[b][c][j] = interp(interp(latents[b]^T, x4), x24000/22050)[c][j]   (hifigan_decoder.py:787-800)
+// out_f16: z is written as interleaved halves [B][C/16][z_stride][16] = fp16 of the same values (strides in elements), the layout the
+// LDS-DMA conv kernel stages from
 void launch_interp2(const float* lat, long lat_bstride, const int* lat_row, const int* n_lat, const int* base_len, float* z,
-                    long z_stride, long z_bstride, int C, int B, int max_len, hipStream_t st);
+                    long z_stride, long z_bstride, int C, int B, int max_len, hipStream_t st, bool out_f16 = false);
 
 // wav[b][t] = tanh(sum_{ci,j} w[ci][j] * lrelu(x[b][ci][t+j-3], slope))   (conv_post, no bias)
 void launch_conv_post(const float* x, const float* w, float* wav, const int* base_len, int len_mul, int Cin,

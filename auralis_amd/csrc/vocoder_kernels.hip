@@ -533,8 +533,12 @@ void launch_conv1d(const ConvArgs& a, int KS, int DIL, hipStream_t st) {
 // XH: the input tensor is fp16 in HBM and already activated (ConvArgs::x_f16), staged without conversion.
 // Staging is synchronous (load -> barrier -> LDS write -> barrier -> MFMAs) at 3 waves per SIMD; the software-pipelined and
 // 512-position forms measured in round 2 (92-111 ms against 94-103 per batch) are gone from the source.
+// MT = 64 (a 64 x 64 accumulator tile per wave next to the staging registers) needs more than the 168 registers of three waves per
+// SIMD: round 5 compiled it at three and spilled 32 VGPRs per lane to scratch; those instantiations now run two
+// waves per SIMD.  None of them is on the default path any more (conv_pre moved to the LDS-DMA kernel): they serve the A/B switches
+// (AUR_CONV_DMA=0, AUR_XT_F16=0) and the fp32-input parity entry point.
 template <int KS, int DIL, int MT, bool XH>
-__global__ __launch_bounds__(256, 3) void conv1d_mfma_f16_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, MT == 64 ? 2 : 3) void conv1d_mfma_f16_kernel(ConvArgs a) {
     constexpr int CK = 16;
     constexpr int WM = MT / 32;
     constexpr int WN = (MT == 64) ? 2 : 4;
@@ -681,21 +685,29 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // NWV = waves per workgroup: the tile is MT channels x (NWV * 32 * WN) positions.  The packed weights of a chunk are the same for
 // every position tile, so a workgroup of 8 waves (512 positions) pulls them through the CU's L1 once for twice the MFMAs.
 // EPIH: the all-halves epilogue (conv_epilogue_plain_h; the launcher checks that the tensors are halves).
+// MT = 128 (round 6): the tile spans TWO of the packed 64-channel weight tiles (the packing stays [Mtot/64][Cin/16][KS][64][16]: the
+// chunk's two weight images land back to back in LDS), a wave keeps a 128-channel x 64-position accumulator tile (128 registers: one
+// workgroup of eight waves per CU), and every staged input window feeds twice the MFMAs: the global -> LDS operand fill, which bounds
+// the k = 3 / 7 convs of the 128- and 256-channel stages (~12.5 B/clk/CU measured, profiles/r05_pmc_conv_latency.txt), drops from
+// 22.6 to 14.4 KB per 96 MFMAs at k = 3.  Same chunk, tap and MFMA order per output element: bitwise the MT = 64 result.
 template <int KS, int DIL, int MT, int NBUF, int NWV = 4, bool EPIH = false>
-__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 4) void conv1d_dma_f16_kernel(ConvArgs a) {   // (two workgroups per CU either way)
+__global__ __launch_bounds__(64 * NWV, MT == 128 ? 2 : NWV == 4 ? 2 : 4) void conv1d_dma_f16_kernel(ConvArgs a) {   // (two workgroups per CU; one at MT = 128)
     constexpr int CK = 16;
     constexpr int WM = MT / 32;
-    constexpr int WN = (MT == 64) ? 2 : 4;
+    constexpr int WN = (MT == 32) ? 4 : 2;
     constexpr int NTW = 32 * WN;
     constexpr int NT = NWV * NTW;
     constexpr int HALO = (KS - 1) * DIL;
     constexpr int XROW = NT + HALO;
-    constexpr int WI = KS * MT * 2 / 64;                   // weight copies (1 KiB each) per chunk
+    constexpr int MTP = MT == 128 ? 64 : MT;               // channels per packed weight tile
+    constexpr int WIP = KS * MTP * 2 / 64;                 // 1-KiB copies of one packed tile's chunk
+    constexpr int WI = WIP * (MT / MTP);                   // weight copies per chunk
     constexpr int XI0 = (2 * XROW + 63) / 64;
     constexpr int XI = XI0 + (NWV - (WI + XI0) % NWV) % NWV;   // input-window copies, padded so that every wave issues IPW of them
     constexpr int IPW = (WI + XI) / NWV;
     constexpr int BUF = (WI + XI) * 1024;
-    static_assert((KS * MT * 2) % 64 == 0 && IPW * (NBUF - 2) < 64, "DMA bookkeeping");
+    static_assert((KS * MTP * 2) % 64 == 0 && IPW * (NBUF - 2) < 64, "DMA bookkeeping");
+    static_assert(NBUF * BUF <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(1024))) char smem[NBUF * BUF];
 
     const int b = blockIdx.z;
@@ -716,7 +728,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 4) void conv1d_dma_f16_ker
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const char* wsrc_tile = reinterpret_cast<const char*>(a.wp16) + (long)mtile * (a.Cin / CK) * (WI * 1024);
+    const long wtile_bytes = (long)(a.Cin / CK) * (WIP * 1024);   // one packed 64- (32-) channel tile, all chunks
+    const char* wsrc_tile = reinterpret_cast<const char*>(a.wp16) + (long)mtile * (MT / MTP) * wtile_bytes;
     const _Float16* xhb = reinterpret_cast<const _Float16*>(a.x) + (long)b * a.x_bstride;
     const unsigned sbase = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
     const int nch = a.Cin / CK;
@@ -727,9 +740,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 4) void conv1d_dma_f16_ker
         for (int k = 0; k < IPW; ++k) {
             const int ii = wvs + NWV * k;
             const bool is_w = ii < WI;   // wave-uniform; selects instead of branches keep the copy sequence straight-line
-            const int s = (is_w ? ii : ii - WI) * 64 + lane, row = s >> 1, h = (s & 1) ^ ((row >> 3) & 1);
+            const int iw = (MT == MTP) ? ii : (ii >= WIP ? ii - WIP : ii);   // copy index inside its packed tile
+            const int s = (is_w ? iw : ii - WI) * 64 + lane, row = s >> 1, h = (s & 1) ^ ((row >> 3) & 1);
             const int t = q0 - a.padl + row;
-            const char* wsrc = wsrc_tile + (long)c * (WI * 1024) + (row * 2 + h) * 16;
+            const char* wsrc = wsrc_tile + ((MT != MTP && ii >= WIP) ? wtile_bytes : 0L) + (long)c * (WIP * 1024) + (row * 2 + h) * 16;
             const char* xsrc = reinterpret_cast<const char*>(xhb + ((long)c * a.x_stride + t) * 16 + 8 * h);
             const char* src = is_w ? wsrc : (t >= 0 && t < len_in) ? xsrc : reinterpret_cast<const char*>(a.zeros);
             glds16(src, __builtin_amdgcn_readfirstlane(dst0 + (unsigned)ii * 1024));
@@ -757,7 +771,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 4) void conv1d_dma_f16_ker
         for (int j = 0; j < KS; ++j) {
             h16x8 av[WM], bv[WN];
 #pragma unroll
-            for (int m = 0; m < WM; ++m) av[m] = *reinterpret_cast<const h16x8*>(wb + (j * MT + m * 32) * 32);
+            for (int m = 0; m < WM; ++m)   // (MT = 128: m = 2, 3 live in the second packed tile's image, WIP KiB further on)
+                av[m] = *reinterpret_cast<const h16x8*>(wb + (m * 32 / MTP) * (WIP * 1024) + (j * MTP + (m * 32) % MTP) * 32);
             const int i0 = l31 + j * DIL;
             const char* xp = xb + i0 * 32 + 16 * (hi ^ ((i0 >> 3) & 1));
 #pragma unroll
@@ -795,6 +810,23 @@ static int conv_dma_waves() {
     }();
     return w;
 }
+// Output-channel tile of the all-halves convs whose Mtot is a multiple of 128 (the ResBlock convs of the 256- and 128-channel
+// stages, conv_pre): 128 (default, round 6) or 64 (AUR_CONV_MT=64: round 5's tile, A/B).  Bit mask AUR_CONV_MT128_KS selects the
+// tap counts that take the wide tile (1 = k 3, 2 = k 7, 4 = k 11; default all).
+static int conv_dma_mt() {
+    static const int v = [] {
+        const char* e = getenv("AUR_CONV_MT");
+        return e ? atoi(e) : 128;
+    }();
+    return v;
+}
+static int conv_dma_mt128_ks() {
+    static const int v = [] {
+        const char* e = getenv("AUR_CONV_MT128_KS");
+        return e ? atoi(e) : 7;
+    }();
+    return v;
+}
 template <int KS, int DIL>
 static void launch_conv_dma(const ConvArgs& a, hipStream_t st) {
     constexpr int NBUF = KS >= 11 ? 2 : KS >= 3 ? 3 : 4;   // the fewer taps, the shorter a chunk's MFMA phase and the deeper the prefetch
@@ -804,6 +836,15 @@ static void launch_conv_dma(const ConvArgs& a, hipStream_t st) {
     const int n_q = a.ups_s ? a.max_len + 1 : a.max_len;
     const bool all_halves = a.ups_s == 0 && (!a.res || a.res_f16) && (a.mrf_mode == 0 || a.mrf_f16) &&
                             ((a.mrf_mode == 1 || a.mrf_mode == 2) || a.out_act_f16);
+    if constexpr (KS >= 3) {
+        const int ksbit = KS == 3 ? 1 : KS == 7 ? 2 : 4;
+        if (a.Mtot % 128 == 0 && conv_dma_waves() == 8 && all_halves && conv_dma_mt() == 128 && (conv_dma_mt128_ks() & ksbit)) {
+            constexpr int NB128 = KS >= 7 ? 2 : 3;
+            dim3 grid((n_q + 511) / 512, a.Mtot / 128, a.B);
+            hipLaunchKernelGGL((conv1d_dma_f16_kernel<KS, DIL, 128, NB128, 8, true>), grid, dim3(512), 0, st, a);
+            return;
+        }
+    }
     if (a.Mtot % 64 == 0 && conv_dma_waves() == 8 && KS >= 3 && all_halves) {
         constexpr int NB8 = KS >= 7 ? 2 : 3;
         dim3 grid((n_q + 511) / 512, a.Mtot / 64, a.B);
@@ -1148,10 +1189,57 @@ __global__ __launch_bounds__(256) void interp2_kernel(const float* __restrict__ 
     z[(long)b * z_bstride + (long)c * z_stride + j] = (1.0f - lam2) * y[0] + lam2 * y[1];
 }
 
+// The same values as interleaved halves z16[b][C/16][z_stride][16] = fp16(z) -- what conv_pre's staging rounds the fp32 z to anyway
+// (its input activation is the identity), so conv_pre can take the LDS-DMA kernel on bit-identical MFMA operands.  A thread = eight
+// channels of one position: 32 contiguous bytes of each of the (at most four) latent rows it blends, one 16-byte store.
+__global__ __launch_bounds__(256) void interp2_h_kernel(const float* __restrict__ lat, long lat_bstride, const int* __restrict__ lat_row,
+                                                        const int* __restrict__ n_lat, const int* __restrict__ base_len,
+                                                        _Float16* __restrict__ z, long z_stride, long z_bstride, int C, float r1, float r2) {
+    const int b = blockIdx.z;
+    const int c8 = blockIdx.y * 8;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int L0 = n_lat[b];
+    const int L1 = 4 * L0;
+    const int L2 = base_len[b];
+    if (j >= L2) return;
+    const float* x = lat + (long)(lat_row ? lat_row[b] : b) * lat_bstride + c8;
+    int i0, i1;
+    float lam2;
+    lin_src(r2, j, L1, i0, i1, lam2);
+    const int idx[2] = {i0, i1};
+    float y[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int k0, k1;
+        float lam1;
+        lin_src(r1, idx[u], L0, k0, k1, lam1);
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(x + (long)k0 * C), a1 = *reinterpret_cast<const f32x4*>(x + (long)k0 * C + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(x + (long)k1 * C), b1 = *reinterpret_cast<const f32x4*>(x + (long)k1 * C + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y[u][e] = (1.0f - lam1) * a0[e] + lam1 * b0[e];
+            y[u][e + 4] = (1.0f - lam1) * a1[e] + lam1 * b1[e];
+        }
+    }
+    h16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)((1.0f - lam2) * y[0][e] + lam2 * y[1][e]);
+    *reinterpret_cast<h16x8*>(z + (long)b * z_bstride + ((long)(c8 >> 4) * z_stride + j) * 16 + (c8 & 15)) = o;
+}
+
 void launch_interp2(const float* lat, long lat_bstride, const int* lat_row, const int* n_lat, const int* base_len, float* z,
-                    long z_stride, long z_bstride, int C, int B, int max_len, hipStream_t st) {
+                    long z_stride, long z_bstride, int C, int B, int max_len, hipStream_t st, bool out_f16) {
     const float r1 = (float)(1.0 / (1024.0 / 256.0));
     const float r2 = (float)(1.0 / (24000.0 / 22050.0));
+    if (out_f16) {
+        AUR_REQUIRE(C % 16 == 0, "interp2: whole 16-channel chunks for the interleaved fp16 output");
+        dim3 grid((max_len + 255) / 256, C / 8, B);
+        trace_launch("interp2_h_kernel");
+        hipLaunchKernelGGL(interp2_h_kernel, grid, dim3(256), 0, st, lat, lat_bstride, lat_row, n_lat, base_len,
+                           reinterpret_cast<_Float16*>(z), z_stride, z_bstride, C, r1, r2);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     dim3 grid((max_len + 255) / 256, C, B);
     trace_launch("interp2_kernel");
     hipLaunchKernelGGL(interp2_kernel, grid, dim3(256), 0, st, lat, lat_bstride, lat_row, n_lat, base_len, z, z_stride,

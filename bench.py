@@ -12,10 +12,11 @@ same workload once more with aur_set_profile on: HIP events on the stream the ke
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-Other workloads: `--workload c2` (configs[1]: ONE 200-char utterance, greedy, batch 1: time to audio), `--workload c5s` (configs[4]
+Other workloads: `--workload c3f` (the headline workload as 64 concurrent TTSRequests through the TTS facade: the drop-in boundary on
+the clock), `--workload c2` (configs[1]: ONE 200-char utterance, greedy, batch 1: time to audio), `--workload c5s` (configs[4]
 at single-GPU scale: one GPU's eighth of the ~450 k characters, mixed en/fr/de through longform.stream_longform, natural stop, ragged),
 `--workload c4` (configs[3]: 512 utterances dealt 64 at a time to the ranks by parallel.shard_units, strong scaling).  The default
-run also measures c2 and c5s once after the headline (`--no-side` skips them) and, under torchrun with N > 1, c4.
+run also measures c3f, c2 and c5s once after the headline (`--no-side` skips them) and, under torchrun with N > 1, c4.
 
 Output: the LAST stdout line is one compact JSON object (< 4 KB: the contract fields + roofline + cpu_baseline + one summary per
 side workload); everything else goes to gpurun_out/bench_full.json and stderr.
@@ -357,6 +358,57 @@ class Bench:
                 "decode_step": ds, "wall_ms_all_reps": [w * 1e3 for w in walls],
                 "hbm_floor_ms_per_step": (ds["bytes_per_step_as_stored"] / (HBM_PEAK_GBPS * 1e9) * 1e3) if ds else None}
 
+    # -- c3f: the headline workload at the DROP-IN boundary: the same 64 utterances as 64 concurrent TTSRequests through the facade
+    #    (TTS.generate_speech_async -> TwoPhaseScheduler -> XTTSv2Engine plugin -> EngineDriver thread -> C ABI), what a user of the
+    #    reference's generate_speech() gets (core/tts.py:196-233, XTTSv2.py:762-814).  Same engine, same sampling, fixed length.
+    C3F_TEXT = ("the old lighthouse keeper climbed the spiral stairs every evening and counted the ships on the horizon while the "
+                "wind pushed grey clouds over the waters and the gulls went quiet above the harbour wall")   # 200 characters
+
+    def workload_c3f(self, reps=3):
+        import asyncio
+
+        from auralis_amd import TTS, TTSRequest
+        from auralis_amd.api.text import XTTSTokenizer
+        from auralis_amd.api.xtts_engine import XTTSv2Engine
+        a, eng = self.args, self.eng
+        tok = XTTSTokenizer(None, vocab_size=self.xtts_sd["text_embedding.weight"].shape[0], synthetic=True)
+        n_ids = len(tok.batch_encode_with_split(self.C3F_TEXT, "en")[0])
+        assert n_ids == len(self.text_ids), f"c3f text gives {n_ids} ids, the headline uses {len(self.text_ids)}"
+        xe = XTTSv2Engine(eng, tok, max_concurrency=a.batch, gpt_max_audio_tokens=a.tokens)
+        xe.fixed_length = True
+        tts = TTS(scheduler_max_concurrency=a.batch).with_engine(xe)
+        voice = {"gpt_cond_latent": self.cond.numpy(), "speaker_embedding": self.spk.numpy()}
+
+        async def batch(k):
+            reqs = [TTSRequest(text=self.C3F_TEXT, speaker_files=[voice], language="en", temperature=0.75, top_p=0.85, top_k=50,
+                               repetition_penalty=5.0, seed=(self.rank * 100003 + (k + 7) * 1009 + b)) for b in range(a.batch)]
+            outs = await asyncio.gather(*[tts.generate_speech_async(r) for r in reqs])
+            return sum(len(o.array) for o in outs), sum(int(o.token_length or 0) for o in outs)
+
+        def run(k):
+            return asyncio.run_coroutine_threadsafe(batch(k), tts._loop).result()
+        try:
+            run(-1)   # warm-up
+            eng.reset_stats()
+            self.fence()
+            t0 = time.perf_counter()
+            ns = nt = 0
+            for k in range(reps):
+                s_, t_ = run(k)
+                ns += s_
+                nt += t_
+            self.fence()
+            dt = time.perf_counter() - t0
+            st = eng.stats()
+        finally:
+            tts.close(keep_engine=True)
+        return {"workload": f"BASELINE configs[2] through the facade: {a.batch} concurrent TTSRequest(text=<{len(self.C3F_TEXT)} chars>, "
+                            f"speaker_files=[voice], seed=...) -> TTS(scheduler_max_concurrency={a.batch}).generate_speech_async, {n_ids} text ids, "
+                            f"{a.tokens} mel tokens fixed-length, T=0.75 top_p=0.85 top_k=50 rep_pen=5.0; {reps} batches",
+                "reps": reps, "ms_per_step": dt / reps * 1e3, "samples": ns, "tokens": nt, "samples_per_s": ns / dt, "rtf": dt / (ns / 24000.0),
+                "prefill_batches_per_step": st["prefill_batches"] / reps, "vocoder_batches_per_step": st["vocoder_batches"] / reps,
+                "decode_steps_per_step": st["decode_steps"] / reps, "failed_steps": xe.driver.failed_steps}
+
     # -- c5s: BASELINE configs[4] at single-GPU scale: mixed-language long form through the facade, natural stop, ragged
     def workload_c5s(self, chars=56250, window=None):
         from auralis_amd import TTS
@@ -400,10 +452,11 @@ class Bench:
             self.fence()
             t0 = time.perf_counter()
             first, n_chunks, ns, order_ok, last = None, 0, 0, True, -1
-            toks = []
+            toks, stamps = [], []
             for i, c in stream_longform(tts, reqs, window=window):
+                stamps.append(time.perf_counter() - t0)
                 if first is None:
-                    first = time.perf_counter() - t0
+                    first = stamps[0]
                 order_ok &= i >= last
                 last = i
                 n_chunks += 1
@@ -418,7 +471,9 @@ class Bench:
             else:
                 eng.load_weights({"mel_head.b": np.asarray(self.packed["mel_head.b"], np.float32)})
         occ = st["decode_rows"] / max(1, st["decode_steps"]) / slots
-        return {"workload": f"BASELINE configs[4] at 1-GPU scale: {sum(len(p) for p in paras)} chars, {len(paras)} paragraphs en/fr/de "
+        gaps = np.diff(np.asarray(stamps)) if len(stamps) > 1 else np.zeros(1)
+        return {"first_chunk_tokens": toks[0] if toks else None, "p95_chunk_gap_s": float(np.percentile(gaps, 95)), "max_chunk_gap_s": float(gaps.max()),
+                "workload": f"BASELINE configs[4] at 1-GPU scale: {sum(len(p) for p in paras)} chars, {len(paras)} paragraphs en/fr/de "
                             f"(language=auto), {n_chunks} chunks, natural stop (mel_head.bias[1025] = {STOP_BIAS_C5S}), {window} paragraphs in flight (every chunk of them submitted; facade gate {inflight}) "
                             f"on {slots} slots (admit_min_batch {a.admit_min_batch or max(1, slots // 8)}), streamed in (paragraph, chunk) order "
                             f"through TTS / longform.stream_longform",
@@ -509,11 +564,20 @@ def compact(line, full_path):
                      "vocoder_ms": _r(c2["vocoder_ms"])}
     elif c2:
         out["c2"] = c2
+    c3f = line.get("c3f")
+    if c3f and "error" not in c3f:
+        out["c3f"] = {"ms_per_step": _r(c3f["ms_per_step"], 5), "samples_per_s": _r(c3f["samples_per_s"], 5),
+                      "facade_overhead_ms": _r(c3f["ms_per_step"] - line["ms_per_step"], 3),
+                      "facade_overhead_frac": _r(c3f["ms_per_step"] / line["ms_per_step"] - 1.0, 3),
+                      "prefill_batches_per_step": _r(c3f["prefill_batches_per_step"], 3),
+                      "vocoder_batches_per_step": _r(c3f["vocoder_batches_per_step"], 3)}
+    elif c3f:
+        out["c3f"] = c3f
     c5 = line.get("c5s")
     if c5 and "error" not in c5:
         out["c5s"] = {"slots": c5.get("slots"), "chars": c5["chars"], "chunks": c5["chunks"], "samples_per_s": _r(c5["samples_per_s"]), "rtf": _r(c5["rtf"]),
                       "slot_occupancy": _r(c5["slot_occupancy"]), "decode_ms_per_step": _r(c5.get("decode_ms_per_step")), "first_chunk_s": _r(c5["first_chunk_s"]),
-                      "in_order": c5["in_order"]}
+                      "first_chunk_tokens": c5.get("first_chunk_tokens"), "p95_chunk_gap_s": _r(c5.get("p95_chunk_gap_s")), "in_order": c5["in_order"]}
     elif c5:
         out["c5s"] = c5
     c4 = line.get("c4")
@@ -533,8 +597,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["c3", "c2", "c5s", "c4"], default="c3",
-                    help="c3 (default) = BASELINE configs[2], the headline; c2 / c5s / c4 run only that workload and print its record")
+    ap.add_argument("--workload", choices=["c3", "c3f", "c2", "c5s", "c4"], default="c3",
+                    help="c3 (default) = BASELINE configs[2], the headline; c3f (the same through the TTS facade) / c2 / c5s / c4 run only "
+                         "that workload and print its record")
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
     ap.add_argument("--tokens", type=int, default=280, help="mel tokens per utterance (fixed-length mode)")
     ap.add_argument("--layers", type=int, default=30)
@@ -699,7 +764,8 @@ def main():
     if args.workload != "c3":   # ad-hoc: one workload, its own record
         if args.warmup:
             B.run_batches(range(-args.warmup, 0), batch=(1 if args.workload == "c2" else None))
-        rec = {"c2": B.workload_c2, "c5s": lambda: B.workload_c5s(args.c5_chars), "c4": B.workload_c4}[args.workload]()
+        rec = {"c2": B.workload_c2, "c5s": lambda: B.workload_c5s(args.c5_chars), "c4": B.workload_c4,
+               "c3f": lambda: B.workload_c3f(max(1, args.steps))}[args.workload]()
         if rank == 0:
             rec["n_gpus"] = world
             print(json.dumps(rec), file=json_out, flush=True)
@@ -774,9 +840,10 @@ def main():
         if use_dist:
             line["multi_gpu"] = multi
     # ---- side workloads
-    c2 = c5 = c4 = None
+    c2 = c5 = c4 = c3f = None
     if not args.no_side:
         if world == 1:
+            c3f = side("c3f", lambda: B.workload_c3f(max(1, min(args.steps, 10))))
             c2 = side("c2", B.workload_c2)
             c5 = side("c5s", lambda: B.workload_c5s(args.c5_chars))
         else:
@@ -810,7 +877,7 @@ def main():
         if line is not None:
             line["multi_gpu"] = multi
     if rank == 0:
-        line["c2"], line["c5s"], line["c4"] = c2, c5, c4
+        line["c2"], line["c5s"], line["c4"], line["c3f"] = c2, c5, c4, c3f
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B.gpt_sd, B.xtts_sd, dims, B.cond, B.spk, B.text_ids, args.cpu_tokens, args.cpu_c1,
                                                 activation="gelu" if B.gelu_erf else "gelu_new")

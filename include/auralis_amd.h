@@ -35,8 +35,9 @@ typedef struct aur_engine aur_engine;
  * (XTTSv2.py:198-232: max_model_len 1047, max_num_seqs = concurrency, block size 16). */
 typedef struct aur_config {
     int32_t n_layer;          /* GPT blocks (30 for XTTSv2; tests may use fewer) */
-    int32_t max_seqs;         /* concurrent sequences (continuous-batching slots); <= 494 (fp32 K/V pool) / 991 (kv_fp16): a layer's
-                                 pool is addressed with 32-bit byte offsets */
+    int32_t max_seqs;         /* concurrent sequences (continuous-batching slots).  A layer's K/V pool is addressed with 32-bit byte
+                                 offsets, so max_seqs * 66 + 2 * max_speakers blocks must stay <= 32767 (fp32 pool; 65535 with
+                                 kv_fp16): 494 / 991 slots at the default 64 speakers; aur_engine_create reports the limit it computed */
     int32_t max_prefill_rows; /* cap on prompt rows prefetched in one step (0 = default 8192) */
     int32_t max_speakers;     /* speaker-conditioning table entries (0 = default 64) */
     int32_t vocoder_min_batch;/* finished sequences wait until this many are ready for one vocoder pass -- at most 16 steps (~30 ms) counted
@@ -157,6 +158,13 @@ typedef struct aur_stats {
     double conv_class_bytes[5];
     double conv_class_flops[5];
     int64_t prefill_batches;       /* prefill passes (one per aur_step that admitted sequences; aur_config.admit_min_batch groups them) */
+    /* resource gauges (not reset by aur_reset_stats): what a soak test watches next to hipMemGetInfo (the reference's only resource
+     * assertion is tests/integration/memory_leak.py:42-51, VRAM delta over 100 generate_speech calls) */
+    int64_t result_blocks;         /* pinned result blocks the engine has allocated (one per vocoder batch in flight or undelivered) */
+    int64_t result_blocks_free;    /* ... of which no sequence holds a reference (reusable by the next vocoder batch) */
+    int64_t result_block_bytes;    /* pinned host bytes of all result blocks */
+    int64_t speakers;              /* voices registered in the speaker table (<= aur_config.max_speakers) */
+    int64_t sequences_tracked;     /* sequences the engine still holds (waiting, running, vocoding, or finished and not yet released) */
 } aur_stats;
 
 const char* aur_last_error(void);
@@ -248,8 +256,10 @@ int aur_dbg_gemm(aur_engine* e, const float* X, const float* W, float* out, int3
 int aur_dbg_gemm_rows(aur_engine* e, const float* X, const float* W, const float* bias, const float* gamma,
                       const float* beta, float* out, int32_t M, int32_t N, int32_t K, int32_t epi, int32_t ln);
 /* Stress of the decode GEMM's K-split form (the K = 4096 -> 1024 projection at M <= 32 live sequences, same reference linear): `iters`
- * back-to-back launches on fixed pseudo-random operands, each compared bitwise on the device with the unsplit kernel's result;
- * *mismatches_out = differing 32-bit words over all launches (0 = the cross-workgroup hand-off held every time). */
+ * back-to-back launches that ALTERNATE between two pseudo-random operand sets (activations and residual), so that consecutive
+ * launches publish different partial tiles and a stale read cannot return the right bits, while a second stream streams 256 MiB
+ * per launch through the chip for the whole test; each result is compared bitwise on the device with the unsplit kernel's result on
+ * the matching operands; *mismatches_out = differing 32-bit words over all launches (0 = the cross-workgroup hand-off held every time). */
 int aur_dbg_gemm_rows_ksplit_stress(aur_engine* e, int32_t M, int32_t iters, int64_t* mismatches_out);
 /* The kernels' cross-lane helpers (lane_xor<J>, wave_sum, wave_max: DPP and gfx950 lane swaps, csrc/common.h) against the wavefront
  * shuffles they replace, on `blocks` workgroups of pseudo-random words; *mismatches_out = results that differ bitwise (0 expected).

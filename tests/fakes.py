@@ -5,15 +5,18 @@ import numpy as np
 class FakeNativeEngine:
     n_layer = 1
 
-    def __init__(self, max_seqs=4, fail_on_step=None, conditioning_weights=None):
+    def __init__(self, max_seqs=4, fail_on_step=None, conditioning_weights=None, fail_once_on_step=None):
         self.conditioning_weights = conditioning_weights   # xtts-v2.safetensors tensors: enables compute_conditioning below
         self.max_seqs = max_seqs
         self.next_id = 1
         self.waiting, self.running, self.done = [], [], []
         self.speakers = {}
         self.submitted = []
-        self.fail_on_step = fail_on_step
+        self.fail_on_step = fail_on_step              # every step from this one on raises (a lost device)
+        self.fail_once_on_step = fail_once_on_step    # this step raises and fails what was running, as Engine::step / fail_in_flight
         self.steps = 0
+        self.finished_total = 0
+        self.polls = 0
 
     def compute_conditioning(self, pcm, max_ref_length=30, gpt_cond_len=6, gpt_cond_chunk_len=6, sound_norm_refs=False):
         """Stand-in for aur_compute_conditioning (mono float32 PCM at 22 050 Hz per reference): the PyTorch restatement of the
@@ -50,6 +53,12 @@ class FakeNativeEngine:
         self.steps += 1
         if self.fail_on_step is not None and self.steps >= self.fail_on_step:
             raise RuntimeError("injected engine failure")
+        if self.fail_once_on_step is not None and self.steps == self.fail_once_on_step:
+            for s in self.running:   # in flight -> reported through poll with error set; waiting sequences stay queued
+                self.done.append({"seq_id": s["seq_id"], "tokens": np.zeros(0, np.int32), "wav": np.zeros(0, np.float32), "error": -2})
+                self.finished_total += 1
+            self.running = []
+            raise RuntimeError("injected step failure")
         while self.waiting and len(self.running) < self.max_seqs:
             self.running.append(self.waiting.pop(0))
         for s in list(self.running):
@@ -59,10 +68,12 @@ class FakeNativeEngine:
                 n = len(s["ids"])
                 wav = np.full(n * 10, float(s["seq_id"]), dtype=np.float32)
                 self.done.append({"seq_id": s["seq_id"], "tokens": np.arange(n, dtype=np.int32), "wav": wav, "error": 0})
-        return len(self.waiting) + len(self.running), 0
+                self.finished_total += 1
+        return len(self.waiting) + len(self.running), self.finished_total   # (n_live, n_finished_total) as aur_step
 
     def poll(self, cap=64, want_latents=True, copy=True):
-        out, self.done = self.done, []
+        self.polls += 1
+        out, self.done = self.done[:cap], self.done[cap:]
         return out
 
     def release(self, seq_id):   # (poll(copy=False) contract of NativeEngine; the fake's arrays are always owned)

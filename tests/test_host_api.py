@@ -145,6 +145,115 @@ def test_driver_resolves_futures_and_fails_loudly():
     asyncio.run(main())
 
 
+def test_driver_polls_only_when_the_finished_counter_moved():
+    """the driver thread calls aur_poll_finished when aur_step's finished counter moved (or nothing is live), not
+    after every step, and asks for views (copy=False)."""
+    async def main():
+        eng = FakeNativeEngine(max_seqs=2)
+        eng.set_conditioning(1, COND["gpt_cond_latent"], COND["speaker_embedding"])
+        copies = []
+        orig = eng.poll
+        eng.poll = lambda cap=64, want_latents=True, copy=True: (copies.append(copy), orig(cap, want_latents, copy))[1]
+        d = EngineDriver(eng)
+        loop = asyncio.get_running_loop()
+        futs = [d.submit(loop, text_ids=[4, 5 * i, 0], speaker_key=1) for i in range(12)]   # 5 steps each on 2 slots: 30 steps
+        await asyncio.gather(*futs)
+        d.shutdown()
+        assert eng.steps >= 25 and eng.polls <= eng.finished_total + 2 < eng.steps, (eng.steps, eng.polls)
+        assert copies and not any(copies)
+    asyncio.run(main())
+
+
+def test_driver_survives_a_failed_step_and_fails_only_the_sequences_it_hit():
+    """a failed aur_step fails what was in flight (the engine reports those through poll with error set and stays
+    usable); queued sequences and later submissions go on, the TTS object is not dead.  Failures in a row stop it for good."""
+    async def main():
+        eng = FakeNativeEngine(max_seqs=2, fail_once_on_step=2)
+        eng.set_conditioning(1, COND["gpt_cond_latent"], COND["speaker_embedding"])
+        d = EngineDriver(eng)
+        loop = asyncio.get_running_loop()
+        futs = [d.submit(loop, text_ids=[4, 0, 0], speaker_key=1) for _ in range(4)]   # two running at the failing step, two queued
+        res = await asyncio.gather(*futs, return_exceptions=True)
+        assert [isinstance(r, RuntimeError) for r in res] == [True, True, False, False]
+        assert "injected step failure" in str(res[0]) and d.failed_steps == 1
+        again = await d.submit(loop, text_ids=[1, 0, 0], speaker_key=1)                  # the driver is still there
+        assert again["seq_id"] == 5 and again["error"] == 0
+        d.shutdown()
+        dead = FakeNativeEngine(fail_on_step=1)
+        dead.set_conditioning(1, COND["gpt_cond_latent"], COND["speaker_embedding"])
+        d2 = EngineDriver(dead)
+        with pytest.raises(RuntimeError, match="injected engine failure"):
+            await d2.submit(loop, text_ids=[1], speaker_key=1)
+        with pytest.raises(RuntimeError, match="driver stopped"):
+            d2.submit(loop, text_ids=[1], speaker_key=1)
+        assert d2.failed_steps == 3
+        d2.shutdown()
+    asyncio.run(main())
+
+
+def test_result_lease_releases_once_and_defers_engine_destruction():
+    """poll(copy=False): the arrays are views of the engine's pinned block; the lease gives the block back exactly once (explicit
+    release or last array dropped), and aur_engine_destroy waits for the last outstanding view."""
+    import ctypes as C
+    import gc
+
+    from auralis_amd import _lib as L
+    calls = []
+    wav = (C.c_float * 8)(*range(8))
+    toks = (C.c_int32 * 3)(7, 8, 9)
+
+    class Lib:
+        def aur_poll_finished(self, h, res, cap, n):
+            for i in range(2):
+                res[i].seq_id, res[i].n_tokens, res[i].n_samples, res[i].error = 10 + i, 3, 8, 0
+                res[i].tokens = C.cast(toks, C.POINTER(C.c_int32))
+                res[i].wav = C.cast(wav, C.POINTER(C.c_float))
+            n._obj.value = 2
+            return 0
+
+        def aur_release(self, h, sid):
+            calls.append(("release", sid))
+            return 0
+
+        def aur_engine_destroy(self, h):
+            calls.append(("destroy",))
+            return 0
+
+        def aur_last_error(self):
+            return b""
+    e = object.__new__(L.NativeEngine)
+    e.lib, e.h = Lib(), 1234
+    import threading
+    e._lease_lock, e._leases, e._leased_bytes, e._closing = threading.Lock(), {}, 0, False
+    a, b = e.poll(copy=False)
+    assert not a["wav"].flags["OWNDATA"] and a["wav"].tolist() == list(range(8)) and a["tokens"].tolist() == [7, 8, 9]
+    assert calls == [] and e._leased_bytes == 64
+    e.release(10)
+    e.release(10)                                   # idempotent
+    assert calls == [("release", 10)]
+    view = b["wav"][2:5]
+    del a, b
+    gc.collect()
+    assert calls == [("release", 10)]               # a slice still refers to sequence 11's block
+    e.close()
+    assert ("destroy",) not in calls and e.h        # destruction waits for the view
+    del view
+    gc.collect()
+    assert calls == [("release", 10), ("release", 11), ("destroy",)] and e.h is None and e._leased_bytes == 0
+    # over the lease budget results are copied and released at once
+    e2 = object.__new__(L.NativeEngine)
+    e2.lib, e2.h = Lib(), 99
+    e2._lease_lock, e2._leases, e2._leased_bytes, e2._closing = threading.Lock(), {}, 0, False
+    e2.LEASE_BUDGET_BYTES = 40
+    calls.clear()
+    x, y = e2.poll(copy=False)
+    assert "lease" in x and "lease" not in y and y["wav"].flags["OWNDATA"] and calls == [("release", 11)]
+    del x, y
+    gc.collect()
+    e2.close()
+    assert calls == [("release", 11), ("release", 10), ("destroy",)]
+
+
 def _tts(fake=None):
     fake = fake or FakeNativeEngine(max_seqs=3)
     eng = XTTSv2Engine(fake, XTTSTokenizer(None, synthetic=True), max_concurrency=3)
@@ -407,7 +516,7 @@ def test_submit_is_repeated_once_after_reregistering_an_evicted_voice():
         def step(self):
             return 0, 0
 
-        def poll(self):
+        def poll(self, cap=64, copy=True):
             return []
 
     eng = Eng()

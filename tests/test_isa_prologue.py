@@ -91,3 +91,40 @@ def test_no_gpt_kernel_spills_or_uses_flat_loads(asm):
         priv = re.findall(r"\.amdhsa_private_segment_fixed_size (\d+)", body)
         assert priv and int(priv[0]) == 0, (name, "scratch bytes per lane", priv)
         assert "flat_load" not in body and "scratch_" not in body, name
+
+
+@pytest.fixture(scope="module")
+def voc_asm():
+    return isa_skeleton.compile_to_asm(os.path.join(ROOT, "auralis_amd", "csrc", "vocoder_kernels.hip"))
+
+
+def test_no_vocoder_kernel_spills(voc_asm):
+    """twenty instantiations of the register-staged fp16 conv kernel (every 64-channel tile, conv_pre among them: on the
+    hot path) carried 32 spilled VGPRs and 76 B of scratch per lane, and no test looked at the vocoder unit.  No kernel of the
+    unit may use scratch -- the engine launches any of them depending on shapes and A/B switches -- and the hot kernels keep the
+    occupancy their launch bounds promise."""
+    import re
+    ks = isa_skeleton.kernels(voc_asm, "")
+    assert len(ks) >= 60, len(ks)
+    bad = []
+    for name, body in ks:
+        priv = re.findall(r"\.amdhsa_private_segment_fixed_size (\d+)", body)
+        spill = re.findall(r"\.vgpr_spill_count:\s*(\d+)", body)
+        if not priv or int(priv[0]) != 0 or "scratch_" in body or (spill and int(spill[0]) != 0):
+            bad.append((name, priv[:1], spill[:1]))
+    assert not bad, bad
+
+
+def test_wide_conv_tile_is_compiled_for_one_workgroup_per_cu(voc_asm):
+    """The 128-channel tile of the LDS-DMA conv kernel (round 6): a 128 x 64 accumulator tile per wave = 128 registers, so eight waves
+    run one workgroup per CU (<= 256 registers), while the 64-channel tile keeps two (<= 128)."""
+    import re
+    wide = isa_skeleton.kernels(voc_asm, "conv1d_dma_f16_kernelILi3ELi1ELi128E")
+    narrow = isa_skeleton.kernels(voc_asm, "conv1d_dma_f16_kernelILi3ELi1ELi64ELi3ELi8E")
+    assert len(wide) == 1 and len(narrow) == 1, (len(wide), len(narrow))
+    for ks, cap in ((wide, 256), (narrow, 128)):
+        body = ks[0][1]
+        n = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        acc = re.search(r"\.amdhsa_accum_offset (\d+)", body)
+        assert n <= cap, (ks[0][0], n)
+        assert len(re.findall(r"v_mfma_f32_32x32x16_f16", body)) >= 3 * 4, ks[0][0]

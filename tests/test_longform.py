@@ -156,7 +156,7 @@ def _sharded_failure_worker(rank, world, port, out_dir, mode):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     paras = [EN, FR, DE] * 6
     reqs = build_requests(paras, [VOICE], seed=1)
-    fake = FakeNativeEngine(max_seqs=4, fail_on_step=(12 if (mode == "remote_error" and rank == 1) else None))
+    fake = FakeNativeEngine(max_seqs=4, fail_on_step=(4 if (mode == "remote_error" and rank == 1) else None))
     tts = TTS(scheduler_max_concurrency=4).with_engine(XTTSv2Engine(fake, XTTSTokenizer(None, synthetic=True)))
     got, err = 0, ""
     try:
