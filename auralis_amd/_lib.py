@@ -27,7 +27,7 @@ class aur_config(C.Structure):
     _fields_ = [("n_layer", C.c_int32), ("max_seqs", C.c_int32), ("max_prefill_rows", C.c_int32),
                 ("max_speakers", C.c_int32), ("vocoder_min_batch", C.c_int32), ("profile", C.c_int32),
                 ("vocoder_fp16", C.c_int32), ("second_pass", C.c_int32), ("return_latents", C.c_int32), ("kv_fp16", C.c_int32),
-                ("gemm_f32_exact", C.c_int32), ("gelu_erf", C.c_int32), ("admit_min_batch", C.c_int32)]
+                ("gemm_f32_exact", C.c_int32), ("gelu_erf", C.c_int32), ("admit_min_batch", C.c_int32), ("urgent_rows", C.c_int32)]
 
 
 class aur_tensor_desc(C.Structure):
@@ -43,7 +43,7 @@ class aur_seq_desc(C.Structure):
     _fields_ = [("text_ids", C.POINTER(C.c_int32)), ("n_text", C.c_int32), ("speaker_key", C.c_uint64),
                 ("temperature", C.c_float), ("top_p", C.c_float), ("top_k", C.c_int32),
                 ("repetition_penalty", C.c_float), ("max_tokens", C.c_int32), ("seed", C.c_uint32),
-                ("ignore_stop", C.c_int32)]
+                ("ignore_stop", C.c_int32), ("priority", C.c_int32)]
 
 
 class aur_result(C.Structure):
@@ -209,10 +209,10 @@ class NativeEngine:
     def __init__(self, n_layer: int = 30, max_seqs: int = 64, device: int = 0, max_prefill_rows: int = 0,
                  max_speakers: int = 0, vocoder_min_batch: int = 0, profile: bool = False, vocoder_fp16: bool = False,
                  second_pass: bool = False, return_latents: bool = True, kv_fp16: bool = False,
-                 gemm_f32_exact: bool = False, gelu_erf: bool = False, admit_min_batch: int = 0):
+                 gemm_f32_exact: bool = False, gelu_erf: bool = False, admit_min_batch: int = 0, urgent_rows: int = 0):
         self.lib = load_library()
         cfg = aur_config(n_layer, max_seqs, max_prefill_rows, max_speakers, vocoder_min_batch, int(profile),
-                         int(vocoder_fp16), int(second_pass), int(return_latents), int(kv_fp16), int(gemm_f32_exact), int(gelu_erf), int(admit_min_batch))
+                         int(vocoder_fp16), int(second_pass), int(return_latents), int(kv_fp16), int(gemm_f32_exact), int(gelu_erf), int(admit_min_batch), int(urgent_rows))
         h = C.c_void_p()
         self._check(self.lib.aur_engine_create(C.byref(cfg), device, C.byref(h)))
         self.h = h
@@ -331,10 +331,10 @@ class NativeEngine:
     # -- sequences -------------------------------------------------------------------------------------
     def submit(self, text_ids: Sequence[int], speaker_key: int, temperature: float = 0.75, top_p: float = 0.85,
                top_k: int = 50, repetition_penalty: float = 5.0, max_tokens: int = 605, seed: int = 0,
-               ignore_stop: bool = False) -> int:
+               ignore_stop: bool = False, priority: int = 0) -> int:
         ids = _i32(list(text_ids))
         d = aur_seq_desc(_ip(ids), len(ids), speaker_key, temperature, top_p, top_k, repetition_penalty,
-                         max_tokens, seed & 0xFFFFFFFF, int(ignore_stop))
+                         max_tokens, seed & 0xFFFFFFFF, int(ignore_stop), int(priority))
         sid = C.c_uint64()
         self._check(self.lib.aur_submit(self.h, C.byref(d), C.byref(sid)))
         return sid.value

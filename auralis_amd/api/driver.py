@@ -31,11 +31,13 @@ class EngineDriver:
         concurrent generate_speech calls reach it a fraction of a millisecond apart, the event loop tokenises them one after
         the other, and a prefill pass costs the same ~4.5 ms of launches for one prompt as for 64 -- but once no submission has
         arrived for burst_gap_s (at most burst_max_s after the first).  A lone request pays burst_gap_s once; a running engine
-        never waits (its admission groups arrivals itself, aur_config.admit_min_batch)."""
+        never waits (its admission groups arrivals itself, aur_config.admit_min_batch), and a latency-critical submission
+        (priority > 0) ends the wait at once."""
         self.engine = engine
         self.max_consecutive_failures = max(1, int(max_consecutive_failures))
         self.burst_gap_s, self.burst_max_s = float(burst_gap_s), float(burst_max_s)
         self._last_submit = 0.0
+        self._urgent = False          # a latency-critical submission (priority > 0) is in the burst: the engine starts at once
         self._pending: Dict[int, Tuple[asyncio.AbstractEventLoop, asyncio.Future]] = {}
         self._lock = threading.Lock()
         self._wake = threading.Event()
@@ -63,6 +65,8 @@ class EngineDriver:
                 sid = self.engine.submit(**seq)
             self._pending[sid] = (loop, fut)
             self._last_submit = time.perf_counter()
+            if seq.get("priority", 0) > 0:
+                self._urgent = True
         self._wake.set()
         return fut
 
@@ -117,9 +121,10 @@ class EngineDriver:
             t_end = time.perf_counter() + self.burst_max_s
             while not self._stop:     # the burst that woke an idle engine is still arriving
                 now = time.perf_counter()
-                if now >= t_end or now - self._last_submit >= self.burst_gap_s:
+                if self._urgent or now >= t_end or now - self._last_submit >= self.burst_gap_s:
                     break
                 time.sleep(self.burst_gap_s * 0.25)
+            self._urgent = False
             last_fin = None
             in_a_row = 0
             while not self._stop:

@@ -47,6 +47,9 @@ class TTSRequest:
     length_penalty: float = 1.0
     do_sample: bool = True
     seed: Optional[int] = None
+    # new surface, like `seed`: > 0 marks the request latency-critical -- its FIRST chunk is what a listener waits for -- and is
+    # handed to the engine as aur_seq_desc.priority (the reference has no such knob: tests/integration/stream_ttfb.py only measures)
+    priority: int = 0
 
     def __post_init__(self):
         if self.language == "auto" and isinstance(self.text, str) and len(self.text) > 0:

@@ -91,7 +91,7 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
         native = NativeEngine(n_layer=ck.n_layer, max_seqs=max(1, max_concurrency), device=device,
                               vocoder_fp16=(vocoder == "fp16"), return_latents=False, gelu_erf=ck.gelu_erf,
                               admit_min_batch=int(kwargs.get("admit_min_batch", 0)), vocoder_min_batch=int(kwargs.get("vocoder_min_batch", 0)),
-                              max_speakers=int(kwargs.get("max_speakers", 0)))
+                              max_speakers=int(kwargs.get("max_speakers", 0)), urgent_rows=int(kwargs.get("urgent_rows", 0)))
         native.load_weights(pack_all(gpt_sd, xtts_sd))
         if any(k.startswith("conditioning_encoder.") for k in xtts_sd):
             from ..weights import pack_conditioning
@@ -232,7 +232,9 @@ class XTTSv2Engine(BaseAsyncTTSEngine):
                                      top_p=request.top_p, top_k=request.top_k,
                                      repetition_penalty=request.repetition_penalty,
                                      max_tokens=self.gpt_max_audio_tokens, seed=seed,
-                                     **({"ignore_stop": True} if self.fixed_length else {}))
+                                     **({"ignore_stop": True} if self.fixed_length else {}),
+                                     # a latency-critical request: its first chunk is the one somebody waits for
+                                     **({"priority": int(request.priority)} if idx == 0 and getattr(request, "priority", 0) > 0 else {}))
             rid = f"{request.request_id}_{idx}"
             handles.append(ChunkHandle(fut, rid, len(text_ids)))
             ids.append(rid)

@@ -52,14 +52,33 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     os.makedirs(OUT_DIR, exist_ok=True)
 
+    def unit_hash(src: str) -> str:
+        """what one object file is keyed on: its translation unit, every header (any of them may be included) and the flags"""
+        import hashlib
+        h = hashlib.sha256()
+        h.update(" ".join(FLAGS).encode())
+        for rel in [src] + sorted(HEADERS):
+            with open(os.path.normpath(os.path.join(CSRC, rel)), "rb") as f:
+                h.update(rel.encode())
+                h.update(f.read())
+        return h.hexdigest()
+
+    compiled = []
+
     def cc(src: str) -> str:
         obj = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
+        tag, want_u = obj + ".srchash", unit_hash(src)
+        if not force and os.path.isfile(obj) and os.path.isfile(tag) and open(tag).read().strip() == want_u:
+            return obj   # this unit and the headers are unchanged (the vocoder unit alone takes four minutes)
         cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+        with open(tag, "w") as f:
+            f.write(want_u + "\n")
+        compiled.append(src)
         return obj
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
@@ -70,7 +89,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
     with open(HASH_FILE, "w") as f:
         f.write(want + "\n")
-    print(f"[auralis_amd.build] compiled {len(SOURCES)} translation units with hipcc for gfx950 -> "
+    print(f"[auralis_amd.build] compiled {len(compiled)} of {len(SOURCES)} translation units with hipcc for gfx950 ({', '.join(compiled) or 'objects up to date'}) -> "
           f"{os.path.relpath(LIB, os.path.dirname(HERE))} (source hash {want[:16]})", file=sys.stderr, flush=True)
     return LIB
 

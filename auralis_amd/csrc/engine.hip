@@ -582,7 +582,13 @@ public:
         s->params.text_ids = nullptr;
         s->n_prompt = n_prompt;
         const uint64_t id = s->id;
-        waiting_.push_back(s.get());
+        if (d.priority > 0) {   // aur_seq_desc.priority: behind the urgent sequences already waiting, in front of everything else
+            auto it = waiting_.begin();
+            while (it != waiting_.end() && (*it)->params.priority > 0) ++it;
+            waiting_.insert(it, s.get());
+        } else {
+            waiting_.push_back(s.get());
+        }
         seqs_[id] = std::move(s);
         return id;
     }
@@ -704,11 +710,31 @@ public:
             const int group = std::min(cfg_.admit_min_batch > 0 ? cfg_.admit_min_batch : std::max(1, cfg_.max_seqs / 8), cfg_.max_seqs);
             // ... but never for long: with few finishes in sight the free slots would idle while requests wait (kAdmitHoldSteps decode
             // steps ~ 60 ms at 30 layers, then whatever fits is admitted)
-            bool hold = free_slots < cfg_.max_seqs && free_slots < std::min(group, (int)waiting_.size());
-            if (hold && free_slots > 0 && ++admit_hold_steps_ > kAdmitHoldSteps) hold = false;
+            // aur_seq_desc.priority (latency-critical sequences: the head chunk of a stream somebody is waiting to hear).  While one of
+            // them waits or runs, (1) it is admitted at once, whatever the group logic says; (2) the others are admitted only up to
+            // `urgent_rows` running sequences -- a decode step's time grows with its rows (attention above all: 1.6 ms at 64 rows, ~3 ms
+            // at 192 and 30 layers), and every step of the urgent sequence pays it -- and only in groups (a prefill pass in front of
+            // every step would stall the urgent sequence's steps for the pass's ~4.5 ms of launches each time).
+            int urgent_waiting = 0, n_running = cfg_.max_seqs - free_slots;
+            bool urgent_running = false;
+            for (Seq* q : waiting_) urgent_waiting += q->params.priority > 0 ? 1 : 0;
+            for (int i = 0; i < cfg_.max_seqs; ++i)
+                if (slot_owner_[i] && slot_owner_[i]->params.priority > 0 && slot_owner_[i]->state == SeqState::RUNNING) urgent_running = true;
+            const bool urgent = urgent_waiting > 0 || urgent_running;
+            // (default a quarter of the slots; measured on the long-form stream at 192 slots, profiles/r06_c5s_urgent_sweep.log: first chunk
+            // 0.55 s / 32.2 M samples/s without a cap, 0.43 / 32.3 at 128 rows, 0.42 / 31.3 at 96, 0.33 / 31.5 at 64, 0.30 / 31.5 at 48)
+            const int urgent_cap = std::min(cfg_.max_seqs, cfg_.urgent_rows > 0 ? cfg_.urgent_rows : std::max(1, cfg_.max_seqs / 4));
+            const int n_plain = (int)waiting_.size() - urgent_waiting;
+            const int free_eff = urgent ? std::max(0, std::min(free_slots, urgent_cap - n_running)) : free_slots;
+            bool hold = free_slots < cfg_.max_seqs && free_eff < std::min(group, n_plain);
+            // (an urgent sequence running beside a trickle of arrivals: wait for a group or kUrgentHoldSteps, not a pass per step)
+            if (!hold && urgent_running && n_plain > 0 && n_plain < group && free_eff > 0) hold = true;
+            if (hold && free_eff > 0 && ++admit_hold_steps_ > (urgent_running ? kUrgentHoldSteps : kAdmitHoldSteps)) hold = false;
             if (!hold) admit_hold_steps_ = 0;
-            while (!hold && !waiting_.empty()) {
+            while (!waiting_.empty()) {
                 Seq* s = waiting_.front();
+                const bool s_urgent = s->params.priority > 0;
+                if (!s_urgent && (hold || (urgent && n_running + (int)admitted.size() >= urgent_cap))) break;
                 const SpeakerInfo& si = spk_info_[s->spk_row];
                 s->shared_prefix = si.ready && share_prefix_now_;
                 const int skip = s->shared_prefix ? 2 : 0;   // table entries 0,1 = the speaker's shared prefix blocks
@@ -782,8 +808,10 @@ public:
         // nothing waits, so a sequence queued behind an active batch is launched as soon as that batch is done once its hold is up)
         if (voc_queue_.empty()) voc_hold_steps_ = 0;
         else ++voc_hold_steps_;
+        bool urgent_voc = false;   // an urgent sequence does not wait for company: its batch is whatever has finished with it
+        for (Seq* q : voc_queue_) urgent_voc |= q->params.priority > 0;
         if (!voc_active_ && !voc_queue_.empty() &&
-            ((int)voc_queue_.size() >= minb || (running == 0 && n_wait == 0) || voc_hold_steps_ > kVocHoldSteps)) {
+            ((int)voc_queue_.size() >= minb || urgent_voc || (running == 0 && n_wait == 0) || voc_hold_steps_ > kVocHoldSteps)) {
             voc_launch();
             voc_hold_steps_ = 0;
         }
@@ -2247,6 +2275,7 @@ private:
     std::unordered_map<uint64_t, std::unique_ptr<Seq>> seqs_;
     std::deque<Seq*> waiting_, done_;
     static constexpr int kAdmitHoldSteps = 32;   // longest hold of an admissible request by aur_config.admit_min_batch, in aur_steps
+    static constexpr int kUrgentHoldSteps = 8;   // ... while an urgent sequence runs (arrivals are grouped, not kept waiting long)
     int admit_hold_steps_ = 0;
     static constexpr int kVocHoldSteps = 16;     // longest wait of a finished sequence for a fuller vocoder batch, in aur_steps (~30 ms)
     int voc_hold_steps_ = 0;

@@ -811,12 +811,18 @@ static int conv_dma_waves() {
     return w;
 }
 // Output-channel tile of the all-halves convs whose Mtot is a multiple of 128 (the ResBlock convs of the 256- and 128-channel
-// stages, conv_pre): 128 (default, round 6) or 64 (AUR_CONV_MT=64: round 5's tile, A/B).  Bit mask AUR_CONV_MT128_KS selects the
-// tap counts that take the wide tile (1 = k 3, 2 = k 7, 4 = k 11; default all).
+// stages, conv_pre): 64 (default) or 128 (AUR_CONV_MT=128, A/B).  Bit mask AUR_CONV_MT128_KS selects the tap counts that take the
+// wide tile (1 = k 3, 2 = k 7, 4 = k 11; default all).  Measured in round 6 on one box, conv time per 64 utterances
+// (profiles/r06_conv_mt_ab.log): 64-channel tile 64.2 / 64.0 ms; 128-channel tile for every k 66.0, for k = 3 only 65.2, k = 7 only
+// 64.9, k = 11 only 65.2 (256-channel class 0.41 -> 0.38 of the matrix peak, 128-channel class 0.345 -> 0.324).  The wide tile halves
+// the window bytes staged per MFMA and cuts the LDS fragment reads per MFMA from 1 to 0.75, and still loses: at 128 accumulator
+// registers a CU holds ONE workgroup of eight waves, and what the second workgroup of the 64-channel form hides -- the per-chunk
+// barrier and the wait for the chunk's copies -- is exposed.  The operand fill is therefore not what bounds these kernels; the
+// vocoder is closed at this tiling.
 static int conv_dma_mt() {
     static const int v = [] {
         const char* e = getenv("AUR_CONV_MT");
-        return e ? atoi(e) : 128;
+        return e ? atoi(e) : 64;
     }();
     return v;
 }
@@ -1161,6 +1167,11 @@ __device__ __forceinline__ void lin_src(float r, int j, int L, int& i0, int& i1,
     lam = src - (float)i0;
 }
 
+// (1 - lam) a + lam b with the contraction spelled out: which of the two products hipcc fuses into an fma depends on the code around
+// the expression, and the fp32 and fp16 forms of the kernel must round alike (the DMA-staged and the register-staged vocoder are
+// compared bit for bit)
+__device__ __forceinline__ float lerp_f(float a, float b, float lam) { return fmaf(lam, b, (1.0f - lam) * a); }
+
 __global__ __launch_bounds__(256) void interp2_kernel(const float* __restrict__ lat, long lat_bstride,
                                                       const int* __restrict__ lat_row,
                                                       const int* __restrict__ n_lat,
@@ -1184,9 +1195,9 @@ __global__ __launch_bounds__(256) void interp2_kernel(const float* __restrict__ 
         int k0, k1;
         float lam1;
         lin_src(r1, idx[u], L0, k0, k1, lam1);
-        y[u] = (1.0f - lam1) * x[(long)k0 * C] + lam1 * x[(long)k1 * C];
+        y[u] = lerp_f(x[(long)k0 * C], x[(long)k1 * C], lam1);
     }
-    z[(long)b * z_bstride + (long)c * z_stride + j] = (1.0f - lam2) * y[0] + lam2 * y[1];
+    z[(long)b * z_bstride + (long)c * z_stride + j] = lerp_f(y[0], y[1], lam2);
 }
 
 // The same values as interleaved halves z16[b][C/16][z_stride][16] = fp16(z) -- what conv_pre's staging rounds the fp32 z to anyway
@@ -1217,13 +1228,13 @@ __global__ __launch_bounds__(256) void interp2_h_kernel(const float* __restrict_
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(x + (long)k1 * C), b1 = *reinterpret_cast<const f32x4*>(x + (long)k1 * C + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            y[u][e] = (1.0f - lam1) * a0[e] + lam1 * b0[e];
-            y[u][e + 4] = (1.0f - lam1) * a1[e] + lam1 * b1[e];
+            y[u][e] = lerp_f(a0[e], b0[e], lam1);
+            y[u][e + 4] = lerp_f(a1[e], b1[e], lam1);
         }
     }
     h16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (_Float16)((1.0f - lam2) * y[0][e] + lam2 * y[1][e]);
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)lerp_f(y[0][e], y[1][e], lam2);
     *reinterpret_cast<h16x8*>(z + (long)b * z_bstride + ((long)(c8 >> 4) * z_stride + j) * 16 + (c8 & 15)) = o;
 }
 

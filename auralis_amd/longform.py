@@ -25,10 +25,13 @@ def split_paragraphs(text: str) -> List[str]:
 
 
 def build_requests(paragraphs: Sequence[str], speaker_files, seed: Optional[int] = None, **gen) -> List[TTSRequest]:
+    """One streaming request per paragraph.  The FIRST one is marked latency-critical (TTSRequest.priority): the stream is consumed
+    in order, so its first chunk is the time to first audio of the whole book; everything behind it only has to keep ahead of the
+    playback."""
     reqs = []
     for i, p in enumerate(paragraphs):
         reqs.append(TTSRequest(text=p, speaker_files=speaker_files, language="auto", stream=True,
-                               seed=None if seed is None else seed + 1000 * i, **gen))
+                               seed=None if seed is None else seed + 1000 * i, **({"priority": 1} if i == 0 else {}), **gen))
     return reqs
 
 

@@ -126,7 +126,7 @@ def kernel_rooflines(args, st, dims, samples_in_pass):
     Decode GEMMs / attention: replay batches (one event pair per n_layer back-to-back launches of one kind, the step's real
     operands, outputs to scratch).  Vocoder convs: a pair per launch (0.2-2 ms each).  Prefill: the whole phase."""
     tj = _traffic()
-    pmc_key = next((k for k in ("r05_decode", "r04_decode", "r03_decode") if k in tj), "r03_decode")
+    pmc_key = next((k for k in ("r06_decode", "r05_decode", "r04_decode", "r03_decode") if k in tj), "r03_decode")
     pmc = tj.get(pmc_key, {})
     gemm_peak = FP32_MFMA_PEAK_TFLOPS if args.gemm == "f32" else BF16_MFMA_PEAK_TFLOPS / 6.0
 
@@ -187,6 +187,12 @@ def kernel_rooflines(args, st, dims, samples_in_pass):
             fam["traffic_from_committed_profile"] = f"profiles/hbm_traffic.json[{pmc_key}]"
     attn = roof("paged_attention_kernel (decode: one query row per sequence against its paged K/V)", st["attn_ms"], st["attn_launches"],
                 st["attn_bytes"], 0.0, 1.0, "attention")
+    if attn and attn.get("traffic_ratio") is not None:
+        # the algorithmic bytes count every sequence's whole context; the shared speaker prefix (32 tokens, two K/V blocks per voice) is
+        # served from cache for all but the first reader, so fewer bytes MOVE: the fraction of the HBM peak on the PMC traffic
+        # (FETCH_SIZE x 2 + WRITE_SIZE of the committed rocprofv3 --pmc passes, run at this bench's own --tokens)
+        attn["frac_on_traffic"] = attn["frac"] * attn["traffic_ratio"]
+        attn["pmc_tokens"] = pmc.get("tokens")
     # vocoder
     voc = None
     if st["conv_ms"] > 0:
@@ -201,7 +207,7 @@ def kernel_rooflines(args, st, dims, samples_in_pass):
             if n and m > 0:
                 cls[names[k]] = {"launches": n, "ms": m, "frac_mfma": st["conv_class_flops"][k] / (m * 1e-3) / 1e12 / mf_peak,
                                  "frac_hbm_as_stored": st["conv_class_bytes"][k] / (m * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-        conv_pmc = (tj.get("r05_conv") or tj.get("r04_conv") or tj.get("r03_conv") or {}).get(f"conv_{args.vocoder}")
+        conv_pmc = (tj.get("r06_conv") or tj.get("r05_conv") or tj.get("r04_conv") or tj.get("r03_conv") or {}).get(f"conv_{args.vocoder}")
         voc = {"kernel": "conv1d_dma_f16_kernel + resblock_round_f16_kernel + conv1d_mfma_f16_kernel (HiFi-GAN convs)"
                          if args.vocoder == "fp16" else "conv1d_mfma_kernel",
                "ms_per_batch": ms / max(1, st["vocoder_batches"]), "launches": st["conv_launches"],
@@ -422,7 +428,8 @@ class Bench:
             from auralis_amd._lib import NativeEngine
             own = eng = NativeEngine(n_layer=a.layers, max_seqs=slots, device=self.local_rank, profile=False, vocoder_fp16=(a.vocoder == "fp16"),
                                      return_latents=False, kv_fp16=(a.kv == "fp16"), gemm_f32_exact=(a.gemm == "f32"),
-                                     admit_min_batch=a.admit_min_batch, vocoder_min_batch=a.vocoder_min_batch, gelu_erf=self.gelu_erf)
+                                     admit_min_batch=a.admit_min_batch, vocoder_min_batch=a.vocoder_min_batch, gelu_erf=self.gelu_erf,
+                                     urgent_rows=a.urgent_rows)
             eng.load_weights(self.packed)
             eng.set_conditioning(self.SPK, self.cond.numpy(), self.spk.numpy())
         EN = ("It was a bright cold day in April, and the clocks were striking thirteen. Nobody in the street seemed to notice, "
@@ -543,8 +550,9 @@ def compact(line, full_path):
     else:
         out["roofline"] = None
     if attn:
-        out["roofline_attention"] = {"frac": _r(attn["frac"]), "achieved": _r(attn["achieved"]), "avg_launch_us": _r(attn["avg_launch_us"]),
-                                     "traffic_ratio": _r(attn.get("traffic_ratio"))}
+        out["roofline_attention"] = {"frac": _r(attn["frac"]), "frac_on_traffic": _r(attn.get("frac_on_traffic")), "achieved": _r(attn["achieved"]),
+                                     "avg_launch_us": _r(attn["avg_launch_us"]), "traffic_ratio": _r(attn.get("traffic_ratio")),
+                                     "traffic_measured_at_tokens": attn.get("pmc_tokens")}
     if voc:
         out["roofline_vocoder"] = {"frac_mfma": _r(voc["frac_mfma"]), "frac_hbm_as_stored": _r(voc["frac_hbm_as_stored"]),
                                    "frac_hbm_8d_fp16": _r(voc["frac_hbm_8d_fp16"]), "frac_hbm_8d_fp32": _r(voc["frac_hbm_8d_fp32"]),
@@ -556,6 +564,16 @@ def compact(line, full_path):
     ds = line.get("decode_step")
     if ds:
         out["decode_step"] = {"ms": _r(ds["ms"]), "frac_as_stored": _r(ds["frac_as_stored"]), "frac_8d_fp16": _r(ds["frac_8d_fp16"])}
+    if ds and fam and attn and out.get("roofline"):
+        # IN SITU: what the four GEMMs of a layer cost inside the timed region's own decode steps (HIP events around every step, profile
+        # mode off) = (step - tail) / layers - attention, tail = embed + final norms + mel head + sampler (the head's replay time + 25 us).
+        # The replay batches above re-issue one kind back to back; in a step the kinds alternate (proj runs ~15 % slower there).
+        L = line["config"]["gpt_layers"]
+        tail_us = fam["per_kind_us"]["head"] + 25.0
+        g4 = (ds["ms"] * 1e3 - tail_us) / L - attn["avg_launch_us"]
+        by4 = 4.0 * fam["algorithmic_bytes_per_launch"]   # (the family average is over the four block GEMMs)
+        out["roofline"]["four_gemms_per_layer_us_in_situ"] = _r(g4)
+        out["roofline"]["frac_in_situ"] = _r(by4 / (g4 * 1e-6) / 1e9 / HBM_PEAK_GBPS)
     out["breakdown_ms_per_step"] = {a: _r(b) for a, b in line["breakdown_ms_per_step"].items()}
     c2 = line.get("c2")
     if c2 and "error" not in c2:
@@ -631,6 +649,9 @@ def main():
                          "0 = --batch.  A value other than --batch builds a second engine for that workload (same weights, its own K/V "
                          "pool).  Default 192: the decode GEMMs stream the weights once per step whatever the rows, so a long-form job is "
                          "cheaper per token on more rows (profiles/r05_c5s_slots_sweep.jsonl: 64 slots 26.3 M samples/s, 128: 28.4, 192: 30.3)")
+    ap.add_argument("--urgent-rows", type=int, default=0,
+                    help="aur_config.urgent_rows (c5s: running sequences the engine fills up to while the stream's head chunk -- TTSRequest.priority, "
+                         "set by longform.build_requests -- waits or runs; 0 = the engine's default, slots / 4)")
     ap.add_argument("--admit-min-batch", type=int, default=0,
                     help="aur_config.admit_min_batch (0 = the engine's default, slots / 8; 1 = admit one by one); matters for c5s only")
     ap.add_argument("--vocoder-min-batch", type=int, default=0,

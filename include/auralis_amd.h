@@ -70,6 +70,8 @@ typedef struct aur_config {
                                  a free slot and no longer queue than free slots is admitted at once, as the reference's vLLM scheduler
                                  does (two_phase_scheduler.py:168-236 hands every request straight to it).  A hold ends after 32 steps (~60 ms) whatever is
                                  free by then.  0 = default max_seqs / 8 (8 at 64 slots); 1 = never hold */
+    int32_t urgent_rows;      /* running sequences the engine fills up to while a latency-critical sequence (aur_seq_desc.priority > 0)
+                                 waits or runs.  0 = default max_seqs / 4; max_seqs = no cap */
 } aur_config;
 
 /* One named fp32 tensor.  Names are the packed names produced by auralis_amd/weights.py from the
@@ -95,6 +97,12 @@ typedef struct aur_seq_desc {
     int32_t max_tokens;       /* gpt_max_audio_tokens (605) */
     uint32_t seed;            /* per-sequence noise stream (new surface; reference has none) */
     int32_t ignore_stop;      /* 1 = fixed-length mode for timing (stop id does not end the sequence) */
+    int32_t priority;         /* 0 = normal; > 0 = latency-critical (the chunk a listener is waiting for: the head of a stream; the
+                                 reference has no counterpart, its streaming latency is whatever vLLM's FIFO gives,
+                                 tests/integration/stream_ttfb.py:24-37).  It is admitted in front of the normal queue and at once,
+                                 vocoded as soon as its tokens are done, and while it waits or runs the engine admits normal
+                                 sequences only up to aur_config.urgent_rows running ones (a decode step's time grows with its
+                                 rows).  Results do not depend on it */
 } aur_seq_desc;
 
 /* Finished sequence.  Pointers stay valid until aur_release(seq_id).  Replaces the RequestOutput consumed at

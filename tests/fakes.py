@@ -40,13 +40,13 @@ class FakeNativeEngine:
         self.speakers[key] = (np.array(g), np.array(s))
 
     def submit(self, text_ids, speaker_key, temperature=0.75, top_p=0.85, top_k=50, repetition_penalty=5.0,
-               max_tokens=605, seed=0, ignore_stop=False):
+               max_tokens=605, seed=0, ignore_stop=False, priority=0):
         assert speaker_key in self.speakers
         sid = self.next_id
         self.next_id += 1
         n_steps = 1 + (sum(text_ids) % 5)          # finish out of submission order
         self.waiting.append({"seq_id": sid, "ids": list(text_ids), "left": n_steps, "seed": seed})
-        self.submitted.append({"seq_id": sid, "text_ids": list(text_ids), "temperature": temperature, "seed": seed})
+        self.submitted.append({"seq_id": sid, "text_ids": list(text_ids), "temperature": temperature, "seed": seed, "priority": priority})
         return sid
 
     def step(self):

@@ -20,6 +20,19 @@ def test_header_and_binding_agree():
     assert _declared_symbols() == sorted(_lib.EXPORTS)
 
 
+def test_struct_fields_of_header_and_binding_agree():
+    """Every struct of include/auralis_amd.h is mirrored field for field, in order, by the ctypes binding (a field added on one side
+    only shifts every later member)."""
+    from auralis_amd import _lib
+    src = open(os.path.join(ROOT, "include", "auralis_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for name in ("aur_config", "aur_tensor_desc", "aur_seq_desc", "aur_result", "aur_stats", "aur_cond_params"):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), src, re.S).group(1)
+        fields = [re.sub(r"\[\d+\]", "", d.strip().split()[-1].lstrip("*")) for d in body.split(";") if d.strip()]
+        bound = [f for f, _ in getattr(_lib, name)._fields_]
+        assert fields == bound, (name, fields, bound)
+
+
 def test_library_exports_every_declared_symbol(lib_path):
     lib = ctypes.CDLL(lib_path)
     for name in _declared_symbols():

@@ -433,6 +433,48 @@ def test_admission_hold_is_bounded(dims):
         assert a["tokens"].tolist() == b["tokens"].tolist() and np.array_equal(a["wav"], b["wav"])
 
 
+def test_admission_urgent_sequence_jumps_the_queue_and_changes_no_output(dims):
+    """aur_seq_desc.priority: 12 sequences submitted at once to 8 slots, the LAST one marked latency-critical.  It is admitted in the
+    first prefill pass (in front of the queue), the engine fills only aur_config.urgent_rows slots while it runs, it is vocoded as soon
+    as its tokens are done -- so it is the first result out -- and no sequence's ids, latents or audio depend on any of that."""
+    from auralis_amd._lib import NativeEngine
+    from auralis_amd.checkpoint import make_synthetic_gpt, make_synthetic_xtts
+    from auralis_amd.weights import pack_all
+    gpt_sd = make_synthetic_gpt(dims.gpt, seed=1234, n_layer=2)
+    packed = pack_all(gpt_sd, make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd))
+    cond, spk = make_synthetic_conditioning(dims)
+
+    def run(priority):
+        e = NativeEngine(n_layer=2, max_seqs=8, urgent_rows=3, vocoder_min_batch=4)
+        try:
+            e.load_weights(packed)
+            e.set_conditioning(SPK_KEY, cond.numpy(), spk.numpy())
+            sids = [e.submit(make_synthetic_text_ids(dims, n_text=9 + k, seed=90 + k), SPK_KEY, temperature=0.8, top_k=50, top_p=0.85, repetition_penalty=5.0,
+                             max_tokens=(10 if k == 11 else 40), seed=500 + k, ignore_stop=True, priority=(priority if k == 11 else 0)) for k in range(12)]
+            order, rows = [], []
+            for _ in range(2000):
+                live, _fin = e.step()
+                st = e.stats()
+                rows.append(st["decode_rows"])
+                order.extend(o for o in e.poll())
+                if live == 0:
+                    break
+            assert len(order) == 12 and all(o["error"] == 0 for o in order)
+            per_step = np.diff([0] + rows)
+            return {o["seq_id"]: o for o in order}, [o["seq_id"] for o in order], sids, per_step
+        finally:
+            e.close()
+
+    plain, order_p, sids_p, rows_p = run(0)
+    urg, order_u, sids_u, rows_u = run(1)
+    assert order_u[0] == sids_u[11] and order_p[0] != sids_p[11]       # first out when urgent; behind the first wave otherwise
+    assert rows_u[:8].max() <= 3 and rows_p[:8].max() == 8              # the engine fills 3 of its 8 slots while the urgent one runs
+    assert rows_u.max() == 8                                           # ... and all of them afterwards
+    for a, b in zip(sids_p, sids_u):
+        assert plain[a]["tokens"].tolist() == urg[b]["tokens"].tolist()
+        assert np.array_equal(plain[a]["wav"], urg[b]["wav"]) and np.array_equal(plain[a]["latents"], urg[b]["latents"])
+
+
 def test_kv_pool_above_the_32_bit_offset_range_is_refused_at_creation():
     """paged_attention_kernel addresses a layer's K/V pool with 32-bit byte offsets: a pool of 4 GiB or more per
     layer -- 495 slots with the fp32 pool, 992 with fp16 -- must be refused when the engine is created, not read past 4 GiB later."""

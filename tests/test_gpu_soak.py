@@ -55,23 +55,26 @@ def test_hundred_facade_requests_leave_no_resources_behind(tmp_path, dims, monke
                                         return_exceptions=True)
             return outs
 
+        def one_iteration(i):   # (its own scope: every output -- a lease on a pinned result block -- is dropped when it returns)
+            n = 0
+            if i % 10 == 9:      # three requests at once (the largest batch shapes come round every ten iterations)
+                for o in asyncio.run_coroutine_threadsafe(three(i), tts._loop).result(timeout=120):
+                    if isinstance(o, BaseException):
+                        failures.append((i, str(o)))
+                    else:
+                        n += len(o.array)
+            elif i % 10 == 4:    # streamed, chunk by chunk
+                for c in tts.generate_speech(req(i, LONG, stream=True)):
+                    n += len(c.array)
+            else:
+                out = tts.generate_speech(req(i, (SHORT, MEDIUM, LONG)[i % 3], temperature=(0.0 if i % 4 == 0 else 0.75)))
+                assert np.isfinite(out.array).all()
+                n += len(out.array)
+            return n
+
         for i in range(100):
             try:
-                if i % 10 == 9:      # three requests at once (the largest batch shapes come round every ten iterations)
-                    outs = asyncio.run_coroutine_threadsafe(three(i), tts._loop).result(timeout=120)
-                    for o in outs:
-                        if isinstance(o, BaseException):
-                            failures.append((i, str(o)))
-                        else:
-                            samples += len(o.array)
-                elif i % 10 == 4:    # streamed, chunk by chunk
-                    for c in tts.generate_speech(req(i, LONG, stream=True)):
-                        samples += len(c.array)
-                else:
-                    out = tts.generate_speech(req(i, (SHORT, MEDIUM, LONG)[i % 3], temperature=(0.0 if i % 4 == 0 else 0.75)))
-                    assert np.isfinite(out.array).all()
-                    samples += len(out.array)
-                    del out
+                samples += one_iteration(i)
             except RuntimeError as e:
                 failures.append((i, str(e)))
             if i in (9, 49, 99):

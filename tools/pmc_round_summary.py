@@ -44,7 +44,8 @@ def decode_summary(d, T):
                     break
         return g
     f, w = load(os.path.join(d, "fetch", "pmc_counter_collection.csv")), load(os.path.join(d, "write", "pmc_counter_collection.csv"))
-    out = {"command": f"PMC_PASSES='fetch write' PMC_KERNELS='paged_attention_kernel|gemm_rows_kernel' PMC_BENCH_ARGS='--tokens {T}' "
+    out = {"tokens": T,
+           "command": f"PMC_PASSES='fetch write' PMC_KERNELS='paged_attention_kernel|gemm_rows_kernel' PMC_BENCH_ARGS='--tokens {T}' "
                       f"tools/pmc.sh <tag>; python tools/pmc_round_summary.py ...",
            "fetch_correction": "x2 (16 B per lane streaming reads, MI355X_MICROARCH.md §HBM); WRITE_SIZE as reported"}
     for key, _, alg in DECODE:
