@@ -38,6 +38,7 @@ class EngineDriver:
         self.burst_gap_s, self.burst_max_s = float(burst_gap_s), float(burst_max_s)
         self._last_submit = 0.0
         self._urgent = False          # a latency-critical submission (priority > 0) is in the burst: the engine starts at once
+        self._burst_loops: set = set()   # event loops that submitted since the engine last went idle
         self._pending: Dict[int, Tuple[asyncio.AbstractEventLoop, asyncio.Future]] = {}
         self._lock = threading.Lock()
         self._wake = threading.Event()
@@ -65,10 +66,21 @@ class EngineDriver:
                 sid = self.engine.submit(**seq)
             self._pending[sid] = (loop, fut)
             self._last_submit = time.perf_counter()
+            self._burst_loops.add(loop)
             if seq.get("priority", 0) > 0:
                 self._urgent = True
         self._wake.set()
         return fut
+
+    @staticmethod
+    def _loop_busy(loop: asyncio.AbstractEventLoop) -> bool:
+        """Callbacks queued on `loop` right now (CPython's BaseEventLoop keeps them in `_ready`; a loop without it counts as idle).
+        Read from the driver thread without a lock: len() of a deque is atomic, and a stale answer only moves the end of the burst wait."""
+        ready = getattr(loop, "_ready", None)
+        try:
+            return ready is not None and len(ready) > 0
+        except TypeError:
+            return False
 
     def _resolve(self, item: dict, step_error: Optional[BaseException] = None):
         with self._lock:
@@ -121,10 +133,15 @@ class EngineDriver:
             t_end = time.perf_counter() + self.burst_max_s
             while not self._stop:     # the burst that woke an idle engine is still arriving
                 now = time.perf_counter()
-                if self._urgent or now >= t_end or now - self._last_submit >= self.burst_gap_s:
+                if self._urgent or now >= t_end:
+                    break
+                # quiet for burst_gap_s AND the submitting loop has nothing queued: a loop thread that stalls in the middle of a burst
+                # (a garbage collection, a slow tokenizer call) still has the other requests' tasks in its ready queue
+                if now - self._last_submit >= self.burst_gap_s and not any(self._loop_busy(lp) for lp in tuple(self._burst_loops)):
                     break
                 time.sleep(self.burst_gap_s * 0.25)
             self._urgent = False
+            self._burst_loops.clear()
             last_fin = None
             in_a_row = 0
             while not self._stop:

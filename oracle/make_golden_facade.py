@@ -41,6 +41,7 @@ from oracle import xtts_oracle as O  # noqa: E402
 
 N_LAYER = 30
 STOP_BIAS = 1.0
+STOP_BIAS_NATURAL = 0.8
 MAX_TOKENS = 96
 SEED = 77
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "facade_L30.npz")
@@ -73,6 +74,38 @@ def checkpoint(dims):
     gpt_sd["mel_head.bias"][1025] = STOP_BIAS
     xtts_sd = make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd)
     return gpt_sd, xtts_sd
+
+
+def main_c1_natural():
+    """tests/golden/facade_c1_natural_L30.npz: BASELINE configs[0] run the way a user runs it -- the 50-character sentence, greedy, the
+    checkpoint's gpt_max_audio_tokens at the reference's own 605 (xttsv2_gpt_config.py: max_audio_tokens), natural stop: the sequence
+    ends where the model emits the stop id (or at 605).  Usage: python -m oracle.make_golden_facade --c1-natural  (~1-2 min)."""
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    dims = XTTSDims()
+    # stop bias 0.8 instead of the fixture's 1.0: the greedy sequence then runs 237 tokens before it emits the stop id (17 at 1.0) --
+    # well past the 96-token cap of the other facade goldens, well short of 605: the stop itself ends it
+    gpt_sd = make_synthetic_gpt(dims.gpt, seed=1234, n_layer=N_LAYER)
+    gpt_sd["mel_head.bias"][1025] = STOP_BIAS_NATURAL
+    xtts_sd = make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd)
+    cond, spk = make_synthetic_conditioning(dims)
+    tok = XTTSTokenizer(None, vocab_size=xtts_sd["text_embedding.weight"].shape[0], synthetic=True)
+    gpt = O.GPTOracle(gpt_sd, xtts_sd)
+    w = O.vocoder_effective_weights(xtts_sd)
+    req = TTSRequest(speaker_files=[], text=C1_TEXT, language="auto", temperature=0.0, seed=SEED)
+    (ids,) = tok.batch_encode_with_split(req.text, req.language)
+    c = gpt.build_cond(cond, ids)
+    t0 = time.time()
+    g = gpt.generate(c, O.SamplingCfg(temperature=0.0, top_k=req.top_k, top_p=req.top_p, repetition_penalty=req.repetition_penalty,
+                                      max_tokens=605, ignore_stop=False, seed=req.seed & 0xFFFFFFFF))
+    lat = gpt.second_pass_latents(c, g["tokens"])
+    wav = O.hifi_decoder_forward(w, lat, spk).reshape(-1).numpy().astype(np.float32)
+    print(f"c1 natural: {len(ids)} text ids -> {len(g['tokens'])} tokens{' (stop)' if g['tokens'][-1] == 1025 else ' (cap)'}, "
+          f"{wav.shape[0]} samples, min margin {min(g['margins']) if 'margins' in g else float('nan'):.3e}, {time.time() - t0:.1f} s")
+    out = os.path.join(os.path.dirname(OUT), "facade_c1_natural_L30.npz")
+    np.savez_compressed(out, stop_bias=np.float32(STOP_BIAS_NATURAL), max_tokens=np.int32(605), n_layer=np.int32(N_LAYER), text=np.array(req.text),
+                        language=np.array(req.language), seed=np.int64(req.seed), ids=np.asarray(ids, np.int32),
+                        tokens=np.asarray(g["tokens"], np.int32), wav=wav)
+    print(f"wrote {out} ({os.path.getsize(out) / 1e6:.2f} MB)")
 
 
 def main():
@@ -122,4 +155,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--c1-natural" in sys.argv:
+        main_c1_natural()
+    else:
+        main()

@@ -17,6 +17,7 @@ class FakeNativeEngine:
         self.steps = 0
         self.finished_total = 0
         self.polls = 0
+        self.waiting_at_step = []   # sequences queued when each step began
 
     def compute_conditioning(self, pcm, max_ref_length=30, gpt_cond_len=6, gpt_cond_chunk_len=6, sound_norm_refs=False):
         """Stand-in for aur_compute_conditioning (mono float32 PCM at 22 050 Hz per reference): the PyTorch restatement of the
@@ -51,6 +52,7 @@ class FakeNativeEngine:
 
     def step(self):
         self.steps += 1
+        self.waiting_at_step.append(len(self.waiting))
         if self.fail_on_step is not None and self.steps >= self.fail_on_step:
             raise RuntimeError("injected engine failure")
         if self.fail_once_on_step is not None and self.steps == self.fail_once_on_step:

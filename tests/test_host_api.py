@@ -164,6 +164,38 @@ def test_driver_polls_only_when_the_finished_counter_moved():
     asyncio.run(main())
 
 
+def test_driver_waits_for_the_whole_burst_even_when_the_loop_stalls():
+    """An idle engine starts on a burst of concurrent requests once, not on its first arrival: a prefill pass costs the same for 1 prompt
+    as for 64.  The event loop submits them one after the other and may stall in the middle (a garbage collection, a slow tokenizer
+    call) for longer than the quiet gap: the requests still queued on the loop keep the driver waiting.  A latency-critical submission
+    ends the wait at once."""
+    import time
+
+    async def burst(d, eng, stall_after, n=8, **kw):
+        loop = asyncio.get_running_loop()
+
+        async def one(i):
+            if i == stall_after:
+                time.sleep(0.006)          # the loop thread is busy: six quiet gaps
+            return await d.submit(loop, text_ids=[4, 0, i], speaker_key=1, **kw)
+        await asyncio.gather(*[one(i) for i in range(n)])
+
+    async def main():
+        eng = FakeNativeEngine(max_seqs=16)
+        eng.set_conditioning(1, COND["gpt_cond_latent"], COND["speaker_embedding"])
+        d = EngineDriver(eng)
+        await burst(d, eng, stall_after=4)
+        assert eng.waiting_at_step[0] == 8, eng.waiting_at_step[:3]      # one admission wave
+        d.shutdown()
+        eng2 = FakeNativeEngine(max_seqs=16)
+        eng2.set_conditioning(1, COND["gpt_cond_latent"], COND["speaker_embedding"])
+        d2 = EngineDriver(eng2)
+        await burst(d2, eng2, stall_after=1, priority=1)
+        assert eng2.waiting_at_step[0] < 8, eng2.waiting_at_step[:3]     # urgent: the engine did not wait for the rest
+        d2.shutdown()
+    asyncio.run(main())
+
+
 def test_driver_survives_a_failed_step_and_fails_only_the_sequences_it_hit():
     """a failed aur_step fails what was in flight (the engine reports those through poll with error set and stays
     usable); queued sequences and later submissions go on, the TTS object is not dead.  Failures in a row stop it for good."""
