@@ -1,4 +1,4 @@
-# PMC passes of round 6: decode kernels at the bench's own --tokens 280, vocoder convs; summary folded into a copy of hbm_traffic.json
+# PMC passes of a round (here r06): decode kernels at the bench's own --tokens 280, vocoder convs; summary folded into a copy of hbm_traffic.json
 exec < /dev/null
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 PMC_TIMEOUT=500 PMC_PASSES='fetch write' PMC_KERNELS='paged_attention_kernel|gemm_rows_kernel' PMC_BENCH_ARGS='--tokens 280' bash tools/pmc.sh r06dec
