@@ -1,6 +1,7 @@
 """Build the gfx950 shared library in-tree: auralis_amd/_C/libauralis_amd.so (hipcc, no cmake)."""
 from __future__ import annotations
 
+import json
 import os
 import subprocess
 import sys
@@ -16,7 +17,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-kernarg-preload-count=16: the leading scalar kernel arguments (up to 14 dwords next to the kernarg pointer) arrive in SGPRs
 # with the wave instead of through dependent s_load round trips; a kernel whose firmware does not preload runs its compatibility
 # prologue (one s_load burst).  The decode kernels order their arguments for it (gemm_rows_kernel.inc, paged_attention_kernel).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+# -Rpass-analysis=kernel-resource-usage: the compiler reports every kernel's registers, scratch and spills while it compiles; the
+# build keeps them next to the object (_C/<unit>.resources.json) and tests/test_isa_prologue.py holds the kernels to them without
+# compiling the four-minute vocoder unit a second time.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-mllvm", "-amdgpu-kernarg-preload-count=16",
+         "-Rpass-analysis=kernel-resource-usage"]
 
 
 HASH_FILE = LIB + ".srchash"
@@ -34,6 +39,35 @@ def source_hash() -> str:
         with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()
+
+
+def resources_path(src: str) -> str:
+    return os.path.join(OUT_DIR, src.replace(".hip", ".resources.json"))
+
+
+def parse_resource_remarks(stderr: str) -> dict:
+    """hipcc's kernel-resource-usage remarks -> {mangled kernel name: {"vgprs", "agprs", "sgprs", "scratch", "sgpr_spill", "vgpr_spill",
+    "lds", "occupancy"}}"""
+    import re
+    out, cur = {}, None
+    keys = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occupancy",
+            "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill", "LDS Size [bytes/block]": "lds"}
+    for line in stderr.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+) \[-Rpass-analysis", line)
+        if m and cur is not None and m.group(1).strip() in keys:
+            cur[keys[m.group(1).strip()]] = int(m.group(2))
+    return out
+
+
+def kernel_resources(src: str) -> dict:
+    """The resource report of one translation unit of the CURRENT build (builds first when the tree is stale)."""
+    build()
+    with open(resources_path(src)) as f:
+        return json.load(f)
 
 
 def _stale(want: str) -> bool:
@@ -76,6 +110,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+        with open(resources_path(src), "w") as f:
+            json.dump(parse_resource_remarks(r.stderr), f, indent=0, sort_keys=True)
         with open(tag, "w") as f:
             f.write(want_u + "\n")
         compiled.append(src)

@@ -93,38 +93,35 @@ def test_no_gpt_kernel_spills_or_uses_flat_loads(asm):
         assert "flat_load" not in body and "scratch_" not in body, name
 
 
-@pytest.fixture(scope="module")
-def voc_asm():
-    return isa_skeleton.compile_to_asm(os.path.join(ROOT, "auralis_amd", "csrc", "vocoder_kernels.hip"))
-
-
-def test_no_vocoder_kernel_spills(voc_asm):
+def test_no_vocoder_kernel_spills():
     """twenty instantiations of the register-staged fp16 conv kernel (every 64-channel tile, conv_pre among them: on the
-    hot path) carried 32 spilled VGPRs and 76 B of scratch per lane, and no test looked at the vocoder unit.  No kernel of the
-    unit may use scratch -- the engine launches any of them depending on shapes and A/B switches -- and the hot kernels keep the
-    occupancy their launch bounds promise."""
-    import re
-    ks = isa_skeleton.kernels(voc_asm, "")
-    assert len(ks) >= 60, len(ks)
-    bad = []
-    for name, body in ks:
-        priv = re.findall(r"\.amdhsa_private_segment_fixed_size (\d+)", body)
-        spill = re.findall(r"\.vgpr_spill_count:\s*(\d+)", body)
-        if not priv or int(priv[0]) != 0 or "scratch_" in body or (spill and int(spill[0]) != 0):
-            bad.append((name, priv[:1], spill[:1]))
-    assert not bad, bad
+    hot path) carried 32 spilled VGPRs and 76 B of scratch per lane, and no test looked at the vocoder unit.  No kernel of ANY unit of
+    the library may use scratch or spill -- the engine launches any of them depending on shapes and A/B switches.  Read from the
+    compiler's own resource report of the in-tree build (auralis_amd/build.py keeps hipcc's -Rpass-analysis=kernel-resource-usage
+    remarks next to each object), so the four-minute vocoder unit is not compiled a second time."""
+    from auralis_amd.build import SOURCES, kernel_resources
+    n = 0
+    for unit in SOURCES:
+        res = kernel_resources(unit)
+        # (an SGPR spill goes to lanes of a VGPR, not to memory: reported by the compiler, not a scratch access)
+        bad = {k: v for k, v in res.items() if v.get("scratch", 0) or v.get("vgpr_spill", 0)}
+        assert not bad, (unit, bad)
+        n += len(res)
+    assert len(kernel_resources("vocoder_kernels.hip")) >= 60 and n >= 150, n
 
 
-def test_wide_conv_tile_is_compiled_for_one_workgroup_per_cu(voc_asm):
-    """The 128-channel tile of the LDS-DMA conv kernel (round 6): a 128 x 64 accumulator tile per wave = 128 registers, so eight waves
-    run one workgroup per CU (<= 256 registers), while the 64-channel tile keeps two (<= 128)."""
-    import re
-    wide = isa_skeleton.kernels(voc_asm, "conv1d_dma_f16_kernelILi3ELi1ELi128E")
-    narrow = isa_skeleton.kernels(voc_asm, "conv1d_dma_f16_kernelILi3ELi1ELi64ELi3ELi8E")
-    assert len(wide) == 1 and len(narrow) == 1, (len(wide), len(narrow))
-    for ks, cap in ((wide, 256), (narrow, 128)):
-        body = ks[0][1]
-        n = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
-        acc = re.search(r"\.amdhsa_accum_offset (\d+)", body)
-        assert n <= cap, (ks[0][0], n)
-        assert len(re.findall(r"v_mfma_f32_32x32x16_f16", body)) >= 3 * 4, ks[0][0]
+def test_conv_tiles_keep_the_occupancy_their_launch_bounds_promise():
+    """The 64-channel tile of the LDS-DMA conv kernel runs two 8-wave workgroups per CU (<= 128 registers); the 128-channel tile of
+    round 6 (AUR_CONV_MT=128, A/B only) one (<= 256); the fused ResBlock rounds fit their 512-thread workgroups (<= 128)."""
+    from auralis_amd.build import kernel_resources
+    res = kernel_resources("vocoder_kernels.hip")
+
+    def regs(v):
+        return v["vgprs"] + v.get("agprs", 0)
+    wide = {k: v for k, v in res.items() if "conv1d_dma_f16_kernelILi3ELi1ELi128E" in k}
+    narrow = {k: v for k, v in res.items() if "conv1d_dma_f16_kernelILi3ELi1ELi64ELi3ELi8E" in k}
+    rounds = {k: v for k, v in res.items() if "resblock_round_f16_kernel" in k}
+    assert len(wide) == 1 and len(narrow) == 1 and len(rounds) >= 18, (len(wide), len(narrow), len(rounds))
+    assert all(regs(v) <= 256 for v in wide.values()), wide
+    assert all(regs(v) <= 128 for v in narrow.values()), narrow
+    assert all(regs(v) <= 128 for v in rounds.values()), {k: regs(v) for k, v in rounds.items() if regs(v) > 128}
