@@ -321,3 +321,31 @@ def test_sampler_topk_fast_path_equals_full_sort(eng, monkeypatch):
                     assert list(a) == list(b), (name, T, k, p, step, a, b)
     finally:
         ref_eng.close()
+
+
+def test_sampler_top_p_cut_is_the_serial_cumulative_sum(eng):
+    """the top-p cumulative sum of the k <= 64 path was a parallel suffix scan in double -- the reference's additions in
+    another order, equal to the serial form except in the 53rd bit.  It is now serial in the reference's order on every path.  The test
+    drives the same distributions through BOTH code paths of the kernel: with top_k = 50 the candidates are the 50 survivors (one wave,
+    registers), with top_k disabled they are all 1026 ids sorted by the full bitonic network and cut by thread 0's serial loop -- the
+    other 976 ids carry probability exactly 0 (their logits sit 1e4 below), which adds nothing to either sum.  Same noise, so the same
+    token on every row, for top_p values that put the cut at a boundary (cumulative sums of dyadic probabilities) and in a wide
+    dynamic range."""
+    g = torch.Generator().manual_seed(91)
+    B = 8
+    base = torch.full((B, 1026), -1.0e4) - torch.arange(1026, dtype=torch.float32)[None, :] * 1e-2   # distinct, far below: probability 0
+    wide = base.clone()
+    dyadic = base.clone()
+    for r in range(B):
+        ids = torch.randperm(1026, generator=g)[:50]
+        wide[r, ids] = torch.randn(50, generator=g) * 6.0                        # probabilities over ~15 orders of magnitude
+        # probabilities 2^-1, 2^-2, ..., 2^-9 and forty-one of 2^-9 / 41: cumulative sums land ON the dyadic boundaries 1 - p
+        lp = torch.cat([-(torch.arange(1, 10, dtype=torch.float32)) * 0.6931471805599453,
+                        torch.full((41,), -9 * 0.6931471805599453 - float(np.log(41.0)))])
+        dyadic[r, ids] = lp
+    for name, lg in (("wide", wide), ("dyadic", dyadic)):
+        for T, p in ((1.0, 0.5), (1.0, 0.75), (1.0, 0.875), (1.0, 0.9375), (0.75, 0.85), (1.3, 0.6)):
+            for step in (0, 5, 9):
+                a = eng.dbg_sample(lg.numpy(), T, p, 50, seed=808, step=step)     # survivors in one wave
+                b = eng.dbg_sample(lg.numpy(), T, p, 0, seed=808, step=step)      # all ids, serial cut
+                assert list(a) == list(b), (name, T, p, step, list(a), list(b))
