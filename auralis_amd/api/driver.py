@@ -137,11 +137,15 @@ class EngineDriver:
                     break
                 # quiet for burst_gap_s AND the submitting loop has nothing queued: a loop thread that stalls in the middle of a burst
                 # (a garbage collection, a slow tokenizer call) still has the other requests' tasks in its ready queue
-                if now - self._last_submit >= self.burst_gap_s and not any(self._loop_busy(lp) for lp in tuple(self._burst_loops)):
-                    break
+                if now - self._last_submit >= self.burst_gap_s:
+                    with self._lock:      # (submit() adds to the set under the same lock)
+                        loops = tuple(self._burst_loops)
+                    if not any(self._loop_busy(lp) for lp in loops):
+                        break
                 time.sleep(self.burst_gap_s * 0.25)
             self._urgent = False
-            self._burst_loops.clear()
+            with self._lock:
+                self._burst_loops.clear()
             last_fin = None
             in_a_row = 0
             while not self._stop:
