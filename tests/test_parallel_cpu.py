@@ -129,3 +129,40 @@ def test_native_route_is_entered_only_when_every_rank_built_its_communicator(tmp
                 assert err == "" and err2 == "" and entered == "1" and n_bcast == "1" and inits == "1"
             if bad:
                 assert inits == "1"   # the agreed failure is remembered: nobody re-enters the id exchange alone
+
+
+def _src_fail_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from auralis_amd.parallel import broadcast_conditioning_native
+
+    class Eng(_CommEngine):
+        def set_conditioning(self, key, g, s):
+            raise RuntimeError("speaker table full: every registered voice has undelivered sequences")
+    _CommEngine.bad = ()
+    eng = Eng(rank)
+    err = ""
+    try:
+        g = torch.zeros(1, 32, 1024) if rank == 0 else None
+        s = torch.zeros(1, 512, 1) if rank == 0 else None
+        broadcast_conditioning_native(eng, 5, g, s, src=0)
+    except RuntimeError as e:
+        err = str(e)
+    with open(os.path.join(out_dir, f"s{rank}.txt"), "w") as f:
+        f.write(f"{err}|{len(eng.bcasts)}")
+    dist.destroy_process_group()
+
+
+def test_native_route_is_not_entered_when_the_source_cannot_register_its_voice(tmp_path):
+    """the source registers the voice BEFORE the collective; if that raises on the source only (mis-shaped tensors, a full
+    speaker table) the other ranks must not be left inside ncclBroadcast: the ranks agree on the source's outcome first, every rank
+    raises, nobody calls aur_broadcast_conditioning."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_src_fail_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    e0, n0 = (tmp_path / "s0.txt").read_text().split("|")
+    e1, n1 = (tmp_path / "s1.txt").read_text().split("|")
+    assert "speaker table full" in e0 and "rank 0" in e0 and n0 == "0"
+    assert "rank 0 could not register" in e1 and n1 == "0"
