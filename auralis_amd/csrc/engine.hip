@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <deque>
@@ -248,6 +249,7 @@ public:
         if (const char* e = getenv("AUR_DECODE_PIPELINE")) pipeline_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_WAV_DIRECT")) wav_direct_ = atoi(e) != 0;   // 0: conv_post writes device memory, one D2H copy per sequence behind it (A/B only)
         if (const char* e = getenv("AUR_SAMPLER_FULL_SORT")) sampler_full_sort_ = atoi(e) != 0;
+        if (const char* e = getenv("AUR_HOST_TRACE")) host_trace_ = atoi(e) != 0;
         if (const char* e = getenv("AUR_TEST_FAIL_STEP")) fail_at_step_ = atoi(e);
         if (const char* e = getenv("AUR_TEST_FAIL_VOC")) fail_at_voc_ = atoi(e);
 
@@ -1843,8 +1845,18 @@ private:
     void decode_pipelined(const std::vector<int>& active) {
         if (!infl_.on) infl_ = launch_decode_step(active);
         InFlight next;
+        const auto t0 = std::chrono::steady_clock::now();
         if (worth_speculating(active, infl_)) next = launch_decode_step(active);
+        const auto t1 = std::chrono::steady_clock::now();
         collect_decode_step(infl_);
+        const auto t2 = std::chrono::steady_clock::now();
+        if (host_trace_) {
+            ht_launch_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+            ht_wait_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
+            if (++ht_n_ % 256 == 0)
+                fprintf(stderr, "[aur host trace] rows %zu: launch_decode_step %.1f us of host time per step, wait for the read-back %.1f us\n", active.size(),
+                        ht_launch_ns_ / 256e3, ht_wait_ns_ / 256e3), ht_launch_ns_ = ht_wait_ns_ = 0;
+        }
         retire_finished();
         infl_ = next;
     }
@@ -2245,6 +2257,8 @@ private:
     hipEvent_t ev_rb_[2] = {nullptr, nullptr}, ev_ds_[2] = {nullptr, nullptr}, ev_de_[2] = {nullptr, nullptr};
     int rb_next_ = 0;
     bool sampler_full_sort_ = false;    // AUR_SAMPLER_FULL_SORT=1: disable the sampler's top-k fast path (A/B)
+    bool host_trace_ = false;           // AUR_HOST_TRACE=1: host time of enqueueing a decode step vs waiting for the previous one (stderr, every 256 steps)
+    long ht_launch_ns_ = 0, ht_wait_ns_ = 0, ht_n_ = 0;
     bool pipeline_ = true;              // AUR_DECODE_PIPELINE=0: wait for every read-back before launching the next step
     bool conv_dma_ = true;              // ResBlock convs of the fp16 vocoder on the LDS-DMA staged kernel
     bool xt_f16_ = false;               // set in the constructor: fp16 vocoder => fp16 c1 -> c2 intermediate (AUR_XT_F16=0 disables)
