@@ -83,7 +83,7 @@ EXPORTS = [
     "aur_set_conditioning", "aur_set_conditioning_device", "aur_has_conditioning", "aur_compute_conditioning", "aur_comm_unique_id", "aur_comm_init", "aur_broadcast_conditioning",
     "aur_comm_info", "aur_conditioning_checksum",
     "aur_submit", "aur_step", "aur_poll_finished",
-    "aur_release", "aur_vocode", "aur_sync", "aur_get_stats", "aur_reset_stats", "aur_set_profile", "aur_dbg_gemm", "aur_dbg_gemm_rows", "aur_dbg_gemm_rows_ksplit_stress", "aur_dbg_lane_xor_selftest",
+    "aur_release", "aur_cancel", "aur_vocode", "aur_sync", "aur_get_stats", "aur_reset_stats", "aur_set_profile", "aur_dbg_gemm", "aur_dbg_gemm_rows", "aur_dbg_gemm_rows_ksplit_stress", "aur_dbg_lane_xor_selftest",
     "aur_dbg_layernorm", "aur_dbg_conv1d", "aur_dbg_conv1d_f16", "aur_dbg_prefill", "aur_dbg_sample",
 ]
 
@@ -126,6 +126,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "aur_step": [eng, ip, ip],
         "aur_poll_finished": [eng, C.POINTER(aur_result), C.c_size_t, C.POINTER(C.c_size_t)],
         "aur_release": [eng, C.c_uint64],
+        "aur_cancel": [eng, C.c_uint64],
         "aur_vocode": [eng, fp, ip, C.c_int32, C.c_int32, C.c_uint64, fp, C.c_int64, ip],
         "aur_sync": [eng],
         "aur_get_stats": [eng, C.POINTER(aur_stats)],
@@ -395,6 +396,11 @@ class NativeEngine:
             lease.release()
         elif ref is not None:     # the lease object is being finalised: its __del__ releases
             return
+
+    def cancel(self, seq_id: int):
+        """aur_cancel: stop a sequence nobody waits for any more.  It is still reported by poll() (error = AUR_E_CANCELLED = -5, the
+        tokens generated so far, no audio).  Does not wait for a running step."""
+        self._check(self.lib.aur_cancel(self.h, seq_id))
 
     def run_until_done(self, max_steps: int = 100000, copy: bool = True) -> List[dict]:
         """Drive aur_step until nothing is live; returns finished results in completion order (copy: see poll)."""

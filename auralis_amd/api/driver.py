@@ -45,6 +45,7 @@ class EngineDriver:
         self._stop = False
         self._error: Optional[BaseException] = None
         self.failed_steps = 0          # aur_step calls that raised (the driver went on after them unless they came in a row)
+        self.cancelled = 0             # sequences stopped with aur_cancel because their consumer had gone
         self._thread = threading.Thread(target=self._run, name="auralis-amd-driver", daemon=True)
         self._thread.start()
 
@@ -65,12 +66,29 @@ class EngineDriver:
                 reregister()
                 sid = self.engine.submit(**seq)
             self._pending[sid] = (loop, fut)
+            # a consumer that walks away (a cancelled task, a closed stream) cancels the future: the engine stops the sequence
+            # instead of decoding it to the end and vocoding it for nobody (aur_cancel)
+            fut.add_done_callback(lambda f, sid=sid: self._on_done(f, sid))
             self._last_submit = time.perf_counter()
             self._burst_loops.add(loop)
             if seq.get("priority", 0) > 0:
                 self._urgent = True
         self._wake.set()
         return fut
+
+    def _on_done(self, fut: "asyncio.Future", sid: int):
+        if not fut.cancelled():
+            return
+        with self._lock:
+            known = self._pending.get(sid) is not None
+        cancel = getattr(self.engine, "cancel", None)
+        if known and cancel is not None:
+            try:
+                cancel(sid)          # the engine still reports the sequence through poll(); _resolve drops it there
+                self.cancelled += 1
+            except Exception:        # noqa: BLE001 - already finished / released: nothing to stop
+                pass
+            self._wake.set()
 
     @staticmethod
     def _loop_busy(loop: asyncio.AbstractEventLoop) -> bool:

@@ -65,6 +65,12 @@ class TwoPhaseScheduler:
                 if not t.done():
                     t.cancel()
                 self._tasks.discard(t)
+            # the consumer left early (stream closed, timeout, a chunk failed): the chunks nobody will read are told so.  A pump that was
+            # still waiting for its turn never awaited its chunk, so cancelling the task alone would leave that chunk decoding
+            for g in gens:
+                h = g.get("generator") if isinstance(g, dict) else None
+                if hasattr(h, "cancel"):
+                    h.cancel()
 
     async def shutdown(self):
         self.is_running = False

@@ -48,6 +48,12 @@ class ChunkHandle:
         self.request_id = request_id
         self.n_text = n_text
 
+    def cancel(self):
+        """Nobody will read this chunk: stop it in the engine (EngineDriver -> aur_cancel).  Nothing happens once it is resolved."""
+        fut = self.future
+        if not fut.done():
+            fut.get_loop().call_soon_threadsafe(fut.cancel)
+
 
 class XTTSv2Engine(BaseAsyncTTSEngine):
     model_type = "xtts"

@@ -173,6 +173,7 @@ struct Seq {
     int pool_idx = -1;   // latent-pool entry once the tokens are done (vocoder stage)
     bool shared_prefix = false;
     int error = 0;
+    bool cancel = false;   // aur_cancel: stop decoding at the next step, skip the vocoder
 };
 
 struct ConvLayer {
@@ -622,6 +623,59 @@ public:
         seqs_.erase(it);
     }
 
+    // aur_cancel.  Takes only the queue lock: a WAITING sequence is dropped here; everything else is noted and handled by the driver
+    // thread at the top of its next aur_step (process_cancels), so the caller -- the facade's event loop -- never waits for a step.
+    void cancel(uint64_t id) {
+        std::lock_guard<std::mutex> lk(mu_);
+        auto it = seqs_.find(id);
+        AUR_REQUIRE(it != seqs_.end(), "unknown seq_id");
+        Seq* s = it->second.get();
+        if (s->state == SeqState::WAITING) {
+            waiting_.erase(std::remove(waiting_.begin(), waiting_.end(), s), waiting_.end());
+            finish_cancelled(s);
+        } else if (s->state == SeqState::RUNNING || s->state == SeqState::TOKENS_DONE) {
+            if (!s->cancel) cancel_pending_.push_back(id);
+        }
+    }
+    // (caller holds mu_; the sequence holds no slot, K/V block or pool entry any more)
+    void finish_cancelled(Seq* s) {
+        s->cancel = true;
+        s->error = AUR_E_CANCELLED;
+        s->wav = nullptr; s->n_samples = 0; s->latents = nullptr; s->n_latent_rows = 0;
+        spk_info_[s->spk_row].refs--;
+        s->state = SeqState::DONE;
+        done_.push_back(s);
+        finished_total_++;
+    }
+    // driver thread, inside aur_step (gpu_mu_ held): a running sequence gets max_tokens = 1 on the device -- the sampler then flags it
+    // finished with the next token it draws, and finish_tokens() drops it instead of parking its latents; a sequence that waits in the
+    // vocoder queue leaves it.  One already inside a vocoder batch is delivered normally.
+    void process_cancels() {
+        std::vector<uint64_t> ids;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            ids.swap(cancel_pending_);
+        }
+        for (uint64_t id : ids) {
+            std::lock_guard<std::mutex> lk(mu_);
+            auto it = seqs_.find(id);
+            if (it == seqs_.end()) continue;
+            Seq* s = it->second.get();
+            if (s->state == SeqState::RUNNING && s->slot >= 0 && !s->cancel) {
+                s->cancel = true;
+                HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(max_tokens_.as<int>() + s->slot), 1, 1, st_));
+            } else if (s->state == SeqState::TOKENS_DONE) {
+                auto q = std::find(voc_queue_.begin(), voc_queue_.end(), s);
+                if (q != voc_queue_.end()) {
+                    voc_queue_.erase(q);
+                    if (s->pool_idx >= 0) latpool_free_.push_back(s->pool_idx);
+                    s->pool_idx = -1;
+                    finish_cancelled(s);
+                }
+            }
+        }
+    }
+
     // ------------------------------------------------------------------ one scheduler iteration
     // A failure inside a step (HIP error, exhausted pool) must not leave slots, KV blocks and pool entries half-updated:
     // every sequence that was in flight is failed (aur_result.error), its resources go back to the pools, and the
@@ -688,6 +742,7 @@ public:
             throw HipError("injected failure (AUR_TEST_FAIL_STEP)");
         }
         bool worked = false;
+        process_cancels();
         // back-pressure: every running sequence must be able to park its latents when it finishes
         while ((int)latpool_free_.size() < cfg_.max_seqs) {
             if (voc_active_)
@@ -1619,7 +1674,12 @@ private:
     // sequences whose tokens completed in this step: (optional literal second pass) -> latent pool -> vocoder queue
     void retire_finished() {
         if (just_finished_.empty()) return;
-        if (cfg_.second_pass) second_pass(just_finished_);
+        if (cfg_.second_pass) {
+            std::vector<Seq*> wanted;
+            for (Seq* s : just_finished_)
+                if (!s->cancel) wanted.push_back(s);
+            if (!wanted.empty()) second_pass(wanted);
+        }
         for (Seq* s : just_finished_) finish_tokens(s);
         just_finished_.clear();
     }
@@ -1668,6 +1728,15 @@ private:
         stats_.prefill_rows += M;
     }
     void finish_tokens(Seq* s) {
+        if (s->cancel) {   // aur_cancel: nobody wants the audio -- free slot and blocks, report it, no vocoder
+            std::lock_guard<std::mutex> lk(mu_);
+            for (int b : s->blocks) free_blocks_.push_back(b);
+            s->blocks.clear();
+            slot_owner_[s->slot] = nullptr;
+            s->slot = -1;
+            finish_cancelled(s);
+            return;
+        }
         s->state = SeqState::TOKENS_DONE;
         // park the stashed latents in the pool (D2D on the main stream, ordered before any later prefill that reuses
         // the slot) and release slot + KV blocks at once: the vocoder stage no longer occupies a batcher slot
@@ -2288,6 +2357,7 @@ private:
     uint64_t next_id_ = 1;
     std::unordered_map<uint64_t, std::unique_ptr<Seq>> seqs_;
     std::deque<Seq*> waiting_, done_;
+    std::vector<uint64_t> cancel_pending_;   // aur_cancel requests for sequences past the waiting queue (guarded by mu_)
     static constexpr int kAdmitHoldSteps = 32;   // longest hold of an admissible request by aur_config.admit_min_batch, in aur_steps
     static constexpr int kUrgentHoldSteps = 8;   // ... while an urgent sequence runs (arrivals are grouped, not kept waiting long)
     int admit_hold_steps_ = 0;
@@ -2432,6 +2502,10 @@ int aur_poll_finished(aur_engine* e, aur_result* out, size_t cap, size_t* n) {
 int aur_release(aur_engine* e, uint64_t seq_id) {
     CHECK_PTR(e);
     return guarded([&] { e->impl.release(seq_id); });
+}
+int aur_cancel(aur_engine* e, uint64_t seq_id) {
+    CHECK_PTR(e);
+    return guarded([&] { e->impl.cancel(seq_id); });
 }
 int aur_vocode(aur_engine* e, const float* latents, const int32_t* n_lat, int32_t B, int32_t t_max,
                uint64_t speaker_key, float* wav_out, int64_t wav_stride, int32_t* n_samples_out) {

@@ -28,6 +28,7 @@ extern "C" {
 #define AUR_E_HIP (-2)       /* HIP runtime or kernel failure */
 #define AUR_E_STATE (-3)     /* call not valid in the current state (e.g. weights not loaded) */
 #define AUR_E_NOMEM (-4)
+#define AUR_E_CANCELLED (-5) /* aur_result.error of a sequence that was cancelled with aur_cancel */
 
 typedef struct aur_engine aur_engine;
 
@@ -239,6 +240,13 @@ int aur_step(aur_engine* e, int32_t* n_live, int32_t* n_finished_total);
 
 int aur_poll_finished(aur_engine* e, aur_result* out, size_t cap, size_t* n);
 int aur_release(aur_engine* e, uint64_t seq_id);
+/* Stop a sequence nobody is waiting for any more (a streaming consumer that disconnected; the reference has no counterpart: its
+ * chunks decode to the end, two_phase_scheduler.py:279-291 only stops scheduling new ones).  A sequence still waiting for a slot is
+ * dropped at once; a running one stops within two decode steps and is NOT vocoded; one whose tokens are done but whose vocoder batch has
+ * not been launched is dropped; one already being vocoded (or finished) is left alone.  A cancelled sequence is reported by
+ * aur_poll_finished like any other, with error = AUR_E_CANCELLED, the tokens generated so far and no audio; it still needs
+ * aur_release.  Thread-safe, does not wait for a running aur_step.  No other sequence's output changes. */
+int aur_cancel(aur_engine* e, uint64_t seq_id);
 
 /* Standalone vocoder (HifiDecoder.forward, hifigan_decoder.py:776-802) for parity tests and for callers
  * that bring their own latents: latents [B][t_max][1024], n_lat[B] valid rows each; wav_out [B][wav_stride]. */

@@ -5,7 +5,7 @@ import numpy as np
 class FakeNativeEngine:
     n_layer = 1
 
-    def __init__(self, max_seqs=4, fail_on_step=None, conditioning_weights=None, fail_once_on_step=None):
+    def __init__(self, max_seqs=4, fail_on_step=None, conditioning_weights=None, fail_once_on_step=None, step_delay=0.0):
         self.conditioning_weights = conditioning_weights   # xtts-v2.safetensors tensors: enables compute_conditioning below
         self.max_seqs = max_seqs
         self.next_id = 1
@@ -18,6 +18,8 @@ class FakeNativeEngine:
         self.finished_total = 0
         self.polls = 0
         self.waiting_at_step = []   # sequences queued when each step began
+        self.cancelled = []
+        self.step_delay = step_delay   # seconds per step (a test that needs work still in flight when it acts)
 
     def compute_conditioning(self, pcm, max_ref_length=30, gpt_cond_len=6, gpt_cond_chunk_len=6, sound_norm_refs=False):
         """Stand-in for aur_compute_conditioning (mono float32 PCM at 22 050 Hz per reference): the PyTorch restatement of the
@@ -52,6 +54,9 @@ class FakeNativeEngine:
 
     def step(self):
         self.steps += 1
+        if self.step_delay:
+            import time
+            time.sleep(self.step_delay)
         self.waiting_at_step.append(len(self.waiting))
         if self.fail_on_step is not None and self.steps >= self.fail_on_step:
             raise RuntimeError("injected engine failure")
@@ -77,6 +82,16 @@ class FakeNativeEngine:
         self.polls += 1
         out, self.done = self.done[:cap], self.done[cap:]
         return out
+
+    def cancel(self, seq_id):
+        """as aur_cancel: a waiting or running sequence stops and is reported with error -5 and no audio"""
+        for q in (self.waiting, self.running):
+            for s in list(q):
+                if s["seq_id"] == seq_id:
+                    q.remove(s)
+                    self.done.append({"seq_id": seq_id, "tokens": np.zeros(0, np.int32), "wav": np.zeros(0, np.float32), "error": -5})
+                    self.finished_total += 1
+                    self.cancelled.append(seq_id)
 
     def release(self, seq_id):   # (poll(copy=False) contract of NativeEngine; the fake's arrays are always owned)
         pass

@@ -475,6 +475,61 @@ def test_admission_urgent_sequence_jumps_the_queue_and_changes_no_output(dims):
         assert np.array_equal(plain[a]["wav"], urg[b]["wav"]) and np.array_equal(plain[a]["latents"], urg[b]["latents"])
 
 
+def test_cancel_stops_a_sequence_frees_its_resources_and_changes_nobody_else(dims):
+    """aur_cancel: ten long sequences on six slots; after a few steps two running ones and one waiting one are cancelled.  The waiting
+    one is reported at once, the running ones stop within a few decode steps (far short of their 150 tokens) and are not vocoded; all
+    three come back with error AUR_E_CANCELLED and no audio.  The other seven finish with ids, latents and audio equal bit for bit to a
+    run without any cancellation; slots, K/V blocks and the latent pool are all back."""
+    from auralis_amd._lib import NativeEngine
+    from auralis_amd.checkpoint import make_synthetic_gpt, make_synthetic_xtts
+    from auralis_amd.weights import pack_all
+    gpt_sd = make_synthetic_gpt(dims.gpt, seed=1234, n_layer=2)
+    packed = pack_all(gpt_sd, make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd))
+    cond, spk = make_synthetic_conditioning(dims)
+
+    def run(cancel):
+        e = NativeEngine(n_layer=2, max_seqs=6)
+        try:
+            e.load_weights(packed)
+            e.set_conditioning(SPK_KEY, cond.numpy(), spk.numpy())
+            sids = [e.submit(make_synthetic_text_ids(dims, n_text=9 + k, seed=120 + k), SPK_KEY, temperature=0.8, top_k=50, top_p=0.85,
+                             repetition_penalty=5.0, max_tokens=150, seed=700 + k, ignore_stop=True) for k in range(10)]
+            got = {}
+            for i in range(4000):
+                live, _ = e.step()
+                if cancel and i == 5:
+                    for k in (1, 4, 8):          # 1 and 4 are running (slots 0..5 hold sequences 0..5), 8 still waits
+                        e.cancel(sids[k])
+                    e.cancel(sids[8])            # twice: harmless
+                for o in e.poll():
+                    got[o["seq_id"]] = o
+                if live == 0:
+                    break
+            assert len(got) == 10
+            st = e.stats()
+            assert st["kv_blocks_total"] - st["kv_blocks_free"] == 2 and st["sequences_tracked"] == 0
+            return [got[s] for s in sids]
+        finally:
+            e.close()
+
+    base = run(False)
+    cut = run(True)
+    for k in range(10):
+        if k in (1, 4, 8):
+            assert cut[k]["error"] == -5 and len(cut[k]["wav"]) == 0
+            assert len(cut[k]["tokens"]) <= (12 if k != 8 else 0), (k, len(cut[k]["tokens"]))
+            assert cut[k]["tokens"].tolist() == base[k]["tokens"][: len(cut[k]["tokens"])].tolist()   # what it did generate is what it would have
+        else:
+            assert cut[k]["error"] == 0 and cut[k]["tokens"].tolist() == base[k]["tokens"].tolist()
+            assert np.array_equal(cut[k]["wav"], base[k]["wav"]) and np.array_equal(cut[k]["latents"], base[k]["latents"])
+    with pytest.raises(AurError, match="unknown seq_id"):
+        e2 = NativeEngine(n_layer=2, max_seqs=2)
+        try:
+            e2.cancel(12345)
+        finally:
+            e2.close()
+
+
 def test_kv_pool_above_the_32_bit_offset_range_is_refused_at_creation():
     """paged_attention_kernel addresses a layer's K/V pool with 32-bit byte offsets: a pool of 4 GiB or more per
     layer -- 495 slots with the fp32 pool, 992 with fp16 -- must be refused when the engine is created, not read past 4 GiB later."""

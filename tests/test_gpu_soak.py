@@ -99,3 +99,56 @@ def test_hundred_facade_requests_leave_no_resources_behind(tmp_path, dims, monke
         assert native._leased_bytes == 0 and not native._leases
     finally:
         tts.close()
+
+
+def test_consumers_that_walk_away_leave_nothing_decoding(tmp_path, dims):
+    """thirty streaming requests of ~10 chunks each on a 4-slot engine whose sequences never stop by themselves
+    (`fixed_length`: 605 tokens each -- a request left to run would hold the engine for seconds); every consumer reads its first
+    chunk (every third one two chunks) and closes the stream.  The chunks nobody will read are cancelled in the engine (aur_cancel): the whole
+    test is over in a fraction of the time the abandoned chunks would have decoded for, the engine ends up idle with every K/V block,
+    result block and sequence record back, and a request after all that is served bit for bit like before."""
+    import time
+
+    from auralis_amd import TTS, TTSRequest
+    from auralis_amd.checkpoint import make_synthetic_conditioning, make_synthetic_gpt, make_synthetic_xtts, save_checkpoint
+    gpt_sd = make_synthetic_gpt(dims.gpt, seed=1234, n_layer=2)
+    save_checkpoint(str(tmp_path), gpt_sd, make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd), dims, synthetic_tokenizer=True)
+    cond, spk = make_synthetic_conditioning(dims)
+    voice = {"gpt_cond_latent": cond.numpy(), "speaker_embedding": spk.numpy()}
+    tts = TTS(scheduler_max_concurrency=4).from_pretrained(str(tmp_path))
+    tts.tts_engine.fixed_length = True
+    native, drv = tts.tts_engine.native, tts.tts_engine.driver
+    try:
+        probe = TTSRequest(text=SHORT, speaker_files=[voice], language="en", seed=5)
+        t0 = time.perf_counter()
+        before = tts.generate_speech(probe).array.copy()
+        t_one = time.perf_counter() - t0           # one 605-token chunk alone
+        book = " ".join([LONG] * 5)
+        n_chunks = len(tts.tts_engine.tokenizer.batch_encode_with_split(book, "en"))
+        assert n_chunks >= 8
+        t0 = time.perf_counter()
+        for i in range(30):
+            gen = tts.generate_speech(TTSRequest(text=book, speaker_files=[voice], language="en", seed=40 + i, stream=True))
+            for _ in range(1 + (i % 3 == 0)):      # one chunk, every third consumer two
+                c = next(gen)
+                assert len(c.array) > 0
+                del c
+            gen.close()
+        deadline = time.time() + 60
+        while drv._pending and time.time() < deadline:      # the cancelled sequences come back through poll() and are dropped
+            time.sleep(0.005)
+        t_all = time.perf_counter() - t0
+        gc.collect()                                         # (the outputs that were read are leases on result blocks)
+        st = native.stats()
+        assert not drv._pending and st["sequences_tracked"] == 0, (len(drv._pending), st["sequences_tracked"])
+        assert drv.cancelled >= 30 * (n_chunks - 4), (drv.cancelled, n_chunks)
+        # 30 x n_chunks chunks of 605 tokens on 4 slots would take ~30 * n_chunks / 4 times one chunk; the 40 chunks that were
+        # read cost about one chunk time each (they ran beside soon-to-be-cancelled neighbours)
+        print(f"one chunk alone {t_one:.2f} s; 30 abandoned {n_chunks}-chunk streams {t_all:.2f} s; {drv.cancelled} sequences cancelled")
+        assert t_all < 0.5 * (30 * n_chunks / 4) * t_one, (t_all, t_one, n_chunks)
+        assert st["kv_blocks_total"] - st["kv_blocks_free"] == 2, st
+        assert st["result_blocks_free"] == st["result_blocks"] and native._leased_bytes == 0
+        after = tts.generate_speech(probe).array
+        assert np.array_equal(before, after)
+    finally:
+        tts.close()

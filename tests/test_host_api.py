@@ -196,6 +196,26 @@ def test_driver_waits_for_the_whole_burst_even_when_the_loop_stalls():
     asyncio.run(main())
 
 
+def test_driver_cancels_the_sequence_of_a_consumer_that_walked_away():
+    """a streaming consumer that disconnects cancels its chunk futures; the driver then stops those sequences in the
+    engine (aur_cancel) instead of letting them decode to the end and be vocoded for nobody.  The others are untouched."""
+    async def main():
+        eng = FakeNativeEngine(max_seqs=2)
+        eng.set_conditioning(1, COND["gpt_cond_latent"], COND["speaker_embedding"])
+        d = EngineDriver(eng)
+        loop = asyncio.get_running_loop()
+        futs = [d.submit(loop, text_ids=[4, 5 * i, 0], speaker_key=1) for i in range(6)]   # 5 steps each on 2 slots
+        futs[1].cancel()           # running (or about to)
+        futs[4].cancel()           # still waiting for a slot
+        res = await asyncio.gather(*futs, return_exceptions=True)
+        assert [isinstance(r, asyncio.CancelledError) for r in res] == [False, True, False, False, True, False]
+        assert sorted(eng.cancelled) == [2, 5] and d.cancelled == 2
+        assert [r["seq_id"] for r in res if isinstance(r, dict)] == [1, 3, 4, 6]
+        assert not d._pending
+        d.shutdown()
+    asyncio.run(main())
+
+
 def test_driver_survives_a_failed_step_and_fails_only_the_sequences_it_hit():
     """a failed aur_step fails what was in flight (the engine reports those through poll with error set and stays
     usable); queued sequences and later submissions go on, the TTS object is not dead.  Failures in a row stop it for good."""

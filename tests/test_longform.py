@@ -61,6 +61,33 @@ def test_longform_mixed_languages_gpu(tmp_path, dims):
         tts.close()
 
 
+def test_a_closed_stream_cancels_the_chunks_nobody_will_read():
+    """A streaming consumer takes the first chunk of a long request and goes away (an HTTP client that disconnects): the chunks still
+    queued or decoding are cancelled in the engine -- also those whose pump was still waiting for a scheduler slot and never looked at
+    its chunk -- and the facade keeps serving."""
+    from auralis_amd import TTSRequest
+    fake = FakeNativeEngine(max_seqs=1, step_delay=0.02)
+    tts = TTS(scheduler_max_concurrency=2).with_engine(XTTSv2Engine(fake, XTTSTokenizer(None, synthetic=True)))
+    try:
+        gen = tts.generate_speech(TTSRequest(text=" ".join([EN] * 6), speaker_files=[VOICE], language="en", stream=True, seed=3))
+        first = next(gen)
+        assert len(first.array) > 0
+        n = len(fake.submitted)
+        assert n >= 10
+        gen.close()
+        import time
+        t0 = time.time()
+        while (fake.finished_total < n or tts.tts_engine.driver._pending) and time.time() - t0 < 10:   # (the driver polls after its next step)
+            time.sleep(0.01)
+        assert len(fake.cancelled) >= n - 4 and len(set(fake.cancelled)) == len(fake.cancelled), (n, fake.cancelled, fake.finished_total)
+        assert not fake.waiting and not fake.running
+        assert not tts.tts_engine.driver._pending
+        out = tts.generate_speech(TTSRequest(text="Still here.", speaker_files=[VOICE], language="en"))
+        assert len(out.array) > 0
+    finally:
+        tts.close()
+
+
 def test_book_scale_stream_host_overhead():
     """BASELINE config 5 size (~450 k characters, > 2 000 chunks) through the facade with the fake engine: every chunk comes
     back once and in order, and the host path stays far below the GPU's per-chunk time (~14 ms per chunk per GPU)."""
