@@ -475,7 +475,8 @@ def test_admission_urgent_sequence_jumps_the_queue_and_changes_no_output(dims):
         assert np.array_equal(plain[a]["wav"], urg[b]["wav"]) and np.array_equal(plain[a]["latents"], urg[b]["latents"])
 
 
-def test_cancel_stops_a_sequence_frees_its_resources_and_changes_nobody_else(dims):
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_cancel_stops_a_sequence_frees_its_resources_and_changes_nobody_else(dims, monkeypatch, pipeline):
     """aur_cancel: ten long sequences on six slots; after a few steps two running ones and one waiting one are cancelled.  The waiting
     one is reported at once, the running ones stop within a few decode steps (far short of their 150 tokens) and are not vocoded; all
     three come back with error AUR_E_CANCELLED and no audio.  The other seven finish with ids, latents and audio equal bit for bit to a
@@ -486,6 +487,8 @@ def test_cancel_stops_a_sequence_frees_its_resources_and_changes_nobody_else(dim
     gpt_sd = make_synthetic_gpt(dims.gpt, seed=1234, n_layer=2)
     packed = pack_all(gpt_sd, make_synthetic_xtts(dims, seed=1234, gpt_sd=gpt_sd))
     cond, spk = make_synthetic_conditioning(dims)
+
+    monkeypatch.setenv("AUR_DECODE_PIPELINE", pipeline)     # (read when the engine is created) pipelined and synchronous decode loop
 
     def run(cancel):
         e = NativeEngine(n_layer=2, max_seqs=6)
