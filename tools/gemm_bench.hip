@@ -121,17 +121,34 @@ int main(int argc, char** argv) {
                             {"fc  ", 4096, 1024, true, kEpiBiasGelu},
                             {"prj2", 1024, 4096, false, kEpiResidual},
                             {"head", 1088, 1024, false, kEpiBias}};
-    auto make_args = [&](const Shape& s, const float* wt, int prec) {
+    // (a second set of activation buffers, K-split scratch and rows 32.. of the row table: the second chain of the two-stream experiment)
+    struct Bufs { float *hres, *act, *att, *qb, *ksp_buf; unsigned* ksp_cnt; int* drm; float2* dstats; };
+    const Bufs B0{hres, act, att, qb, ksp_buf, ksp_cnt, drm, dstats};
+    Bufs B1 = B0;
+    if (getenv("DUAL")) {
+        B1.hres = dalloc((size_t)256 * 4096, 1.0f, 32);
+        B1.act = dalloc((size_t)256 * 4096, 0.5f, 33);
+        B1.att = dalloc((size_t)256 * 1024, 0.5f, 34);
+        B1.qb = dalloc((size_t)256 * 1024, 0.f, 35);
+        HIP_CHECK(hipMalloc(&B1.ksp_buf, (size_t)kGemmKspTiles * 16 * 256 * 4));
+        HIP_CHECK(hipMalloc(&B1.ksp_cnt, (size_t)kGemmKspTiles * 4));
+        HIP_CHECK(hipMemset(B1.ksp_cnt, 0, (size_t)kGemmKspTiles * 4));
+        B1.drm = drm + (size_t)M * kRowMetaStride;
+        HIP_CHECK(hipMalloc(&B1.dstats, 256 * 64 * sizeof(float2)));
+        HIP_CHECK(hipMemcpy(B1.dstats, dstats, 256 * 64 * sizeof(float2), hipMemcpyDeviceToDevice));
+    }
+    auto make_args_b = [&](const Shape& s, const float* wt, int prec, const Bufs& B) {
         GemmRowsArgs a{};
         a.M = M; a.prec = prec; a.eps = 1e-5f; a.xmt = MTT; a.omt = MTT; a.Wt = wt; a.N = s.N; a.K = s.K; a.bias = bias;
-        a.ksp_buf = ksp_buf; a.ksp_cnt = ksp_cnt;
-        if (s.ln) { a.ln_c1 = gamma; a.stats_in = dstats; }
-        if (s.epi == kEpiQkv) { a.X = hres; a.out = qb; a.ldo = H; a.kv_layer = kv; a.row_meta = drm; }
-        else if (s.epi == kEpiBiasGelu) { a.X = hres; a.out = act; }
-        else if (s.epi == kEpiResidual) { a.X = s.K == 4096 ? act : att; a.out = hres; a.stats_out = dstats + 128 * 64; }
-        else { a.X = att; a.out = out; a.ldo = s.N; }
+        a.ksp_buf = B.ksp_buf; a.ksp_cnt = B.ksp_cnt;
+        if (s.ln) { a.ln_c1 = gamma; a.stats_in = B.dstats; }
+        if (s.epi == kEpiQkv) { a.X = B.hres; a.out = B.qb; a.ldo = H; a.kv_layer = kv; a.row_meta = B.drm; }
+        else if (s.epi == kEpiBiasGelu) { a.X = B.hres; a.out = B.act; }
+        else if (s.epi == kEpiResidual) { a.X = s.K == 4096 ? B.act : B.att; a.out = B.hres; a.stats_out = B.dstats + 128 * 64; }
+        else { a.X = B.att; a.out = out; a.ldo = s.N; }
         return a;
     };
+    auto make_args = [&](const Shape& s, const float* wt, int prec) { return make_args_b(s, wt, prec, B0); };
     {
         const float e_us = time_us(st, 2000, [&] { hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), 0, st, 0); });
         printf("empty 256-workgroup kernel, back to back: %.2f us per launch (host-bound floor of this loop)\n", e_us);
@@ -200,6 +217,48 @@ int main(int argc, char** argv) {
                 launch_gemm_rows(make_args(shapes[3], w2[l], prec), false, kEpiResidual, st);
             }
         };
+        if (getenv("DUAL")) {
+            // two chains of M rows each on two streams, enqueued layer by layer in turn (rows 0..M-1 and M..2M-1 of the row table: distinct
+            // K/V blocks; the same weights, a layer apart at most): do the launch boundaries of one chain hide under the other's data?
+            hipStream_t st2;
+            HIP_CHECK(hipStreamCreate(&st2));
+            auto layer = [&](int l, const Bufs& B, hipStream_t s_, int prec) {
+                float* kvl = kv + (size_t)l * kv_blocks * kKvBlockElems;
+                GemmRowsArgs a = make_args_b(shapes[0], wq[l], prec, B);
+                a.kv_layer = kvl;
+                launch_gemm_rows(a, true, kEpiQkv, s_);
+                launch_paged_attention(B.qb, kvl, B.drm, 66, B.att, M, s_, MTT, false);
+                launch_gemm_rows(make_args_b(shapes[1], wp[l], prec, B), false, kEpiResidual, s_);
+                launch_gemm_rows(make_args_b(shapes[2], wf[l], prec, B), true, kEpiBiasGelu, s_);
+                launch_gemm_rows(make_args_b(shapes[3], w2[l], prec, B), false, kEpiResidual, s_);
+            };
+            for (int stagger : {0, 2}) {
+                hipEvent_t e0, e1, e2;
+                HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); HIP_CHECK(hipEventCreate(&e2));
+                const int iters = 20;
+                for (int rep = 0; rep < 2; ++rep) {   // rep 0 = warm-up
+                    HIP_CHECK(hipDeviceSynchronize());
+                    HIP_CHECK(hipEventRecord(e0, st));
+                    HIP_CHECK(hipStreamWaitEvent(st2, e0, 0));
+                    for (int it = 0; it < iters; ++it)
+                        for (int l = 0; l < n_layers + stagger; ++l) {   // chain B runs `stagger` layers behind chain A
+                            if (l < n_layers) layer(l, B0, st, 1);
+                            if (l >= stagger) layer(l - stagger, B1, st2, 1);
+                        }
+                    HIP_CHECK(hipEventRecord(e1, st));
+                    HIP_CHECK(hipEventRecord(e2, st2));
+                    HIP_CHECK(hipEventSynchronize(e1));
+                    HIP_CHECK(hipEventSynchronize(e2));
+                }
+                float m1 = 0.f, m2 = 0.f;
+                HIP_CHECK(hipEventElapsedTime(&m1, e0, e1));
+                HIP_CHECK(hipEventElapsedTime(&m2, e0, e2));
+                const float us = (m1 > m2 ? m1 : m2) * 1000.f / iters;
+                printf("TWO chains of 30 x (qkv, attention, proj, fc, proj2) M=%d each on two streams, stagger %d layers, prec=1: %.1f us per layer pair (%.3f ms per step of %d rows)\n",
+                       M, stagger, us / n_layers, us / 1000, 2 * M);
+                fflush(stdout);
+            }
+        }
         for (int attn : {0, 1})
             for (int prec : {0, 1}) {
                 const float us = time_us(st, 20, [&] { chain(attn != 0, prec); });
