@@ -84,7 +84,7 @@ EXPORTS = [
     "aur_comm_info", "aur_conditioning_checksum",
     "aur_submit", "aur_step", "aur_poll_finished",
     "aur_release", "aur_cancel", "aur_vocode", "aur_sync", "aur_get_stats", "aur_reset_stats", "aur_set_profile", "aur_dbg_gemm", "aur_dbg_gemm_rows", "aur_dbg_gemm_rows_ksplit_stress", "aur_dbg_lane_xor_selftest",
-    "aur_dbg_layernorm", "aur_dbg_conv1d", "aur_dbg_conv1d_f16", "aur_dbg_prefill", "aur_dbg_sample",
+    "aur_dbg_paged_attention", "aur_dbg_layernorm", "aur_dbg_conv1d", "aur_dbg_conv1d_f16", "aur_dbg_prefill", "aur_dbg_sample",
 ]
 
 _lib = None
@@ -136,6 +136,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "aur_dbg_gemm_rows": [eng, fp, fp, fp, fp, fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32],
         "aur_dbg_gemm_rows_ksplit_stress": [eng, C.c_int32, C.c_int32, C.POINTER(C.c_int64)],
         "aur_dbg_lane_xor_selftest": [eng, C.c_int32, C.POINTER(C.c_int64)],
+        "aur_dbg_paged_attention": [eng, fp, fp, fp, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp],
         "aur_dbg_layernorm": [eng, fp, fp, fp, fp, C.c_int32],
         "aur_dbg_conv1d": [eng, fp, fp, fp, fp, fp, ip, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                            C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32],
@@ -485,6 +486,14 @@ class NativeEngine:
         bad = C.c_int64(-1)
         self._check(self.lib.aur_dbg_lane_xor_selftest(self.h, int(blocks), C.byref(bad)))
         return int(bad.value)
+
+    def dbg_paged_attention(self, q, k, v, ctx, shared=0, kv_half=False) -> np.ndarray:
+        """q [M][1024], k / v [M][ctx_max][1024], ctx [M] -> [M][1024]: the decode attention kernel on a paged pool built from k / v."""
+        q, k, v, ctx = _f32(q), _f32(k), _f32(v), _i32(ctx)
+        out = np.empty_like(q)
+        self._check(self.lib.aur_dbg_paged_attention(self.h, _fp(q), _fp(k), _fp(v), ctx.ctypes.data_as(C.POINTER(C.c_int32)), q.shape[0],
+                                                     k.shape[1], int(shared), int(bool(kv_half)), _fp(out)))
+        return out
 
     def dbg_layernorm(self, h, gamma, beta) -> np.ndarray:
         h, gamma, beta = _f32(h), _f32(gamma), _f32(beta)

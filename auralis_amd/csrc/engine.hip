@@ -1130,6 +1130,53 @@ public:
         HIP_CHECK(hipStreamSynchronize(st_voc_));
         return (long long)bad;
     }
+    void dbg_paged_attention(const float* q, const float* k, const float* v, const int* ctx, int M, int ctx_max, int shared, bool half,
+                             float* out) {
+        use();
+        AUR_REQUIRE(M >= 1 && M <= 256 && ctx_max >= 1 && ctx_max <= kMaxBlocks * kKvBlockTokens, "dbg_paged_attention: 1..256 rows, context 1..1056");
+        AUR_REQUIRE(shared == 0 || shared == 16 || shared == 32, "dbg_paged_attention: shared prefix of 0, 16 or 32 tokens");
+        const int n_shared = shared / kKvBlockTokens, per_row = (ctx_max + kKvBlockTokens - 1) / kKvBlockTokens;
+        const long n_blocks = 1 + n_shared + (long)M * per_row;   // (block 0 stays empty: what a table entry past a row's blocks names)
+        std::vector<int> rm((size_t)M * kRowMetaStride, 0);
+        std::vector<float> pool((size_t)n_blocks * kKvBlockElems, 0.f);
+        for (int m = 0; m < M; ++m) {
+            AUR_REQUIRE(ctx[m] >= 1 && ctx[m] <= ctx_max && ctx[m] >= shared, "dbg_paged_attention: ctx[m] in [max(1, shared), ctx_max]");
+            int* r = &rm[(size_t)m * kRowMetaStride];
+            for (int b = 0; b < per_row; ++b) r[kRowMetaBt + b] = b < n_shared ? 1 + b : 1 + n_shared + m * per_row + b;
+            r[0] = ctx[m] - 1;
+            r[1] = m;
+            r[kRowMetaWblk] = r[kRowMetaBt + (ctx[m] - 1) / kKvBlockTokens];
+            for (int t = 0; t < ctx[m]; ++t) {
+                const int src = t < shared ? 0 : m;   // the shared tokens are row 0's
+                const int blk = r[kRowMetaBt + t / kKvBlockTokens];
+                for (int kvi = 0; kvi < 2; ++kvi) {
+                    const float* row = (kvi ? v : k) + ((size_t)src * ctx_max + t) * kHidden;
+                    for (int h = 0; h < kHeads; ++h)
+                        // ([block][K|V][head][token in block][64], gpt_kernels.hip: kv_offset)
+                        std::memcpy(&pool[((((size_t)blk * 2 + kvi) * kHeads + h) * kKvBlockTokens + t % kKvBlockTokens) * kHeadDim],
+                                    row + h * kHeadDim, kHeadDim * sizeof(float));
+                }
+            }
+        }
+        DevBuf dq, dpool, drm, dout;
+        dq.ensure((size_t)M * kHidden * 4);
+        drm.ensure(rm.size() * 4);
+        dout.ensure((size_t)M * kHidden * 4);
+        HIP_CHECK(hipMemcpy(dq.p, q, (size_t)M * kHidden * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(drm.p, rm.data(), rm.size() * 4, hipMemcpyHostToDevice));
+        if (half) {
+            std::vector<_Float16> ph(pool.size());
+            for (size_t i = 0; i < pool.size(); ++i) ph[i] = (_Float16)pool[i];
+            dpool.ensure(ph.size() * 2);
+            HIP_CHECK(hipMemcpy(dpool.p, ph.data(), ph.size() * 2, hipMemcpyHostToDevice));
+        } else {
+            dpool.ensure(pool.size() * 4);
+            HIP_CHECK(hipMemcpy(dpool.p, pool.data(), pool.size() * 4, hipMemcpyHostToDevice));
+        }
+        launch_paged_attention(dq.as<float>(), dpool.p, drm.as<int>(), kMaxBlocks, dout.as<float>(), M, st_, 0, half);
+        HIP_CHECK(hipStreamSynchronize(st_));
+        HIP_CHECK(hipMemcpy(out, dout.p, (size_t)M * kHidden * 4, hipMemcpyDeviceToHost));
+    }
     void dbg_layernorm(const float* h, const float* gamma, const float* beta, float* out, int M) {
         use();
         DevBuf dh, dg, db, dout;
@@ -2553,6 +2600,16 @@ int aur_dbg_lane_xor_selftest(aur_engine* e, int32_t blocks, int64_t* mismatches
     CHECK_PTR(e);
     CHECK_PTR(mismatches_out);
     return guarded([&] { *mismatches_out = e->impl.dbg_lane_xor_selftest(blocks); });
+}
+int aur_dbg_paged_attention(aur_engine* e, const float* q, const float* k, const float* v, const int32_t* ctx, int32_t M, int32_t ctx_max,
+                            int32_t shared, int32_t kv_half, float* out) {
+    CHECK_PTR(e);
+    CHECK_PTR(q);
+    CHECK_PTR(k);
+    CHECK_PTR(v);
+    CHECK_PTR(ctx);
+    CHECK_PTR(out);
+    return guarded([&] { e->impl.dbg_paged_attention(q, k, v, ctx, M, ctx_max, shared, kv_half != 0, out); });
 }
 int aur_dbg_layernorm(aur_engine* e, const float* h, const float* gamma, const float* beta, float* out, int32_t M) {
     CHECK_PTR(e);

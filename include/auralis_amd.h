@@ -281,6 +281,12 @@ int aur_dbg_gemm_rows_ksplit_stress(aur_engine* e, int32_t M, int32_t iters, int
  * shuffles they replace, on `blocks` workgroups of pseudo-random words; *mismatches_out = results that differ bitwise (0 expected).
  * Test support: the reference has no counterpart (its reductions are torch's). */
 int aur_dbg_lane_xor_selftest(aur_engine* e, int32_t blocks, int64_t* mismatches_out);
+/* The decode attention kernel alone (models/xttsv2/components/vllm_mm_gpt.py:757-761: GPT2Attention over vLLM's paged K/V).
+ * q [M][1024]; row m attends ctx[m] >= 1 cached tokens whose keys / values are k, v [M][ctx_max][1024] (16 heads x 64 inside a token);
+ * the first `shared` tokens (0, 16 or 32; <= every ctx[m]) are taken from row 0 and live in blocks every row's table points to, as the
+ * speaker prefix does.  kv_half: the fp16 pool (values rounded to nearest on the way in).  out [M][1024].  Test support. */
+int aur_dbg_paged_attention(aur_engine* e, const float* q, const float* k, const float* v, const int32_t* ctx, int32_t M,
+                            int32_t ctx_max, int32_t shared, int32_t kv_half, float* out);
 /* out[M][1024] = LayerNorm(h) rows */
 int aur_dbg_layernorm(aur_engine* e, const float* h, const float* gamma, const float* beta, float* out,
                       int32_t M);

@@ -349,3 +349,64 @@ def test_sampler_top_p_cut_is_the_serial_cumulative_sum(eng):
                 a = eng.dbg_sample(lg.numpy(), T, p, 50, seed=808, step=step)     # survivors in one wave
                 b = eng.dbg_sample(lg.numpy(), T, p, 0, seed=808, step=step)      # all ids, serial cut
                 assert list(a) == list(b), (name, T, p, step, list(a), list(b))
+
+
+def _attention_f64(q, k, v, ctx):
+    """float64 restatement of GPT2Attention on a cached context (vllm_mm_gpt.py:757-761 -> vLLM paged attention): per head,
+    softmax(q . K^T / sqrt(64)) V over the row's first ctx[m] tokens."""
+    M = q.shape[0]
+    out = np.zeros((M, 1024), np.float64)
+    for m in range(M):
+        n = int(ctx[m])
+        qq = q[m].astype(np.float64).reshape(16, 64)
+        kk = k[m, :n].astype(np.float64).reshape(n, 16, 64)
+        vv = v[m, :n].astype(np.float64).reshape(n, 16, 64)
+        s = np.einsum("hd,nhd->hn", qq, kk) / 8.0
+        s -= s.max(axis=1, keepdims=True)
+        p = np.exp(s)
+        p /= p.sum(axis=1, keepdims=True)
+        out[m] = np.einsum("hn,nhd->hd", p, vv).reshape(1024)
+    return out
+
+
+def test_paged_attention_kernel_against_float64_ragged_shared_prefix_and_batch_invariance(eng):
+    from auralis_amd._lib import AurError
+    engine = eng
+    """The decode attention kernel alone (31 % of the GPU time of the bench; until round 6 it was held only through the end-to-end
+    goldens).  Fifteen rows whose contexts sit on every edge of its tiling -- 1 token, either side of a 16-token block, of the 64-token
+    iteration of a workgroup, the bench's 244, the 605-token budget + prompt, the table's full 1 056 -- with keys scaled so that the
+    softmax is peaked on some rows and flat on others:
+      * against a float64 restatement: <= 2e-6 of the output scale;
+      * a row alone == the row in the batch, bit for bit (batch invariance);
+      * the first 32 tokens in blocks shared by every row (the speaker prefix) == the same tokens in the rows' own blocks, bit for bit;
+      * the fp16 pool against float64 on the rounded keys / values: same tolerance."""
+    rng = np.random.default_rng(5)
+    ctx = np.array([1, 2, 15, 16, 17, 32, 33, 63, 64, 65, 128, 244, 640, 708, 1056], np.int32)
+    M, cmax = len(ctx), int(ctx.max())
+    q = rng.standard_normal((M, 1024)).astype(np.float32)
+    k = rng.standard_normal((M, cmax, 1024)).astype(np.float32)
+    v = rng.standard_normal((M, cmax, 1024)).astype(np.float32)
+    k[::2] *= 0.25           # every other row: nearly flat softmax; the others peaked (|q.k| / 8 ~ N(0, 1) * 8 / 8)
+    got = engine.dbg_paged_attention(q, k, v, ctx)
+    ref = _attention_f64(q, k, v, ctx)
+    err = np.abs(got - ref).max()
+    assert err <= 2e-6 * max(1.0, np.abs(ref).max()), err
+    for m in (0, 3, 7, 11, 14):
+        solo = engine.dbg_paged_attention(q[m:m + 1], k[m:m + 1, :ctx[m]], v[m:m + 1, :ctx[m]], ctx[m:m + 1])
+        assert np.array_equal(solo[0], got[m]), m
+    # shared prefix: rows with >= 32 tokens, the first 32 tokens of every row replaced by row 0's (what sharing means), once in
+    # private blocks and once in two blocks every table points to
+    rows = np.nonzero(ctx >= 32)[0]
+    qs, ks, vs, cs = q[rows], k[rows].copy(), v[rows].copy(), ctx[rows]
+    ks[:, :32] = ks[0, :32]
+    vs[:, :32] = vs[0, :32]
+    private = engine.dbg_paged_attention(qs, ks, vs, cs, shared=0)
+    shared = engine.dbg_paged_attention(qs, ks, vs, cs, shared=32)
+    assert np.array_equal(private, shared)
+    assert np.abs(shared - _attention_f64(qs, ks, vs, cs)).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+    # fp16 pool
+    got_h = engine.dbg_paged_attention(q, k, v, ctx, kv_half=True)
+    ref_h = _attention_f64(q, k.astype(np.float16).astype(np.float32), v.astype(np.float16).astype(np.float32), ctx)
+    assert np.abs(got_h - ref_h).max() <= 2e-6 * max(1.0, np.abs(ref_h).max())
+    with pytest.raises(AurError):
+        engine.dbg_paged_attention(q[:1], k[:1], v[:1], np.array([0], np.int32))
