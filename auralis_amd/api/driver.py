@@ -84,11 +84,15 @@ class EngineDriver:
         cancel = getattr(self.engine, "cancel", None)
         if known and cancel is not None:
             try:
-                cancel(sid)          # the engine still reports the sequence through poll(); _resolve drops it there
+                cancel(sid)          # the engine still reports the sequence through poll(); _resolve_all drops it there
                 self.cancelled += 1
             except Exception:        # noqa: BLE001 - already finished / released: nothing to stop
                 pass
             self._wake.set()
+
+    def _full_house(self) -> bool:
+        slots = getattr(self.engine, "max_seqs", None)
+        return bool(slots) and len(self._pending) >= int(slots)
 
     @staticmethod
     def _loop_busy(loop: asyncio.AbstractEventLoop) -> bool:
@@ -100,28 +104,34 @@ class EngineDriver:
         except TypeError:
             return False
 
-    def _resolve(self, item: dict, step_error: Optional[BaseException] = None):
+    def _resolve_all(self, items, step_error: Optional[BaseException] = None):
+        """Hand a poll's results to their futures: ONE call_soon_threadsafe per event loop (each one is a write to the loop's wake-up
+        pipe; 64 utterances finishing in one vocoder batch used to be 64 of them)."""
+        by_loop: Dict[asyncio.AbstractEventLoop, list] = {}
         with self._lock:
-            ent = self._pending.pop(item["seq_id"], None)
-        if ent is None:
-            lease = item.get("lease")
-            if lease is not None:      # nobody waits for it (cancelled / unknown id): give the block back at once
-                lease.release()
-            return
-        loop, fut = ent
+            ents = [(item, self._pending.pop(item["seq_id"], None)) for item in items]
+        for item, ent in ents:
+            if ent is None:
+                lease = item.get("lease")
+                if lease is not None:      # nobody waits for it (cancelled / unknown id): give the block back at once
+                    lease.release()
+                continue
+            by_loop.setdefault(ent[0], []).append((ent[1], item))
 
-        def done():
-            if fut.done():             # cancelled consumer: the result is dropped, the lease goes with it
-                return
-            if item.get("error"):
-                exc = RuntimeError(f"sequence {item['seq_id']} failed with code {item['error']}"
-                                   + (f": {step_error}" if step_error is not None else ""))
-                if step_error is not None:
-                    exc.__cause__ = step_error
-                fut.set_exception(exc)
-            else:
-                fut.set_result(item)
-        loop.call_soon_threadsafe(done)
+        def done(pairs):
+            for fut, item in pairs:
+                if fut.done():             # cancelled consumer: the result is dropped, the lease goes with it
+                    continue
+                if item.get("error"):
+                    exc = RuntimeError(f"sequence {item['seq_id']} failed with code {item['error']}"
+                                       + (f": {step_error}" if step_error is not None else ""))
+                    if step_error is not None:
+                        exc.__cause__ = step_error
+                    fut.set_exception(exc)
+                else:
+                    fut.set_result(item)
+        for loop, pairs in by_loop.items():
+            loop.call_soon_threadsafe(done, pairs)
 
     def _fail_all(self, exc: BaseException):
         with self._lock:
@@ -132,8 +142,8 @@ class EngineDriver:
     def _drain(self, step_error: Optional[BaseException] = None):
         while True:                    # a vocoder batch (or a failed step) can finish more than one poll's worth at once
             got = self.engine.poll(cap=64, copy=False)
-            for item in got:
-                self._resolve(item, step_error)
+            if got:
+                self._resolve_all(got, step_error)
             if len(got) < 64:
                 return
 
@@ -152,6 +162,8 @@ class EngineDriver:
             while not self._stop:     # the burst that woke an idle engine is still arriving
                 now = time.perf_counter()
                 if self._urgent or now >= t_end:
+                    break
+                if self._full_house():     # every slot is spoken for: whatever arrives next waits for a free one anyway
                     break
                 # quiet for burst_gap_s AND the submitting loop has nothing queued: a loop thread that stalls in the middle of a burst
                 # (a garbage collection, a slow tokenizer call) still has the other requests' tasks in its ready queue
