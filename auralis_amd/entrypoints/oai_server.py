@@ -20,7 +20,7 @@ import json
 import uuid
 from typing import Any, Dict, List, Literal, Optional
 
-from fastapi import FastAPI, Header, HTTPException
+from fastapi import FastAPI, Header, HTTPException, Request
 from fastapi.responses import JSONResponse, Response, StreamingResponse
 from pydantic import BaseModel, Field, field_validator
 
@@ -141,20 +141,47 @@ class VoiceChatCompletionRequest(BaseModel):
         return d
 
 
+class ClientDisconnected(Exception):
+    pass
+
+
+async def run_unless_disconnected(http_request: Any, awaitable, poll_s: float = 0.1):
+    """Await `awaitable` while the HTTP client is still there.  A plain (non-streaming) ASGI handler is not cancelled when its client
+    goes away -- the server only queues an `http.disconnect` message -- so the request would be synthesised to the end for nobody
+    (the reference does exactly that).  Here the connection is polled (`Request.is_disconnected`) beside the work; when the client has
+    gone the work is cancelled, which reaches the engine as aur_cancel for every chunk that is still queued or decoding
+    (api/scheduler.py, api/driver.py).  `http_request` = None: no watcher."""
+    task = asyncio.ensure_future(awaitable)
+    if http_request is None:
+        return await task
+    try:
+        while True:
+            done, _ = await asyncio.wait({task}, timeout=poll_s)
+            if done:
+                return task.result()
+            if await http_request.is_disconnected():
+                raise ClientDisconnected()
+    finally:
+        if not task.done():
+            task.cancel()
+
+
 def create_app(tts: Optional[TTS]) -> FastAPI:
     app = FastAPI(title="auralis_amd TTS server")
     app.state.tts = tts
 
     @app.post("/v1/audio/speech")
-    async def generate_audio(request: AudioSpeechGenerationRequest):
+    async def generate_audio(request: AudioSpeechGenerationRequest, http_request: Request):
         engine: Optional[TTS] = app.state.tts
         if engine is None or engine.tts_engine is None:
             raise HTTPException(status_code=500, detail="TTS engine not initialized")
         try:
-            import asyncio
             # the facade owns its own event loop thread: hop over to it and await the result here
             fut = asyncio.run_coroutine_threadsafe(engine.generate_speech_async(request.to_tts_request()), engine._loop)
-            output = await asyncio.wrap_future(fut)
+            try:
+                output = await run_unless_disconnected(http_request, asyncio.wrap_future(fut))
+            except ClientDisconnected:
+                return Response(status_code=499)   # (nobody reads it; nginx's "client closed request")
             if request.speed != 1.0:
                 output = output.change_speed(request.speed)
             data = output.to_bytes(request.response_format)

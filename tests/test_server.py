@@ -148,3 +148,50 @@ def test_chat_completions_proxy_streams_text_and_audio():
         tts.close()
         loop.call_soon_threadsafe(loop.stop)
         th.join(timeout=5)
+
+
+def test_speech_request_of_a_client_that_disconnected_is_cancelled_in_the_engine():
+    """POST /v1/audio/speech is a plain response: the ASGI server does not cancel its handler when the client goes away.  The route
+    polls the connection beside the work (`run_unless_disconnected`); here a long request (a dozen chunks on a one-slot engine that
+    takes 20 ms per step) whose client reports a disconnect after the second poll: the handler gives up, the chunks still queued or
+    decoding are cancelled in the engine, and the next request is served."""
+    import asyncio
+    import time
+
+    from auralis_amd import TTSRequest
+    from auralis_amd.entrypoints.oai_server import ClientDisconnected, run_unless_disconnected
+    fake = FakeNativeEngine(max_seqs=1, step_delay=0.02)
+    tts = TTS(scheduler_max_concurrency=2).with_engine(XTTSv2Engine(fake, XTTSTokenizer(None, synthetic=True)))
+    voice = {"gpt_cond_latent": np.zeros((1, 32, 1024), np.float32), "speaker_embedding": np.ones((1, 512, 1), np.float32)}
+    text = " ".join(["It was a bright cold day in April, and the clocks were striking thirteen. Nobody in the street seemed to notice, "
+                     "and the wind kept pushing the dust along the old road as if nothing had happened at all."] * 12)
+
+    class Gone:
+        polls = 0
+
+        async def is_disconnected(self):
+            Gone.polls += 1
+            return Gone.polls >= 2
+
+    async def handler():
+        fut = asyncio.run_coroutine_threadsafe(tts.generate_speech_async(TTSRequest(text=text, speaker_files=[voice], language="en")), tts._loop)
+        return await run_unless_disconnected(Gone(), asyncio.wrap_future(fut), poll_s=0.05)
+    try:
+        with pytest.raises(ClientDisconnected):
+            asyncio.run(handler())
+        n = len(fake.submitted)
+        assert n >= 10
+        t0 = time.time()
+        while (fake.finished_total < n or tts.tts_engine.driver._pending) and time.time() - t0 < 10:
+            time.sleep(0.01)
+        assert len(fake.cancelled) >= n - 5 and not fake.waiting and not fake.running, (n, fake.cancelled)
+
+        async def served():   # a client that stays: the same helper returns the result
+            class Here:
+                async def is_disconnected(self):
+                    return False
+            fut = asyncio.run_coroutine_threadsafe(tts.generate_speech_async(TTSRequest(text="Still here.", speaker_files=[voice], language="en")), tts._loop)
+            return await run_unless_disconnected(Here(), asyncio.wrap_future(fut), poll_s=0.01)
+        assert len(asyncio.run(served()).array) > 0
+    finally:
+        tts.close()
