@@ -1784,7 +1784,6 @@ private:
             finish_cancelled(s);
             return;
         }
-        s->state = SeqState::TOKENS_DONE;
         // park the stashed latents in the pool (D2D on the main stream, ordered before any later prefill that reuses
         // the slot) and release slot + KV blocks at once: the vocoder stage no longer occupies a batcher slot
         if (s->pool_idx < 0) {   // (the second-pass mode has already written the pool entry)
@@ -1797,6 +1796,7 @@ private:
         }
         HIP_CHECK(hipEventRecord(ev_lat_, st_));
         std::lock_guard<std::mutex> lk(mu_);
+        s->state = SeqState::TOKENS_DONE;   // (under the lock: aur_cancel reads the state from another thread)
         for (int b : s->blocks) free_blocks_.push_back(b);
         s->blocks.clear();
         slot_owner_[s->slot] = nullptr;
