@@ -107,7 +107,7 @@ class TTS:
             return [c async for c in self.scheduler.run(inputs=sub, request_id=sub.request_id,
                                                         first_phase_fn=self._prepare_generation_context,
                                                         second_phase_fn=self._second_phase_fn)]
-        parts = await asyncio.gather(*[one(s) for s in subs])
+        parts = [await one(subs[0])] if len(subs) == 1 else await asyncio.gather(*[one(s) for s in subs])   # (no task for the usual case)
         return TTSOutput.combine_outputs([c for p in parts for c in p])
 
     def _submit(self, coro):

@@ -200,11 +200,11 @@ def test_driver_cancels_the_sequence_of_a_consumer_that_walked_away():
     """a streaming consumer that disconnects cancels its chunk futures; the driver then stops those sequences in the
     engine (aur_cancel) instead of letting them decode to the end and be vocoded for nobody.  The others are untouched."""
     async def main():
-        eng = FakeNativeEngine(max_seqs=2)
+        eng = FakeNativeEngine(max_seqs=2, step_delay=0.01)   # (slow enough that nothing has finished when the cancellations arrive)
         eng.set_conditioning(1, COND["gpt_cond_latent"], COND["speaker_embedding"])
         d = EngineDriver(eng)
         loop = asyncio.get_running_loop()
-        futs = [d.submit(loop, text_ids=[4, 5 * i, 0], speaker_key=1) for i in range(6)]   # 5 steps each on 2 slots
+        futs = [d.submit(loop, text_ids=[4, 5 * i, 0], speaker_key=1) for i in range(6)]   # 1-5 steps each on 2 slots
         futs[1].cancel()           # running (or about to)
         futs[4].cancel()           # still waiting for a slot
         res = await asyncio.gather(*futs, return_exceptions=True)
