@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 6 experiment: the K = 4096 projection at 33-64 rows on a K split with wider row tiles (-DAUR_P2_SHAPE=1|2|3) against the product
 # shape, same box, interleaved.  usage: bash tools/p2_shape_bench.sh <tag> [M ...]   -> gpurun_out/p2_shape_<tag>.log
+# (the switch it drives is not in the tree: `git apply tools/experiments/gemm_rows_ksplit_wide.patch` first -- tools/experiments/README.md)
 exec < /dev/null
 TAG=${1:-a}; shift
 mkdir -p gpurun_out

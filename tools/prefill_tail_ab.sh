@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 6: the last, quarter-full round of the prompt-row FC / mlp-projection GEMMs on smaller tiles in a second launch on the SAME stream
 # (AUR_PREFILL_TAIL=1, default) against one launch (=0): same box, interleaved.  -> gpurun_out/prefill_tail_ab_<tag>.log
+# (the switch it drives is not in the tree: `git apply tools/experiments/prefill_tail_same_stream.patch` first -- tools/experiments/README.md)
 exec < /dev/null
 TAG=${1:-a}
 mkdir -p gpurun_out
