@@ -84,7 +84,7 @@ EXPORTS = [
     "aur_comm_info", "aur_conditioning_checksum",
     "aur_submit", "aur_step", "aur_poll_finished",
     "aur_release", "aur_cancel", "aur_vocode", "aur_sync", "aur_get_stats", "aur_reset_stats", "aur_set_profile", "aur_dbg_gemm", "aur_dbg_gemm_rows", "aur_dbg_gemm_rows_ksplit_stress", "aur_dbg_lane_xor_selftest",
-    "aur_dbg_paged_attention", "aur_dbg_layernorm", "aur_dbg_conv1d", "aur_dbg_conv1d_f16", "aur_dbg_prefill", "aur_dbg_sample",
+    "aur_dbg_paged_attention", "aur_dbg_prompt_attention", "aur_dbg_layernorm", "aur_dbg_conv1d", "aur_dbg_conv1d_f16", "aur_dbg_prefill", "aur_dbg_sample",
 ]
 
 _lib = None
@@ -137,6 +137,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "aur_dbg_gemm_rows_ksplit_stress": [eng, C.c_int32, C.c_int32, C.POINTER(C.c_int64)],
         "aur_dbg_lane_xor_selftest": [eng, C.c_int32, C.POINTER(C.c_int64)],
         "aur_dbg_paged_attention": [eng, fp, fp, fp, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp],
+        "aur_dbg_prompt_attention": [eng, fp, fp, fp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, fp],
         "aur_dbg_layernorm": [eng, fp, fp, fp, fp, C.c_int32],
         "aur_dbg_conv1d": [eng, fp, fp, fp, fp, fp, ip, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                            C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32],
@@ -493,6 +495,15 @@ class NativeEngine:
         out = np.empty_like(q)
         self._check(self.lib.aur_dbg_paged_attention(self.h, _fp(q), _fp(k), _fp(v), ctx.ctypes.data_as(C.POINTER(C.c_int32)), q.shape[0],
                                                      k.shape[1], int(shared), int(bool(kv_half)), _fp(out)))
+        return out
+
+    def dbg_prompt_attention(self, q, k, v, row_seq, row_pos, shared=0, kv_half=False) -> np.ndarray:
+        """q [M][1024], k / v [n_seq][ctx_max][1024], row_seq / row_pos [M] -> [M][1024]: the prefill attention kernel on a paged pool."""
+        q, k, v, row_seq, row_pos = _f32(q), _f32(k), _f32(v), _i32(row_seq), _i32(row_pos)
+        out = np.empty_like(q)
+        ip = C.POINTER(C.c_int32)
+        self._check(self.lib.aur_dbg_prompt_attention(self.h, _fp(q), _fp(k), _fp(v), row_seq.ctypes.data_as(ip), row_pos.ctypes.data_as(ip),
+                                                      q.shape[0], k.shape[0], k.shape[1], int(shared), int(bool(kv_half)), _fp(out)))
         return out
 
     def dbg_layernorm(self, h, gamma, beta) -> np.ndarray:

@@ -1177,6 +1177,59 @@ public:
         HIP_CHECK(hipStreamSynchronize(st_));
         HIP_CHECK(hipMemcpy(out, dout.p, (size_t)M * kHidden * 4, hipMemcpyDeviceToHost));
     }
+    void dbg_prompt_attention(const float* q, const float* k, const float* v, const int* row_seq, const int* row_pos, int M, int n_seq,
+                              int ctx_max, int shared, bool half, float* out) {
+        use();
+        AUR_REQUIRE(M >= 1 && M <= 8192 && n_seq >= 1 && n_seq <= 64 && ctx_max >= 1 && ctx_max <= kMaxBlocks * kKvBlockTokens,
+                    "dbg_prompt_attention: 1..8192 rows, 1..64 sequences, context 1..1056");
+        AUR_REQUIRE(shared == 0 || shared == 16 || shared == 32, "dbg_prompt_attention: shared prefix of 0, 16 or 32 tokens");
+        const int n_shared = shared / kKvBlockTokens, per_seq = (ctx_max + kKvBlockTokens - 1) / kKvBlockTokens;
+        const long n_blocks = 1 + n_shared + (long)n_seq * per_seq;
+        std::vector<int> bt((size_t)n_seq * kMaxBlocks, 0);
+        std::vector<float> pool((size_t)n_blocks * kKvBlockElems, 0.f);
+        for (int sq = 0; sq < n_seq; ++sq) {
+            for (int b = 0; b < per_seq; ++b) bt[(size_t)sq * kMaxBlocks + b] = b < n_shared ? 1 + b : 1 + n_shared + sq * per_seq + b;
+            for (int t = 0; t < ctx_max; ++t) {
+                const int src = t < shared ? 0 : sq;
+                const int blk = bt[(size_t)sq * kMaxBlocks + t / kKvBlockTokens];
+                for (int kvi = 0; kvi < 2; ++kvi) {
+                    const float* row = (kvi ? v : k) + ((size_t)src * ctx_max + t) * kHidden;
+                    for (int h = 0; h < kHeads; ++h)
+                        std::memcpy(&pool[((((size_t)blk * 2 + kvi) * kHeads + h) * kKvBlockTokens + t % kKvBlockTokens) * kHeadDim],
+                                    row + h * kHeadDim, kHeadDim * sizeof(float));
+                }
+            }
+        }
+        std::vector<int> rs(row_seq, row_seq + M), rp(row_pos, row_pos + M);
+        for (int m = 0; m < M; ++m)
+            AUR_REQUIRE(rs[m] >= 0 && rs[m] < n_seq && rp[m] >= 0 && rp[m] < ctx_max, "dbg_prompt_attention: row_seq / row_pos out of range");
+        RowWs w;
+        w.st = st_;
+        const int n_qblk = upload_qblocks(w, rs, rp);
+        DevBuf dq, dpool, dbt, drs, drp, dout;
+        dq.ensure((size_t)M * kHidden * 4);
+        dout.ensure((size_t)M * kHidden * 4);
+        dbt.ensure(bt.size() * 4);
+        drs.ensure((size_t)M * 4);
+        drp.ensure((size_t)M * 4);
+        HIP_CHECK(hipMemcpy(dq.p, q, (size_t)M * kHidden * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dbt.p, bt.data(), bt.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(drs.p, rs.data(), (size_t)M * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(drp.p, rp.data(), (size_t)M * 4, hipMemcpyHostToDevice));
+        if (half) {
+            std::vector<_Float16> ph(pool.size());
+            for (size_t i = 0; i < pool.size(); ++i) ph[i] = (_Float16)pool[i];
+            dpool.ensure(ph.size() * 2);
+            HIP_CHECK(hipMemcpy(dpool.p, ph.data(), ph.size() * 2, hipMemcpyHostToDevice));
+        } else {
+            dpool.ensure(pool.size() * 4);
+            HIP_CHECK(hipMemcpy(dpool.p, pool.data(), pool.size() * 4, hipMemcpyHostToDevice));
+        }
+        launch_prompt_attention(dq.as<float>(), dpool.p, w.i_qblk.as<int2>(), n_qblk, drs.as<int>(), drp.as<int>(), dbt.as<int>(), kMaxBlocks,
+                                dout.as<float>(), st_, half);
+        HIP_CHECK(hipStreamSynchronize(st_));
+        HIP_CHECK(hipMemcpy(out, dout.p, (size_t)M * kHidden * 4, hipMemcpyDeviceToHost));
+    }
     void dbg_layernorm(const float* h, const float* gamma, const float* beta, float* out, int M) {
         use();
         DevBuf dh, dg, db, dout;
@@ -2610,6 +2663,17 @@ int aur_dbg_paged_attention(aur_engine* e, const float* q, const float* k, const
     CHECK_PTR(ctx);
     CHECK_PTR(out);
     return guarded([&] { e->impl.dbg_paged_attention(q, k, v, ctx, M, ctx_max, shared, kv_half != 0, out); });
+}
+int aur_dbg_prompt_attention(aur_engine* e, const float* q, const float* k, const float* v, const int32_t* row_seq, const int32_t* row_pos,
+                             int32_t M, int32_t n_seq, int32_t ctx_max, int32_t shared, int32_t kv_half, float* out) {
+    CHECK_PTR(e);
+    CHECK_PTR(q);
+    CHECK_PTR(k);
+    CHECK_PTR(v);
+    CHECK_PTR(row_seq);
+    CHECK_PTR(row_pos);
+    CHECK_PTR(out);
+    return guarded([&] { e->impl.dbg_prompt_attention(q, k, v, row_seq, row_pos, M, n_seq, ctx_max, shared, kv_half != 0, out); });
 }
 int aur_dbg_layernorm(aur_engine* e, const float* h, const float* gamma, const float* beta, float* out, int32_t M) {
     CHECK_PTR(e);

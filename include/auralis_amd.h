@@ -287,6 +287,13 @@ int aur_dbg_lane_xor_selftest(aur_engine* e, int32_t blocks, int64_t* mismatches
  * speaker prefix does.  kv_half: the fp16 pool (values rounded to nearest on the way in).  out [M][1024].  Test support. */
 int aur_dbg_paged_attention(aur_engine* e, const float* q, const float* k, const float* v, const int32_t* ctx, int32_t M,
                             int32_t ctx_max, int32_t shared, int32_t kv_half, float* out);
+/* The prompt-row (prefill) attention kernel alone.  n_seq sequences with keys / values k, v [n_seq][ctx_max][1024]; M query rows
+ * q [M][1024], row m belongs to sequence row_seq[m] and sits at position row_pos[m] (it attends that sequence's tokens 0..row_pos[m]);
+ * consecutive rows of one sequence with positions ascending by one form the kernel's query blocks (cut every 32 rows), exactly as the
+ * engine's prefill builds them.  The first `shared` tokens (0, 16 or 32) are sequence 0's and live in blocks every table points to.
+ * out [M][1024].  Test support. */
+int aur_dbg_prompt_attention(aur_engine* e, const float* q, const float* k, const float* v, const int32_t* row_seq, const int32_t* row_pos,
+                             int32_t M, int32_t n_seq, int32_t ctx_max, int32_t shared, int32_t kv_half, float* out);
 /* out[M][1024] = LayerNorm(h) rows */
 int aur_dbg_layernorm(aur_engine* e, const float* h, const float* gamma, const float* beta, float* out,
                       int32_t M);

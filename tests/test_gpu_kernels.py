@@ -410,3 +410,45 @@ def test_paged_attention_kernel_against_float64_ragged_shared_prefix_and_batch_i
     assert np.abs(got_h - ref_h).max() <= 2e-6 * max(1.0, np.abs(ref_h).max())
     with pytest.raises(AurError):
         engine.dbg_paged_attention(q[:1], k[:1], v[:1], np.array([0], np.int32))
+
+
+def test_prompt_attention_kernel_against_float64_query_blocks_shared_prefix_and_batch_invariance(eng):
+    """The prefill attention kernel alone (exact-f32 MFMA tiles over query blocks of up to 32 consecutive rows of one sequence): a full
+    prompt from position 0 (103 rows = blocks of 32, 32, 32, 7), a prompt whose first 32 positions are somebody else's (rows start at
+    position 32, as with the shared speaker prefix), one lone row deep in a context, a 41-row prompt; causal mask per element.
+      * against a float64 restatement: <= 2e-6 of the output scale;
+      * a sequence's rows alone == the same rows in the batch, bit for bit;
+      * the first 32 tokens in shared blocks == the same tokens in private blocks, bit for bit;
+      * the fp16 pool against float64 on the rounded keys / values."""
+    rng = np.random.default_rng(9)
+    n_seq, cmax = 4, 200
+    k = rng.standard_normal((n_seq, cmax, 1024)).astype(np.float32)
+    v = rng.standard_normal((n_seq, cmax, 1024)).astype(np.float32)
+    k[1] *= 0.25
+    spans = [(0, 0, 103), (1, 32, 111), (2, 150, 151), (3, 0, 41)]          # (sequence, first position, one past the last)
+    row_seq = np.concatenate([np.full(b - a, s_, np.int32) for s_, a, b in spans])
+    row_pos = np.concatenate([np.arange(a, b, dtype=np.int32) for _, a, b in spans])
+    M = len(row_seq)
+    q = rng.standard_normal((M, 1024)).astype(np.float32)
+
+    def ref64(q_, k_, v_, rs, rp):
+        kk = np.stack([k_[s_] for s_ in rs])
+        vv = np.stack([v_[s_] for s_ in rs])
+        return _attention_f64(q_, kk, vv, rp + 1)
+    got = eng.dbg_prompt_attention(q, k, v, row_seq, row_pos)
+    ref = ref64(q, k, v, row_seq, row_pos)
+    scale = max(1.0, np.abs(ref).max())
+    assert np.abs(got - ref).max() <= 2e-6 * scale, np.abs(got - ref).max()
+    sel = row_seq == 1                                                        # sequence 1 alone, as sequence 0 of its own launch
+    solo = eng.dbg_prompt_attention(q[sel], k[1:2], v[1:2], np.zeros(sel.sum(), np.int32), row_pos[sel])
+    assert np.array_equal(solo, got[sel])
+    ks, vs = k.copy(), v.copy()
+    ks[:, :32] = ks[0, :32]
+    vs[:, :32] = vs[0, :32]
+    private = eng.dbg_prompt_attention(q, ks, vs, row_seq, row_pos, shared=0)
+    shared = eng.dbg_prompt_attention(q, ks, vs, row_seq, row_pos, shared=32)
+    assert np.array_equal(private, shared)
+    assert np.abs(shared - ref64(q, ks, vs, row_seq, row_pos)).max() <= 2e-6 * scale
+    got_h = eng.dbg_prompt_attention(q, k, v, row_seq, row_pos, kv_half=True)
+    ref_h = ref64(q, k.astype(np.float16).astype(np.float32), v.astype(np.float16).astype(np.float32), row_seq, row_pos)
+    assert np.abs(got_h - ref_h).max() <= 2e-6 * max(1.0, np.abs(ref_h).max())
